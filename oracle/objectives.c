@@ -1,0 +1,121 @@
+/*
+ * oracle/objectives.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * Test / benchmark objectives in the oracle's evaluate-callback form
+ * (E: FnMut(&[f64], &mut [f64]) -> Result<f64>, reference src/core.rs:12).
+ *
+ *  - Rosenbrock: the reference's default_evaluate (src/lib.rs:79-94,
+ *    benches/rosenbrock.rs:16-29).
+ *  - Lennard-Jones all-pairs: the user objective of examples/lj.rs:20-64,113-118.
+ *  - Hashed diagonal quadratic / separable logistic: the SYNTHETIC workloads of
+ *    BASELINE.json configs 2-4 (not in the reference).  Their data is a
+ *    counter-based hash of the GLOBAL element index, built from + and * only,
+ *    so CPU, GPU and every shard generate bit-identical inputs with nothing to
+ *    store.  The same formulas are restated in HIP in
+ *    rust-lbfgs_amd/csrc/objectives.hip (product side, independent code).
+ */
+#include "lbfgs_oracle.h"
+
+#include <math.h>
+
+/* src/lib.rs:79-94 */
+double oracle_obj_rosenbrock(void* user, const double* x, double* g, size_t n, int* failed) {
+    (void)user;
+    (void)failed;
+    double fx = 0.0;
+    for (size_t i = 0; i + 1 < n; i += 2) {
+        double t1 = 1.0 - x[i];
+        double t2 = 10.0 * (x[i + 1] - x[i] * x[i]);
+        g[i + 1] = 20.0 * t2;
+        g[i] = -2.0 * (x[i] * g[i + 1] + t1);
+        fx += t1 * t1 + t2 * t2;
+    }
+    return fx;
+}
+
+/* splitmix64 finaliser applied to a counter: state = seed + (i+1)*golden */
+static uint64_t mix64(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+double oracle_hash_u01(uint64_t seed, uint64_t i) {
+    return (double)(mix64(seed, i) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* f = sum_i x_i*(0.5*a_i*x_i - b_i),  g_i = a_i*x_i - b_i
+ * a_i = 1 + 999*u_a^2 (condition number 1e3), b_i = 2*u_b - 1 */
+double oracle_obj_quadratic(void* user, const double* x, double* g, size_t n, int* failed) {
+    const oracle_hashed_obj* o = (const oracle_hashed_obj*)user;
+    (void)failed;
+    double fx = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t gi = o->global_offset + i;
+        double ua = oracle_hash_u01(o->seed_a, gi);
+        double ub = oracle_hash_u01(o->seed_b, gi);
+        double a = 1.0 + 999.0 * (ua * ua);
+        double b = 2.0 * ub - 1.0;
+        double t = a * x[i];
+        g[i] = t - b;
+        fx += x[i] * (0.5 * t - b);
+    }
+    return fx;
+}
+
+/* f = sum_i log(1 + exp(-z_i)), z_i = w_i*x_i, w_i = t_i*a_i,
+ * a_i = 0.5 + 1.5*u_a, t_i = +1 if top hash bit of (seed_b, i) set else -1
+ * g_i = -w_i / (1 + exp(z_i)) */
+double oracle_obj_logistic(void* user, const double* x, double* g, size_t n, int* failed) {
+    const oracle_hashed_obj* o = (const oracle_hashed_obj*)user;
+    (void)failed;
+    double fx = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t gi = o->global_offset + i;
+        double a = 0.5 + 1.5 * oracle_hash_u01(o->seed_a, gi);
+        double w = (mix64(o->seed_b, gi) >> 63) ? a : -a;
+        double z = w * x[i];
+        double e = exp(-fabs(z));
+        double fi = log1p(e);
+        double sig; /* 1/(1+exp(z)) */
+        if (z >= 0.0) {
+            sig = e / (1.0 + e);
+        } else {
+            sig = 1.0 / (1.0 + e);
+            fi -= z;
+        }
+        g[i] = -w * sig;
+        fx += fi;
+    }
+    return fx;
+}
+
+/* examples/lj.rs:20-64 with epsilon = sigma = 1, then gx.vecscale(-1.0) (:116) */
+double oracle_obj_lj(void* user, const double* x, double* g, size_t n, int* failed) {
+    (void)user;
+    (void)failed;
+    size_t na = n / 3;
+    double energy = 0.0;
+    for (size_t i = 0; i < n; ++i) g[i] = 0.0;
+    for (size_t i = 0; i < na; ++i) {
+        for (size_t j = 0; j < i; ++j) {
+            double dx = x[3 * i] - x[3 * j];
+            double dy = x[3 * i + 1] - x[3 * j + 1];
+            double dz = x[3 * i + 2] - x[3 * j + 2];
+            double r = sqrt(dx * dx + dy * dy + dz * dz);
+            double q = 1.0 / r;
+            double s2 = q * q;
+            double s6 = s2 * s2 * s2;
+            energy += 4.0 * (s6 * s6 - s6);                 /* pair_energy  :22-25 */
+            double gr = 24.0 * (s6 - 2.0 * (s6 * s6)) / r;  /* pair_gradient :28-32 */
+            for (int k = 0; k < 3; ++k) {
+                double dr = x[3 * j + k] - x[3 * i + k];
+                g[3 * i + k] += 1.0 * gr * dr / r;
+                g[3 * j + k] += -1.0 * gr * dr / r;
+            }
+        }
+    }
+    for (size_t i = 0; i < n; ++i) g[i] *= -1.0;
+    return energy;
+}
