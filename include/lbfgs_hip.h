@@ -1,0 +1,250 @@
+/*
+ * include/lbfgs_hip.h -- C-ABI of the MI355X-native L-BFGS / OWL-QN vector backend.
+ *
+ * This is the drop-in boundary for the hot path of ybyygu/rust-lbfgs (crate
+ * `liblbfgs` v0.2.0).  The reference has NO FFI: its seam
+ * is `trait LbfgsMath` (src/math.rs:4-29) plus raw loops in src/core.rs,
+ * src/lbfgs.rs and src/orthantwise.rs.  Every entry point below names the
+ * reference function (file:line, relative to the crate root) whose body a Rust
+ * maintainer would replace by the call; INTEGRATION.md shows the `extern "C"`
+ * block and the shim.
+ *
+ * Conventions
+ *  - plain C, no torch / HIP types in signatures (a stream is passed as void*);
+ *  - every function returns an int status (0 = ok, <0 = error, see below) and
+ *    never unwinds; lbfgs_hip_last_error() gives the message;
+ *  - all n-vectors are f64 and live in HBM for their whole life; the host sees
+ *    them only through upload/download;
+ *  - reductions (dot, norms, L1 sum) leave their result in a device-resident
+ *    SCALAR BOARD (an array of LBFGS_HIP_BOARD_SLOTS doubles owned by the
+ *    context); the caller names the slot(s).  Consumers on the device (axpy with
+ *    a device coefficient, the two-loop) read the board directly, so a dependent
+ *    chain of reductions needs no host round trip.  lbfgs_hip_scalars_read()
+ *    is the only call that synchronises the stream;
+ *  - with world > 1 the n-vector is sharded contiguously (one process per GPU);
+ *    every reduction is closed by a sum all-reduce of its f64 scalars before it
+ *    becomes visible in the board, so board values are GLOBAL on every rank;
+ *  - element-wise arithmetic keeps the reference's roundings (mul then add, no
+ *    FMA contraction); only the summation ORDER of reductions differs from the
+ *    reference's sequential sum (src/math.rs:41).  It is a fixed tree: results
+ *    are deterministic for a given (n, world).
+ */
+#ifndef LBFGS_HIP_H
+#define LBFGS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBFGS_HIP_ABI_VERSION 1
+#define LBFGS_HIP_BOARD_SLOTS 256
+
+/* status codes */
+enum {
+    LBFGS_HIP_OK = 0,
+    LBFGS_HIP_ERR_ARG = -101,      /* bad argument (null handle, size mismatch, slot out of range) */
+    LBFGS_HIP_ERR_HIP = -102,      /* a HIP runtime call failed */
+    LBFGS_HIP_ERR_COMM = -103,     /* RCCL / callback all-reduce failed */
+    LBFGS_HIP_ERR_NOMEM = -104,
+    LBFGS_HIP_ERR_NO_DEVICE = -105 /* no usable GPU: there is no CPU fallback */
+};
+
+typedef struct lbfgs_hip_ctx lbfgs_hip_ctx;         /* device, stream, board, communicator */
+typedef struct lbfgs_hip_vec lbfgs_hip_vec;         /* this rank's shard of one n-vector    */
+typedef struct lbfgs_hip_history lbfgs_hip_history; /* the m (s, y, ys, alpha) corrections  */
+
+/* contiguous shard [offset, offset + n_local) of a global vector of n_global */
+typedef struct lbfgs_hip_shard {
+    int32_t rank, world;
+    uint64_t n_global;
+    uint64_t offset;
+    uint64_t n_local;
+} lbfgs_hip_shard;
+
+/* how reductions are closed across ranks */
+enum {
+    LBFGS_HIP_COMM_NONE = 0,     /* world == 1 */
+    LBFGS_HIP_COMM_RCCL = 1,     /* ncclAllReduce(ncclDouble, ncclSum) on the context's stream */
+    LBFGS_HIP_COMM_CALLBACK = 2  /* host callback (e.g. torch.distributed/gloo); stages through pinned memory */
+};
+/* in-place sum all-reduce of `count` doubles in host memory; return 0 on success */
+typedef int (*lbfgs_hip_allreduce_cb)(void* user, double* buf, int32_t count);
+
+typedef struct lbfgs_hip_comm {
+    int32_t kind;
+    int32_t _pad;
+    const void* rccl_unique_id;  /* 128 bytes from lbfgs_hip_rccl_unique_id() on rank 0, shared out of band */
+    lbfgs_hip_allreduce_cb callback;
+    void* callback_user;
+} lbfgs_hip_comm;
+
+/* ------------------------------------------------------------------------- */
+/* context                                                                     */
+/* ------------------------------------------------------------------------- */
+int lbfgs_hip_abi_version(void);
+int lbfgs_hip_device_count(int* count);
+/* rank 0: produce the 128-byte RCCL unique id to broadcast to the other ranks */
+int lbfgs_hip_rccl_unique_id(void* out128);
+/* shard == NULL => single rank holding n elements.  comm == NULL => NONE.
+ * stream == NULL => the context creates its own non-blocking stream. */
+int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfgs_hip_shard* shard,
+                         const lbfgs_hip_comm* comm, void* stream);
+void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* ctx);
+const char* lbfgs_hip_last_error(const lbfgs_hip_ctx* ctx); /* ctx may be NULL: creation errors */
+int lbfgs_hip_sync(lbfgs_hip_ctx* ctx);
+void* lbfgs_hip_stream(lbfgs_hip_ctx* ctx); /* hipStream_t */
+int lbfgs_hip_get_shard(const lbfgs_hip_ctx* ctx, lbfgs_hip_shard* out);
+/* launch geometry override for tuning (0 = default): blocks, i.e. workgroups per launch */
+int lbfgs_hip_set_grid(lbfgs_hip_ctx* ctx, int blocks);
+
+/* ------------------------------------------------------------------------- */
+/* vectors: Vec<f64> of the reference (core.rs:24-39, lbfgs.rs:611-613)        */
+/* ------------------------------------------------------------------------- */
+int lbfgs_hip_vec_alloc(lbfgs_hip_ctx* ctx, lbfgs_hip_vec** out);          /* vec![0.0; n] */
+void lbfgs_hip_vec_free(lbfgs_hip_vec* v);
+int lbfgs_hip_vec_upload(lbfgs_hip_vec* v, const double* host, uint64_t count);   /* local shard */
+int lbfgs_hip_vec_download(const lbfgs_hip_vec* v, double* host, uint64_t count); /* synchronises */
+int lbfgs_hip_vec_fill(lbfgs_hip_vec* v, double value);
+void* lbfgs_hip_vec_ptr(lbfgs_hip_vec* v);       /* device pointer of the shard (for device-side evaluators) */
+int lbfgs_hip_vec_swap(lbfgs_hip_vec* a, lbfgs_hip_vec* b); /* O(1) exchange of the two buffers */
+
+/* ------------------------------------------------------------------------- */
+/* scalar board                                                                */
+/* ------------------------------------------------------------------------- */
+int lbfgs_hip_scalars_read(lbfgs_hip_ctx* ctx, int first, int count, double* host); /* synchronises */
+int lbfgs_hip_scalars_write(lbfgs_hip_ctx* ctx, int first, int count, const double* host);
+void* lbfgs_hip_scalars_ptr(lbfgs_hip_ctx* ctx);
+/* sum all-reduce of board[first, first+count) across ranks (no-op when world == 1): closes a
+ * reduction whose per-rank partial the HOST produced (a sharded host closure's partial f) */
+int lbfgs_hip_scalars_allreduce(lbfgs_hip_ctx* ctx, int first, int count);
+
+/* ------------------------------------------------------------------------- */
+/* primitives: impl LbfgsMath<f64> for [f64]  (src/math.rs:31-82)              */
+/* ------------------------------------------------------------------------- */
+int lbfgs_hip_vecadd(lbfgs_hip_vec* y, const lbfgs_hip_vec* x, double c);        /* math.rs:33  y += c*x */
+int lbfgs_hip_vecadd_dev(lbfgs_hip_vec* y, const lbfgs_hip_vec* x, int c_slot);  /* same, c read from the board */
+int lbfgs_hip_vecdot(const lbfgs_hip_vec* x, const lbfgs_hip_vec* y, int out_slot); /* math.rs:40 */
+int lbfgs_hip_vecscale(lbfgs_hip_vec* y, double c);                              /* math.rs:45 */
+int lbfgs_hip_veccpy(lbfgs_hip_vec* y, const lbfgs_hip_vec* x);                  /* math.rs:52 */
+int lbfgs_hip_vecncpy(lbfgs_hip_vec* y, const lbfgs_hip_vec* x);                 /* math.rs:59 */
+int lbfgs_hip_vecdiff(lbfgs_hip_vec* z, const lbfgs_hip_vec* x, const lbfgs_hip_vec* y); /* math.rs:66 */
+/* math.rs:73-81: the board receives the SQUARED norm (dot(x,x)); sqrt / 1.0/sqrt are host scalar ops */
+int lbfgs_hip_vec2norm_sq(const lbfgs_hip_vec* x, int out_slot);
+
+/* ------------------------------------------------------------------------- */
+/* fused hot-path operators                                                    */
+/* ------------------------------------------------------------------------- */
+
+/* Problem::take_line_step (core.rs:155-164): x = xp + step*d, then, when wp != NULL,
+ * Orthantwise::constraint_line_search (orthantwise.rs:118-133): x_i = 0 where
+ * signum(x_i) != signum(wp_i) for global i in [start, end).  2r(+1r) 1w. */
+int lbfgs_hip_line_step(lbfgs_hip_vec* x, const lbfgs_hip_vec* xp, const lbfgs_hip_vec* d, double step,
+                        const lbfgs_hip_vec* wp, uint64_t start, uint64_t end);
+
+/* Progress::new / Report::new norms (core.rs:261-262, 294-295) in one pass:
+ * board[out_slot] = ||x||^2, board[out_slot+1] = ||g||^2.  2r. */
+int lbfgs_hip_norms_sq(const lbfgs_hip_vec* x, const lbfgs_hip_vec* g, int out_slot);
+
+/* history (lbfgs.rs:607-627 IterationData x m) */
+int lbfgs_hip_history_create(lbfgs_hip_ctx* ctx, int m, lbfgs_hip_history** out);
+void lbfgs_hip_history_destroy(lbfgs_hip_history* h);
+lbfgs_hip_vec* lbfgs_hip_history_s(lbfgs_hip_history* h, int slot);
+lbfgs_hip_vec* lbfgs_hip_history_y(lbfgs_hip_history* h, int slot);
+/* read/write the per-slot scalars ys[m], alpha[m] (device arrays owned by the history) */
+int lbfgs_hip_history_scalars_read(lbfgs_hip_history* h, double* ys, double* alpha);  /* synchronises */
+int lbfgs_hip_history_scalars_write(lbfgs_hip_history* h, const double* ys, const double* alpha);
+
+/* IterationData::update (lbfgs.rs:640-692), vector part, ONE pass (4r 2w):
+ *   s = x - xp ; y = g - gp ;
+ *   board[out_slot+0] = ||s||^2      (:645, squared)
+ *   board[out_slot+1] = y.s          (:653)  also stored as ys[slot] (:656)
+ *   board[out_slot+2] = y.y          (:654)
+ *   board[out_slot+3] = ||x||^2, board[out_slot+4] = ||g||^2   (free: x and g are read anyway)
+ *   board[out_slot+5] = s.bs with bs = gp*(-step)               (:670-673; only when damping != 0)
+ * The caller does the scalar tests (:646, :655) and gamma = ys/yy (:691).  */
+int lbfgs_hip_history_update(lbfgs_hip_history* h, int slot, const lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
+                             const lbfgs_hip_vec* g, const lbfgs_hip_vec* gp, double step, int damping,
+                             int out_slot);
+/* Powell damping case 1 (lbfgs.rs:675-680): y = (gp*(-step))*(1-theta) + theta*y.  2r 1w. */
+int lbfgs_hip_history_damp(lbfgs_hip_history* h, int slot, const lbfgs_hip_vec* gp, double step, double theta);
+
+/* update_search_direction + lbfgs_two_loop_recursion + dnorm
+ * (core.rs:95-101, lbfgs.rs:569-604, lbfgs.rs:543), fused to 8*bound passes:
+ *   d = -g ; two-loop over the history ; board[dnorm_slot] = ||d||^2.
+ * gamma is read on the device as board[gamma_num_slot] / board[gamma_den_slot]
+ * (ys / yy of the update just done).  k and end are the reference's arguments
+ * (k = number of corrections stored so far, end = slot just written); *new_end
+ * receives (end+1)%m.  alpha[] of the history is overwritten (lbfgs.rs:587).
+ * `g` is gx, or pg under OWL-QN (core.rs:96-97). */
+int lbfgs_hip_two_loop(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
+                       int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int* new_end);
+/* the same recursion as the reference's UNFUSED sequence of primitives (10*bound+2 passes);
+ * d must already hold -g.  Kept as the on-device cross-check of the fused kernels. */
+int lbfgs_hip_two_loop_unfused(lbfgs_hip_history* h, lbfgs_hip_vec* d, uint64_t k, int end,
+                               int gamma_num_slot, int gamma_den_slot, int* new_end);
+
+/* ------------------------------------------------------------------------- */
+/* OWL-QN operators (src/orthantwise.rs, core.rs:119-132,167-180,213-217)      */
+/* [start, end) are GLOBAL indices, already clamped by the caller (orthantwise.rs:59-67) */
+/* ------------------------------------------------------------------------- */
+/* Problem::evaluate tail (core.rs:123-126): board[out_slot] = sum c*|x_i| over [start,end)
+ * (orthantwise.rs:70-79), pg = pseudo-gradient (orthantwise.rs:82-112),
+ * board[out_slot+1] = ||pg||^2 (core.rs:185), board[out_slot+2] = ||x||^2.  2r 1w. */
+int lbfgs_hip_owlqn_post_eval(const lbfgs_hip_vec* x, const lbfgs_hip_vec* g, lbfgs_hip_vec* pg, double c,
+                              uint64_t start, uint64_t end, int out_slot);
+/* Problem::update_orthant_new_point (core.rs:167-180): wp_i = xp_i==0 ? signum(-pg_i) : signum(xp_i), all i */
+int lbfgs_hip_orthant_select(lbfgs_hip_vec* wp, const lbfgs_hip_vec* xp, const lbfgs_hip_vec* pg);
+/* Orthantwise::constrain_search_direction (orthantwise.rs:140-161): d_i = 0 where
+ * signum(d_i) != signum(-pg_i) on [start,end); board[out_slot] = ||d||^2 (caller asserts != 0). */
+int lbfgs_hip_constrain_direction(lbfgs_hip_vec* d, const lbfgs_hip_vec* pg, uint64_t start, uint64_t end,
+                                  int out_slot);
+
+/* ------------------------------------------------------------------------- */
+/* device-resident objectives (the "user closure" of core.rs:119-121 kept in HBM) */
+/* ------------------------------------------------------------------------- */
+enum {
+    LBFGS_HIP_OBJ_QUADRATIC = 1,  /* hashed diagonal quadratic  (BASELINE.json configs 2, 4) */
+    LBFGS_HIP_OBJ_LOGISTIC = 2,   /* hashed separable logistic  (config 3, with OWL-QN)      */
+    LBFGS_HIP_OBJ_ROSENBROCK = 3  /* src/lib.rs:79-94 default_evaluate (pairs must not straddle shards) */
+};
+typedef struct lbfgs_hip_objective {
+    int32_t kind;
+    int32_t _pad;
+    uint64_t seed_a, seed_b;
+} lbfgs_hip_objective;
+/* g = grad f(x); board[out_slot] = f(x) (global sum).  1r 1w. */
+int lbfgs_hip_objective_eval(const lbfgs_hip_objective* obj, const lbfgs_hip_vec* x, lbfgs_hip_vec* g,
+                             int out_slot);
+/* take_line_step + evaluate + dg_unchecked in ONE pass (core.rs:155-158,119-121,114-116), no OWL-QN:
+ *   x = xp + step*d ; g = grad f(x) ; board[out_slot] = f(x) ; board[out_slot+1] = g.d.   2r 2w. */
+int lbfgs_hip_objective_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
+                                  const lbfgs_hip_vec* d, double step, lbfgs_hip_vec* g, int out_slot);
+
+/* ------------------------------------------------------------------------- */
+/* measurement                                                                 */
+/* ------------------------------------------------------------------------- */
+/* Kernel classes timed with HIP events on the context's stream when profiling is on. */
+enum {
+    LBFGS_HIP_K_TWOLOOP_STEP = 0, /* q += c*u ; out = v.q  (3r 1w) -- the dominant kernel */
+    LBFGS_HIP_K_TWOLOOP_EDGE = 1, /* first dot (2r), gamma transition and last step (2r 1w) */
+    LBFGS_HIP_K_UPDATE = 2,
+    LBFGS_HIP_K_LINE = 3,
+    LBFGS_HIP_K_EVAL = 4,
+    LBFGS_HIP_K_OWLQN = 5,
+    LBFGS_HIP_K_BLAS1 = 6,
+    LBFGS_HIP_K_COMM = 7,
+    LBFGS_HIP_K_TWOLOOP_ALL = 8,  /* one event pair around a whole lbfgs_hip_two_loop call */
+    LBFGS_HIP_K_CLASSES = 9
+};
+int lbfgs_hip_prof_enable(lbfgs_hip_ctx* ctx, int on);
+int lbfgs_hip_prof_reset(lbfgs_hip_ctx* ctx);
+/* synchronises; launches and summed milliseconds of a class since the last reset */
+int lbfgs_hip_prof_read(lbfgs_hip_ctx* ctx, int kclass, uint64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

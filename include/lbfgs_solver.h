@@ -1,0 +1,134 @@
+/*
+ * include/lbfgs_solver.h -- host orchestration above the C-ABI of lbfgs_hip.h.
+ *
+ * In the reference the host side is Rust (src/lbfgs.rs:399-566 Lbfgs/LbfgsState,
+ * src/core.rs:10-218 Problem, src/line.rs LineSearch).  This image has no Rust
+ * toolchain, so that layer is written in C++ (rust-lbfgs_amd/csrc/host/solver.cpp)
+ * and calls ONLY the functions of lbfgs_hip.h -- exactly what a Rust shim would
+ * do.  This header is its C interface, bound by the Python
+ * package; names, argument meaning and error behaviour mirror the reference.
+ */
+#ifndef LBFGS_SOLVER_H
+#define LBFGS_SOLVER_H
+
+#include "lbfgs_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* LineSearchAlgorithm (line.rs:39-81) */
+enum {
+    LBFGS_LS_MORETHUENTE = 0,
+    LBFGS_LS_BACKTRACKING_ARMIJO = 1,
+    LBFGS_LS_BACKTRACKING_STRONGWOLFE = 2,
+    LBFGS_LS_BACKTRACKING_WOLFE = 3
+};
+
+/* Result<..>::Err / panic sites of the reference, as status codes (backend errors
+ * from lbfgs_hip.h, <= -101, pass through unchanged) */
+enum {
+    LBFGS_OK = 0,
+    LBFGS_ERR_EVALUATE = -1,          /* Err from the user's evaluate (lbfgs.rs:454)                  */
+    LBFGS_ERR_NEGATIVE_STEP = -2,     /* line.rs:198-201                                              */
+    LBFGS_ERR_GRADONLY_MT = -3,       /* line.rs:208                                                  */
+    LBFGS_ERR_X_NOT_CHANGED = -4,     /* lbfgs.rs:646                                                 */
+    LBFGS_ERR_GX_NOT_CHANGED = -5,    /* lbfgs.rs:655                                                 */
+    LBFGS_ERR_INVALID_DNORM = -6,     /* lbfgs.rs:544                                                 */
+    LBFGS_PANIC_OWLQN_RANGE = -20,    /* orthantwise.rs:64                                            */
+    LBFGS_PANIC_ZERO_DIRECTION = -21, /* orthantwise.rs:160                                           */
+    LBFGS_ERR_PARAM = -40             /* setter assert!s of lbfgs.rs:195-361 / unimplemented!() :379  */
+};
+
+/* LbfgsParam (lbfgs.rs:72-154) + LineSearch (line.rs:91-148) + Orthantwise (orthantwise.rs:19-45) */
+typedef struct lbfgs_param {
+    uint64_t m;                 /* 6; the reference has no setter: `with_m` is an extension */
+    double epsilon;             /* 1e-5 */
+    uint64_t past;              /* 0, unused by the reference (lbfgs.rs:702) */
+    double delta;               /* 1e-5, unused */
+    uint64_t max_iterations;    /* 0 */
+    uint64_t max_evaluations;   /* 0 */
+    double initial_inverse_hessian; /* 1.0 */
+    double max_step_size;       /* 1.0 */
+    int32_t damping;            /* 0 */
+    int32_t constrain_step_size;/* 1 */
+    int32_t ls_algorithm;       /* MoreThuente */
+    int32_t gradient_only;      /* 0 */
+    double ftol, gtol, xtol;    /* 1e-4, 0.9, f64::EPSILON */
+    double min_step, max_step;  /* 1e-20, 1e20 */
+    uint64_t max_linesearch;    /* 20 */
+    int32_t orthantwise;        /* 0 = None */
+    int32_t _pad;
+    double owl_c;               /* 1.0 */
+    uint64_t owl_start;         /* 0 */
+    int64_t owl_end;            /* -1 = None */
+} lbfgs_param;
+
+void lbfgs_param_default(lbfgs_param* p);
+
+/* The user's evaluate, three ways:
+ *  HOST    E: FnMut(&[f64], &mut [f64]) -> Result<f64> on host slices (lbfgs.rs:401): the drop-in form.
+ *          x is downloaded and g uploaded around every call (PCIe), so it is for compatibility, not speed.
+ *          With world > 1 the slices are this rank's shard and the return value is the shard's partial f.
+ *  DEVICE  the same contract on device pointers: x and g never leave HBM.
+ *  BUILTIN one of the device-resident objectives of lbfgs_hip.h. */
+enum { LBFGS_EVAL_HOST = 0, LBFGS_EVAL_DEVICE = 1, LBFGS_EVAL_BUILTIN = 2 };
+typedef double (*lbfgs_host_eval_cb)(void* user, const double* x, double* g, uint64_t n_local, int* failed);
+typedef double (*lbfgs_device_eval_cb)(void* user, const void* x_dev, void* g_dev, uint64_t n_local, void* stream,
+                                       int* failed);
+typedef struct lbfgs_evaluator {
+    int32_t kind;
+    int32_t fuse_line_eval;  /* BUILTIN without OWL-QN: line step + evaluate + g.d in one pass */
+    lbfgs_host_eval_cb host;
+    lbfgs_device_eval_cb device;
+    void* user;
+    lbfgs_hip_objective builtin;
+} lbfgs_evaluator;
+
+/* Progress (core.rs:223-250); x and gx stay on the device: fetch them with lbfgs_state_download */
+typedef struct lbfgs_progress {
+    double fx, xnorm, gnorm, step;
+    uint64_t niter, neval, ncall;
+} lbfgs_progress;
+typedef int (*lbfgs_progress_cb)(void* user, const lbfgs_progress* p); /* non-zero cancels (lbfgs.rs:412-416) */
+
+/* Report (core.rs:273-285) */
+typedef struct lbfgs_report {
+    double fx, xnorm, gnorm;
+    uint64_t neval;
+} lbfgs_report;
+
+typedef struct lbfgs_state lbfgs_state; /* LbfgsState (lbfgs.rs:425-439) */
+
+/* Lbfgs::build (lbfgs.rs:443-481).  x0 is this rank's shard (n_local doubles).  On Err no state is returned. */
+int lbfgs_build(lbfgs_state** out, lbfgs_hip_ctx* ctx, const lbfgs_param* param, const double* x0,
+                const lbfgs_evaluator* eval);
+int lbfgs_is_converged(lbfgs_state* st, int* converged);      /* lbfgs.rs:489-494 */
+int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out);    /* lbfgs.rs:503-560 */
+int lbfgs_get_report(lbfgs_state* st, lbfgs_report* out);     /* lbfgs.rs:497-499 */
+void lbfgs_state_free(lbfgs_state* st);
+const char* lbfgs_state_error(const lbfgs_state* st);         /* message of the last Err */
+/* last swallowed line-search failure (line.rs:213-220), "" if the last search succeeded */
+const char* lbfgs_state_ls_error(const lbfgs_state* st);
+
+/* LineSearch::find on the state's Problem (line.rs:193-223) */
+int lbfgs_line_search(lbfgs_state* st, double* step, uint64_t* ncall);
+
+/* vectors of the Problem / history, for Progress.x / Progress.gx and for parity tests */
+enum { LBFGS_VEC_X = 0, LBFGS_VEC_GX, LBFGS_VEC_XP, LBFGS_VEC_GP, LBFGS_VEC_PG, LBFGS_VEC_WP, LBFGS_VEC_D,
+       LBFGS_VEC_S0 = 100, LBFGS_VEC_Y0 = 200 };
+int lbfgs_state_download(lbfgs_state* st, int which, double* host);
+void* lbfgs_state_devptr(lbfgs_state* st, int which);
+int lbfgs_state_info(lbfgs_state* st, uint64_t* k, uint64_t* end, double* step, double* gamma);
+lbfgs_hip_history* lbfgs_state_history(lbfgs_state* st);
+
+/* Lbfgs::minimize (lbfgs.rs:399-421).  x is read as the start point and receives the result
+ * (this rank's shard).  progress may be NULL. */
+int lbfgs_minimize(lbfgs_hip_ctx* ctx, const lbfgs_param* param, double* x, const lbfgs_evaluator* eval,
+                   lbfgs_progress_cb progress, void* progress_user, lbfgs_report* report, char* errbuf,
+                   size_t errbuf_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

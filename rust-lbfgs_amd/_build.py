@@ -1,0 +1,65 @@
+"""Build the native libraries in-tree (they travel to the GPU box with the snapshot).
+
+  liblbfgs_hip.so     HIP kernels + the C-ABI of include/lbfgs_hip.h   (hipcc, gfx950)
+  liblbfgs_solver.so  host orchestration of include/lbfgs_solver.h    (g++, links the former)
+
+hipcc cross-compiles for gfx950 without a GPU.  -ffp-contract=off on both sides: the
+reference's arithmetic is mul-then-add with separate roundings (src/math.rs:35,41).
+"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HIP_LIB = os.path.join(HERE, "liblbfgs_hip.so")
+SOLVER_LIB = os.path.join(HERE, "liblbfgs_solver.so")
+
+HIP_SRCS = [os.path.join(CSRC, f) for f in ("lbfgs_hip.hip", "ops.h", "stream.h")] + [
+    os.path.join(ROOT, "include", "lbfgs_hip.h")
+]
+SOLVER_SRCS = [os.path.join(CSRC, "host", "solver.cpp"), os.path.join(ROOT, "include", "lbfgs_solver.h"),
+               os.path.join(ROOT, "include", "lbfgs_hip.h")]
+
+
+def _stale(target, srcs):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+
+
+def hipcc():
+    for c in ("/opt/rocm/bin/hipcc", "hipcc"):
+        if os.path.isabs(c) and os.path.exists(c):
+            return c
+    return "hipcc"
+
+
+def build_hip(force=False):
+    if force or _stale(HIP_LIB, HIP_SRCS):
+        _run([hipcc(), "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+              "-Wall", HIP_SRCS[0], "-o", HIP_LIB, "-ldl"])
+    return HIP_LIB
+
+
+def build_solver(force=False):
+    build_hip(force)
+    if force or _stale(SOLVER_LIB, SOLVER_SRCS + [HIP_LIB]):
+        _run(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall", SOLVER_SRCS[0], "-o",
+              SOLVER_LIB, "-L" + HERE, "-llbfgs_hip", "-Wl,-rpath,$ORIGIN"])
+    return SOLVER_LIB
+
+
+def build_all(force=False):
+    return build_hip(force), build_solver(force)
+
+
+if __name__ == "__main__":
+    print(build_all(force=True))

@@ -1,0 +1,216 @@
+"""ctypes declarations of include/lbfgs_hip.h and include/lbfgs_solver.h.
+
+The product loads ``liblbfgs_hip.so`` (HIP kernels + C-ABI) and ``liblbfgs_solver.so``
+(host orchestration) from this directory and FAILS LOUDLY when they are missing or no
+GPU is visible: there is no CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+BOARD_SLOTS = 256
+
+# status codes (lbfgs_solver.h / lbfgs_hip.h)
+OK = 0
+ERR_EVALUATE, ERR_NEGATIVE_STEP, ERR_GRADONLY_MT = -1, -2, -3
+ERR_X_NOT_CHANGED, ERR_GX_NOT_CHANGED, ERR_INVALID_DNORM = -4, -5, -6
+PANIC_OWLQN_RANGE, PANIC_ZERO_DIRECTION, ERR_PARAM = -20, -21, -40
+HIP_ERR_ARG, HIP_ERR_HIP, HIP_ERR_COMM, HIP_ERR_NOMEM, HIP_ERR_NO_DEVICE = -101, -102, -103, -104, -105
+
+LS_MORETHUENTE, LS_BT_ARMIJO, LS_BT_STRONGWOLFE, LS_BT_WOLFE = 0, 1, 2, 3
+EVAL_HOST, EVAL_DEVICE, EVAL_BUILTIN = 0, 1, 2
+COMM_NONE, COMM_RCCL, COMM_CALLBACK = 0, 1, 2
+OBJ_QUADRATIC, OBJ_LOGISTIC, OBJ_ROSENBROCK = 1, 2, 3
+(K_TWOLOOP_STEP, K_TWOLOOP_EDGE, K_UPDATE, K_LINE, K_EVAL, K_OWLQN, K_BLAS1, K_COMM, K_TWOLOOP_ALL) = range(9)
+VEC_X, VEC_GX, VEC_XP, VEC_GP, VEC_PG, VEC_WP, VEC_D = range(7)
+VEC_S0, VEC_Y0 = 100, 200
+
+
+class Shard(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("n_global", C.c_uint64), ("offset", C.c_uint64),
+                ("n_local", C.c_uint64)]
+
+
+ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
+
+
+class Comm(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("rccl_unique_id", C.c_void_p),
+                ("callback", ALLREDUCE_CB), ("callback_user", C.c_void_p)]
+
+
+class Objective(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("seed_a", C.c_uint64), ("seed_b", C.c_uint64)]
+
+
+class Param(C.Structure):
+    _fields_ = [
+        ("m", C.c_uint64), ("epsilon", C.c_double), ("past", C.c_uint64), ("delta", C.c_double),
+        ("max_iterations", C.c_uint64), ("max_evaluations", C.c_uint64),
+        ("initial_inverse_hessian", C.c_double), ("max_step_size", C.c_double),
+        ("damping", C.c_int32), ("constrain_step_size", C.c_int32),
+        ("ls_algorithm", C.c_int32), ("gradient_only", C.c_int32),
+        ("ftol", C.c_double), ("gtol", C.c_double), ("xtol", C.c_double),
+        ("min_step", C.c_double), ("max_step", C.c_double), ("max_linesearch", C.c_uint64),
+        ("orthantwise", C.c_int32), ("_pad", C.c_int32), ("owl_c", C.c_double), ("owl_start", C.c_uint64),
+        ("owl_end", C.c_int64),
+    ]
+
+
+HOST_EVAL_CB = C.CFUNCTYPE(C.c_double, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint64,
+                           C.POINTER(C.c_int))
+DEVICE_EVAL_CB = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                             C.POINTER(C.c_int))
+
+
+class Evaluator(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("fuse_line_eval", C.c_int32), ("host", HOST_EVAL_CB),
+                ("device", DEVICE_EVAL_CB), ("user", C.c_void_p), ("builtin", Objective)]
+
+
+class CProgress(C.Structure):
+    _fields_ = [("fx", C.c_double), ("xnorm", C.c_double), ("gnorm", C.c_double), ("step", C.c_double),
+                ("niter", C.c_uint64), ("neval", C.c_uint64), ("ncall", C.c_uint64)]
+
+
+PROGRESS_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(CProgress))
+
+
+class CReport(C.Structure):
+    _fields_ = [("fx", C.c_double), ("xnorm", C.c_double), ("gnorm", C.c_double), ("neval", C.c_uint64)]
+
+
+# every symbol include/lbfgs_hip.h declares
+HIP_SYMBOLS = """
+lbfgs_hip_abi_version lbfgs_hip_device_count lbfgs_hip_rccl_unique_id lbfgs_hip_ctx_create lbfgs_hip_ctx_destroy
+lbfgs_hip_last_error lbfgs_hip_sync lbfgs_hip_stream lbfgs_hip_get_shard lbfgs_hip_set_grid
+lbfgs_hip_vec_alloc lbfgs_hip_vec_free lbfgs_hip_vec_upload lbfgs_hip_vec_download lbfgs_hip_vec_fill
+lbfgs_hip_vec_ptr lbfgs_hip_vec_swap
+lbfgs_hip_scalars_read lbfgs_hip_scalars_write lbfgs_hip_scalars_ptr lbfgs_hip_scalars_allreduce
+lbfgs_hip_vecadd lbfgs_hip_vecadd_dev lbfgs_hip_vecdot lbfgs_hip_vecscale lbfgs_hip_veccpy lbfgs_hip_vecncpy
+lbfgs_hip_vecdiff lbfgs_hip_vec2norm_sq
+lbfgs_hip_line_step lbfgs_hip_norms_sq
+lbfgs_hip_history_create lbfgs_hip_history_destroy lbfgs_hip_history_s lbfgs_hip_history_y
+lbfgs_hip_history_scalars_read lbfgs_hip_history_scalars_write lbfgs_hip_history_update lbfgs_hip_history_damp
+lbfgs_hip_two_loop lbfgs_hip_two_loop_unfused
+lbfgs_hip_owlqn_post_eval lbfgs_hip_orthant_select lbfgs_hip_constrain_direction
+lbfgs_hip_objective_eval lbfgs_hip_objective_line_eval
+lbfgs_hip_prof_enable lbfgs_hip_prof_reset lbfgs_hip_prof_read
+""".split()
+
+SOLVER_SYMBOLS = """
+lbfgs_param_default lbfgs_build lbfgs_is_converged lbfgs_propagate lbfgs_get_report lbfgs_state_free
+lbfgs_state_error lbfgs_state_ls_error lbfgs_line_search lbfgs_state_download lbfgs_state_devptr lbfgs_state_info
+lbfgs_state_history lbfgs_minimize
+""".split()
+
+
+def declare(L):
+    """Attach argtypes/restypes for both headers to one CDLL that exports all symbols."""
+    vp, dp, i, u64, dbl = C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_uint64, C.c_double
+    sig = {
+        "lbfgs_hip_abi_version": (i, []),
+        "lbfgs_hip_device_count": (i, [C.POINTER(i)]),
+        "lbfgs_hip_rccl_unique_id": (i, [vp]),
+        "lbfgs_hip_ctx_create": (i, [C.POINTER(vp), i, u64, C.POINTER(Shard), C.POINTER(Comm), vp]),
+        "lbfgs_hip_ctx_destroy": (None, [vp]),
+        "lbfgs_hip_last_error": (C.c_char_p, [vp]),
+        "lbfgs_hip_sync": (i, [vp]),
+        "lbfgs_hip_stream": (vp, [vp]),
+        "lbfgs_hip_get_shard": (i, [vp, C.POINTER(Shard)]),
+        "lbfgs_hip_set_grid": (i, [vp, i]),
+        "lbfgs_hip_vec_alloc": (i, [vp, C.POINTER(vp)]),
+        "lbfgs_hip_vec_free": (None, [vp]),
+        "lbfgs_hip_vec_upload": (i, [vp, dp, u64]),
+        "lbfgs_hip_vec_download": (i, [vp, dp, u64]),
+        "lbfgs_hip_vec_fill": (i, [vp, dbl]),
+        "lbfgs_hip_vec_ptr": (vp, [vp]),
+        "lbfgs_hip_vec_swap": (i, [vp, vp]),
+        "lbfgs_hip_scalars_read": (i, [vp, i, i, dp]),
+        "lbfgs_hip_scalars_write": (i, [vp, i, i, dp]),
+        "lbfgs_hip_scalars_ptr": (vp, [vp]),
+        "lbfgs_hip_scalars_allreduce": (i, [vp, i, i]),
+        "lbfgs_hip_vecadd": (i, [vp, vp, dbl]),
+        "lbfgs_hip_vecadd_dev": (i, [vp, vp, i]),
+        "lbfgs_hip_vecdot": (i, [vp, vp, i]),
+        "lbfgs_hip_vecscale": (i, [vp, dbl]),
+        "lbfgs_hip_veccpy": (i, [vp, vp]),
+        "lbfgs_hip_vecncpy": (i, [vp, vp]),
+        "lbfgs_hip_vecdiff": (i, [vp, vp, vp]),
+        "lbfgs_hip_vec2norm_sq": (i, [vp, i]),
+        "lbfgs_hip_line_step": (i, [vp, vp, vp, dbl, vp, u64, u64]),
+        "lbfgs_hip_norms_sq": (i, [vp, vp, i]),
+        "lbfgs_hip_history_create": (i, [vp, i, C.POINTER(vp)]),
+        "lbfgs_hip_history_destroy": (None, [vp]),
+        "lbfgs_hip_history_s": (vp, [vp, i]),
+        "lbfgs_hip_history_y": (vp, [vp, i]),
+        "lbfgs_hip_history_scalars_read": (i, [vp, dp, dp]),
+        "lbfgs_hip_history_scalars_write": (i, [vp, dp, dp]),
+        "lbfgs_hip_history_update": (i, [vp, i, vp, vp, vp, vp, dbl, i, i]),
+        "lbfgs_hip_history_damp": (i, [vp, i, vp, dbl, dbl]),
+        "lbfgs_hip_two_loop": (i, [vp, vp, vp, u64, i, i, i, i, C.POINTER(i)]),
+        "lbfgs_hip_two_loop_unfused": (i, [vp, vp, u64, i, i, i, C.POINTER(i)]),
+        "lbfgs_hip_owlqn_post_eval": (i, [vp, vp, vp, dbl, u64, u64, i]),
+        "lbfgs_hip_orthant_select": (i, [vp, vp, vp]),
+        "lbfgs_hip_constrain_direction": (i, [vp, vp, u64, u64, i]),
+        "lbfgs_hip_objective_eval": (i, [C.POINTER(Objective), vp, vp, i]),
+        "lbfgs_hip_objective_line_eval": (i, [C.POINTER(Objective), vp, vp, vp, dbl, vp, i]),
+        "lbfgs_hip_prof_enable": (i, [vp, i]),
+        "lbfgs_hip_prof_reset": (i, [vp]),
+        "lbfgs_hip_prof_read": (i, [vp, i, C.POINTER(u64), dp]),
+        # solver
+        "lbfgs_param_default": (None, [C.POINTER(Param)]),
+        "lbfgs_build": (i, [C.POINTER(vp), vp, C.POINTER(Param), dp, C.POINTER(Evaluator)]),
+        "lbfgs_is_converged": (i, [vp, C.POINTER(i)]),
+        "lbfgs_propagate": (i, [vp, C.POINTER(CProgress)]),
+        "lbfgs_get_report": (i, [vp, C.POINTER(CReport)]),
+        "lbfgs_state_free": (None, [vp]),
+        "lbfgs_state_error": (C.c_char_p, [vp]),
+        "lbfgs_state_ls_error": (C.c_char_p, [vp]),
+        "lbfgs_line_search": (i, [vp, dp, C.POINTER(u64)]),
+        "lbfgs_state_download": (i, [vp, i, dp]),
+        "lbfgs_state_devptr": (vp, [vp, i]),
+        "lbfgs_state_info": (i, [vp, C.POINTER(u64), C.POINTER(u64), dp, dp]),
+        "lbfgs_state_history": (vp, [vp]),
+        "lbfgs_minimize": (i, [vp, C.POINTER(Param), dp, C.POINTER(Evaluator), PROGRESS_CB, vp, C.POINTER(CReport),
+                               C.c_char_p, C.c_size_t]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError = missing export: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+_LIB = None
+
+
+def load():
+    """Load the product libraries.  Raises if they are not built (run rust_lbfgs_amd.build())."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    hip = os.path.join(HERE, "liblbfgs_hip.so")
+    solver = os.path.join(HERE, "liblbfgs_solver.so")
+    for p in (hip, solver):
+        if not os.path.exists(p):
+            raise ImportError(
+                f"{p} is missing: the HIP extension is not built (python -c 'import rust_lbfgs_amd as r; r.build()'); "
+                "this package has no CPU fallback")
+    # liblbfgs_solver.so names liblbfgs_hip.so as a dependency (rpath $ORIGIN); RTLD_LOCAL keeps the
+    # lbfgs_hip_* symbols out of the global namespace
+    _LIB = declare(C.CDLL(solver, mode=C.RTLD_LOCAL))
+    return _LIB
+
+
+def use_library_for_tests(lib):
+    """TESTS ONLY: substitute the loaded library (the CPU test double of tests/support/).
+
+    The product never calls this; it exists so the host orchestration can be tested in
+    the GPU-less suite.  Returns the previous library so a fixture can restore it."""
+    global _LIB
+    prev, _LIB = _LIB, lib
+    return prev

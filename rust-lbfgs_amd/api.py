@@ -1,0 +1,473 @@
+"""Host-side mirror of the reference's user API, over the native libraries.
+
+    lbfgs().with_*(..).minimize(x, evaluate, progress) -> Report          (src/lbfgs.rs:399-421)
+    lbfgs().build(x, evaluate) -> LbfgsState {is_converged, propagate, report}   (:443-565)
+
+Names, argument meaning, defaults and error behaviour follow the reference crate
+(`liblbfgs` v0.2.0); the work happens in liblbfgs_solver.so (host orchestration, C++)
+and liblbfgs_hip.so (HIP kernels on MI355X).  Three kinds of `evaluate`:
+
+  * a Python callable ``evaluate(x: np.ndarray, gx: np.ndarray) -> float`` -- the drop-in
+    closure form ``FnMut(&[f64], &mut [f64]) -> Result<f64>`` on HOST slices (raise to
+    signal ``Err``).  x/gx cross PCIe on every call: compatibility path;
+  * ``DeviceEvaluate(fn)``: ``fn(x_ptr, g_ptr, n, stream) -> float`` on DEVICE pointers;
+  * a built-in device-resident objective from ``objectives`` (benchmark workloads).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import Param
+
+
+class LbfgsError(RuntimeError):
+    """`Err(..)` of the reference's `anyhow::Result` (status code + message)."""
+
+    def __init__(self, code, message=""):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+        self.message = message
+
+
+class LbfgsPanic(LbfgsError):
+    """A `panic!`/`assert!` site of the reference (orthantwise.rs:64,160)."""
+
+
+def _raise(code, message):
+    if code in (_ffi.PANIC_OWLQN_RANGE, _ffi.PANIC_ZERO_DIRECTION):
+        raise LbfgsPanic(code, message)
+    raise LbfgsError(code, message)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+# ------------------------------------------------------------------------------------ context
+class Context:
+    """Device, stream, scalar board and communicator (lbfgs_hip_ctx)."""
+
+    def __init__(self, n, device=0, shard=None, comm=None, stream=None):
+        L = _ffi.load()
+        self._L = L
+        self._h = C.c_void_p()
+        self._keep = comm  # keeps the callback / id buffer alive
+        shard_p = C.byref(shard) if shard is not None else None
+        comm_p = C.byref(comm.c) if comm is not None else None
+        rc = L.lbfgs_hip_ctx_create(C.byref(self._h), device, n, shard_p, comm_p, stream)
+        if rc != 0:
+            msg = L.lbfgs_hip_last_error(None).decode()
+            self._h = C.c_void_p()
+            raise LbfgsError(rc, msg)
+        s = _ffi.Shard()
+        L.lbfgs_hip_get_shard(self._h, C.byref(s))
+        self.shard = s
+        self.n_local = int(s.n_local)
+        self.n_global = int(s.n_global)
+
+    def check(self, rc):
+        if rc != 0:
+            _raise(rc, self._L.lbfgs_hip_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._L.lbfgs_hip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # scalar board
+    def scalars(self, first, count=1):
+        out = np.zeros(count)
+        self.check(self._L.lbfgs_hip_scalars_read(self._h, first, count, _dp(out)))
+        return out
+
+    def set_scalars(self, first, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        self.check(self._L.lbfgs_hip_scalars_write(self._h, first, len(v), _dp(v)))
+
+    def sync(self):
+        self.check(self._L.lbfgs_hip_sync(self._h))
+
+    def set_grid(self, blocks):
+        self.check(self._L.lbfgs_hip_set_grid(self._h, blocks))
+
+    @property
+    def stream(self):
+        return self._L.lbfgs_hip_stream(self._h)
+
+    # measurement
+    def prof_enable(self, on=True):
+        self.check(self._L.lbfgs_hip_prof_enable(self._h, int(on)))
+
+    def prof_reset(self):
+        self.check(self._L.lbfgs_hip_prof_reset(self._h))
+
+    def prof_read(self, kclass):
+        n = C.c_uint64()
+        ms = C.c_double()
+        self.check(self._L.lbfgs_hip_prof_read(self._h, kclass, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+
+# ------------------------------------------------------------------------------------ evaluators
+class DeviceEvaluate:
+    """`evaluate` on device pointers: fn(x_ptr:int, g_ptr:int, n_local:int, stream:int) -> float."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+
+@dataclass
+class BuiltinObjective:
+    kind: int
+    seed_a: int = 0
+    seed_b: int = 0
+    fuse_line_eval: bool = True
+
+
+def _make_evaluator(evaluate):
+    """-> (Evaluator struct, keepalive, error-holder)"""
+    ev = _ffi.Evaluator()
+    holder = {"exc": None}
+    if isinstance(evaluate, BuiltinObjective):
+        ev.kind = _ffi.EVAL_BUILTIN
+        ev.fuse_line_eval = int(evaluate.fuse_line_eval)
+        ev.builtin = _ffi.Objective(evaluate.kind, 0, evaluate.seed_a, evaluate.seed_b)
+        return ev, None, holder
+    if isinstance(evaluate, DeviceEvaluate):
+        def dtramp(_user, xptr, gptr, n, stream, failed):
+            try:
+                return float(evaluate.fn(xptr, gptr, n, stream))
+            except Exception as e:  # Err(..)
+                holder["exc"] = e
+                failed[0] = 1
+                return 0.0
+
+        cb = _ffi.DEVICE_EVAL_CB(dtramp)
+        ev.kind = _ffi.EVAL_DEVICE
+        ev.device = cb
+        return ev, cb, holder
+
+    def tramp(_user, xp, gp, n, failed):
+        x = np.ctypeslib.as_array(xp, shape=(n,))
+        g = np.ctypeslib.as_array(gp, shape=(n,))
+        try:
+            return float(evaluate(x, g))
+        except Exception as e:  # Err(..)
+            holder["exc"] = e
+            failed[0] = 1
+            return 0.0
+
+    cb = _ffi.HOST_EVAL_CB(tramp)
+    ev.kind = _ffi.EVAL_HOST
+    ev.host = cb
+    return ev, cb, holder
+
+
+# ------------------------------------------------------------------------------------ Progress / Report
+class Progress:
+    """core.rs:223-250.  `x` and `gx` live on the device and are fetched on first access."""
+
+    def __init__(self, state, c):
+        self._state = state
+        self.fx, self.xnorm, self.gnorm, self.step = c.fx, c.xnorm, c.gnorm, c.step
+        self.niter, self.neval, self.ncall = c.niter, c.neval, c.ncall
+
+    @property
+    def x(self):
+        return self._state.download("x")
+
+    @property
+    def gx(self):
+        return self._state.download("gx")
+
+    def __repr__(self):
+        return (f"Progress(niter={self.niter}, neval={self.neval}, ncall={self.ncall}, fx={self.fx!r}, "
+                f"xnorm={self.xnorm!r}, gnorm={self.gnorm!r}, step={self.step!r})")
+
+
+@dataclass
+class Report:
+    """core.rs:273-285"""
+    fx: float
+    xnorm: float
+    gnorm: float
+    neval: int
+
+
+# ------------------------------------------------------------------------------------ LbfgsState
+class LbfgsState:
+    """lbfgs.rs:425-566: caller-driven stepping."""
+
+    _VEC = {"x": _ffi.VEC_X, "gx": _ffi.VEC_GX, "xp": _ffi.VEC_XP, "gp": _ffi.VEC_GP, "pg": _ffi.VEC_PG,
+            "wp": _ffi.VEC_WP, "d": _ffi.VEC_D}
+
+    def __init__(self, param, x, evaluate, ctx=None, device=0):
+        L = _ffi.load()
+        self._L = L
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        self._own_ctx = ctx is None
+        self.ctx = ctx if ctx is not None else Context(len(x), device=device)
+        if len(x) != self.ctx.n_local:
+            raise LbfgsError(_ffi.ERR_PARAM, f"x has {len(x)} elements, the context's shard {self.ctx.n_local}")
+        self.m = int(param.m)
+        self._ev, self._keep, self._holder = _make_evaluator(evaluate)
+        self._h = C.c_void_p()
+        p = Param()
+        C.memmove(C.byref(p), C.byref(param), C.sizeof(Param))
+        rc = L.lbfgs_build(C.byref(self._h), self.ctx._h, C.byref(p), _dp(x), C.byref(self._ev))
+        if rc != 0:
+            msg = L.lbfgs_state_error(None).decode()
+            self._h = C.c_void_p()
+            if self._own_ctx:
+                self.ctx.close()
+            self._reraise(rc, msg)
+
+    def _reraise(self, rc, msg):
+        exc = self._holder.get("exc")
+        if rc == _ffi.ERR_EVALUATE and exc is not None:
+            self._holder["exc"] = None
+            raise LbfgsError(rc, f"{msg}: {exc!r}") from exc
+        _raise(rc, msg)
+
+    def _check(self, rc):
+        if rc != 0:
+            self._reraise(rc, self._L.lbfgs_state_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._L.lbfgs_state_free(self._h)
+            self._h = C.c_void_p()
+        if self._own_ctx:
+            self.ctx.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def is_converged(self):
+        c = C.c_int()
+        self._check(self._L.lbfgs_is_converged(self._h, C.byref(c)))
+        return bool(c.value)
+
+    def propagate(self):
+        p = _ffi.CProgress()
+        self._check(self._L.lbfgs_propagate(self._h, C.byref(p)))
+        return Progress(self, p)
+
+    def report(self):
+        r = _ffi.CReport()
+        self._check(self._L.lbfgs_get_report(self._h, C.byref(r)))
+        return Report(r.fx, r.xnorm, r.gnorm, r.neval)
+
+    def line_search(self, step):
+        """LineSearch::find (line.rs:193-223) on the current point; returns (ncall, step)."""
+        s = C.c_double(step)
+        n = C.c_uint64()
+        self._check(self._L.lbfgs_line_search(self._h, C.byref(s), C.byref(n)))
+        return n.value, s.value
+
+    # --- introspection (parity tests, Progress.x / .gx)
+    def download(self, name):
+        if isinstance(name, str):
+            which = self._VEC[name] if name in self._VEC else None
+            if which is None:
+                kind, slot = name[0], int(name[1:])  # "s3", "y0"
+                which = (_ffi.VEC_S0 if kind == "s" else _ffi.VEC_Y0) + slot
+        else:
+            which = name
+        out = np.zeros(self.ctx.n_local)
+        self._check(self._L.lbfgs_state_download(self._h, which, _dp(out)))
+        return out
+
+    def devptr(self, name):
+        return self._L.lbfgs_state_devptr(self._h, self._VEC[name])
+
+    def info(self):
+        k, e = C.c_uint64(), C.c_uint64()
+        s, g = C.c_double(), C.c_double()
+        self._check(self._L.lbfgs_state_info(self._h, C.byref(k), C.byref(e), C.byref(s), C.byref(g)))
+        return dict(k=k.value, end=e.value, step=s.value, gamma=g.value)
+
+    def history_scalars(self):
+        ys, al = np.zeros(self.m), np.zeros(self.m)
+        h = self._L.lbfgs_state_history(self._h)
+        self.ctx.check(self._L.lbfgs_hip_history_scalars_read(h, _dp(ys), _dp(al)))
+        return ys, al
+
+    @property
+    def ls_error(self):
+        return self._L.lbfgs_state_ls_error(self._h).decode()
+
+
+# ------------------------------------------------------------------------------------ builder
+def _assert(cond, msg):
+    if not cond:
+        raise AssertionError(msg)  # the reference's assert! panics (lbfgs.rs:195-361)
+
+
+class Lbfgs:
+    """lbfgs.rs:180-384.  Every setter keeps the reference's name, meaning and assertion."""
+
+    _ALGOS = {
+        "MoreThuente": _ffi.LS_MORETHUENTE,
+        "BacktrackingArmijo": _ffi.LS_BT_ARMIJO,
+        "BacktrackingStrongWolfe": _ffi.LS_BT_STRONGWOLFE,
+        "BacktrackingWolfe": _ffi.LS_BT_WOLFE,
+        "Backtracking": _ffi.LS_BT_WOLFE,
+    }
+
+    def __init__(self):
+        self.param = Param()
+        _ffi.load().lbfgs_param_default(C.byref(self.param))
+
+    def with_epsilon(self, epsilon):
+        _assert(not np.signbit(epsilon), "Invalid parameter epsilon specified.")
+        self.param.epsilon = epsilon
+        return self
+
+    def with_initial_step_size(self, b):
+        _assert(not np.signbit(b), "Invalid beta parameter for scaling the initial step size.")
+        self.param.initial_inverse_hessian = b
+        return self
+
+    def with_max_step_size(self, s):
+        _assert(not np.signbit(s), "Invalid max_step_size parameter.")
+        self.param.max_step_size = s
+        return self
+
+    def with_damping(self, damped):
+        self.param.damping = int(bool(damped))
+        return self
+
+    def with_orthantwise(self, c, start, end=None):
+        _assert(not np.signbit(c), "Invalid parameter orthantwise c parameter specified.")
+        self.param.orthantwise = 1
+        self.param.owl_c = c
+        self.param.owl_start = start
+        self.param.owl_end = -1 if end is None else end
+        return self
+
+    def with_linesearch_ftol(self, ftol):
+        _assert(ftol >= 0.0, "Invalid parameter ftol specified.")
+        self.param.ftol = ftol
+        return self
+
+    def with_linesearch_gtol(self, gtol):
+        _assert(0.0 <= gtol < 1.0 and gtol > self.param.ftol, "Invalid parameter gtol specified.")
+        self.param.gtol = gtol
+        return self
+
+    def with_gradient_only(self):
+        self.param.gradient_only = 1
+        self.param.damping = 1
+        self.param.ls_algorithm = _ffi.LS_BT_STRONGWOLFE
+        return self
+
+    def with_max_linesearch(self, n):
+        self.param.max_linesearch = n
+        return self
+
+    def with_linesearch_xtol(self, xtol):
+        _assert(xtol >= 0.0, "Invalid parameter xtol specified.")
+        self.param.xtol = xtol
+        return self
+
+    def with_linesearch_min_step(self, min_step):
+        _assert(min_step >= 0.0, "Invalid parameter min_step specified.")
+        self.param.min_step = min_step
+        return self
+
+    def with_max_iterations(self, niter):
+        self.param.max_iterations = niter
+        return self
+
+    def with_max_evaluations(self, neval):
+        self.param.max_evaluations = neval
+        return self
+
+    def with_fx_delta(self, delta, past):
+        _assert(delta >= 0.0, "Invalid parameter delta specified.")
+        self.param.past = past
+        self.param.delta = delta
+        return self
+
+    def with_linesearch_algorithm(self, algo):
+        if algo not in self._ALGOS:
+            raise NotImplementedError(algo)  # unimplemented!() lbfgs.rs:379
+        self.param.ls_algorithm = self._ALGOS[algo]
+        return self
+
+    def with_m(self, m):
+        """EXTENSION: number of corrections.  The reference has no setter (always 6);
+        BASELINE.json's configs need m = 7 and m = 10."""
+        _assert(1 <= m <= 64, "m must be in 1..=64")
+        self.param.m = m
+        return self
+
+    def build(self, x, evaluate, *, ctx=None, device=0):
+        """lbfgs.rs:443-481"""
+        return LbfgsState(self.param, x, evaluate, ctx=ctx, device=device)
+
+    def minimize(self, x, evaluate, progress=None, *, ctx=None, device=0):
+        """lbfgs.rs:399-421.  `x` (numpy f64) is the start point and receives the result in place.
+        `progress(prgr) -> bool`: returning True cancels."""
+        if not (isinstance(x, np.ndarray) and x.dtype == np.float64 and x.flags["C_CONTIGUOUS"]):
+            raise TypeError("x must be a C-contiguous float64 numpy array (it is updated in place)")
+        state = self.build(x, evaluate, ctx=ctx, device=device)
+        try:
+            try:
+                while not state.is_converged():
+                    prgr = state.propagate()
+                    if progress is not None and progress(prgr):
+                        break  # "The minimization process has been canceled."
+                return state.report()
+            finally:
+                x[:] = state.download("x")  # `x: &mut [f64]` always holds the current point
+        finally:
+            state.close()
+
+
+def lbfgs():
+    """lib.rs:74"""
+    return Lbfgs()
+
+
+def default_progress():
+    """lib.rs:102-112"""
+
+    def prgr_fn(prgr):
+        print(f"Iteration {prgr.niter}, Evaluation {prgr.neval}:")
+        print(f" fx = {prgr.fx:<12.6f} xnorm = {prgr.xnorm:<12.6f}, gnorm = {prgr.gnorm:<12.6f}, "
+              f"ls = {prgr.ncall}, step = {prgr.step}")
+        return False
+
+    return prgr_fn
+
+
+def default_evaluate():
+    """lib.rs:79-94: Rosenbrock, as a host closure."""
+
+    def evaluate(arr_x, gx):
+        x0, x1 = arr_x[0::2], arr_x[1::2]
+        t1 = 1.0 - x0
+        t2 = 10.0 * (x1 - x0 * x0)
+        gx[1::2] = 20.0 * t2
+        gx[0::2] = -2.0 * (x0 * gx[1::2] + t1)
+        fx = 0.0
+        for v in (t1 * t1 + t2 * t2):
+            fx += v
+        return fx
+
+    return evaluate

@@ -1,0 +1,755 @@
+// rust-lbfgs_amd/csrc/host/solver.cpp -- host orchestration of L-BFGS / OWL-QN above the C-ABI.
+//
+// The reference keeps this layer in Rust: Lbfgs::build / LbfgsState::propagate
+// (src/lbfgs.rs:443-566), Problem (src/core.rs:10-218) and the two line searches
+// (src/line.rs).  Here it is C++ (no Rust toolchain in this image) and it calls
+// nothing but the functions of include/lbfgs_hip.h: every n-vector stays in HBM,
+// this file only moves O(1) scalars per call and decides which point is evaluated
+// next.  The scalar logic is therefore held to the reference operation by
+// operation -- it selects the trial steps, so a one-ulp difference here would
+// change every later iterate.
+//
+// Host synchronisations per iteration: one per line-search trial (f and g.d),
+// one after the history update (||s||, ys, yy, norms) and one after the two-loop
+// (||d||) -- nothing inside the two-loop recursion.
+#include "../../../include/lbfgs_solver.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+// board slots used by this file
+enum Slot {
+    S_F = 0,        // f(x) of the last evaluate
+    S_DG = 1,       // g.d of the last trial
+    S_L1 = 2,       // sum c*|x|          (OWL-QN)
+    S_PGN2 = 3,     // ||pg||^2           (OWL-QN)
+    S_XN2_OWL = 4,  // ||x||^2            (OWL-QN)
+    S_DGINIT = 5,
+    S_UPD = 6,      // ||s||^2, ys, yy, ||x||^2, ||g||^2, s.bs
+    S_DNORM2 = 12,
+    S_DNORM2C = 13,
+    S_NORMS = 14,   // ||x||^2, ||g||^2
+    S_FAILED = 16   // closure failure count (world > 1)
+};
+
+inline bool sign_positive(double v) { return !std::signbit(v); }  // f64::is_sign_positive
+
+// ------------------------------------------------------------------------------------------------
+// More'-Thuente safeguarded step (line.rs:446-606 `mcstep::update_trial_interval`, :620-709)
+// ------------------------------------------------------------------------------------------------
+struct Endpoint {
+    double st, f, dg;  // step, function value, directional derivative
+};
+
+// minimiser of the cubic through (u, fu, du) and (v, fv, dv)            line.rs:620-637
+inline double cubic_min(double u, double fu, double du, double v, double fv, double dv) {
+    const double d = v - u;
+    const double theta = (fu - fv) * 3.0 / d + du + dv;
+    const double s = std::fmax(std::fmax(std::fabs(theta), std::fabs(du)), std::fabs(dv));
+    const double a = theta / s;
+    double gamma = s * std::sqrt(a * a - du / s * (dv / s));
+    if (v < u) gamma = -gamma;
+    const double p = gamma - du + theta;
+    const double q = gamma - du + gamma + dv;
+    const double r = p / q;
+    return u + r * d;
+}
+
+// the guarded variant with fall-back to the interval ends                line.rs:652-680
+inline double cubic_min_bounded(double u, double fu, double du, double v, double fv, double dv, double lo,
+                                double hi) {
+    const double d = v - u;
+    const double theta = (fu - fv) * 3.0 / d + du + dv;
+    const double s = std::fmax(std::fmax(std::fabs(theta), std::fabs(du)), std::fabs(dv));
+    const double a = theta / s;
+    double gamma = s * std::sqrt(std::fmax(0.0, a * a - du / s * (dv / s)));
+    if (u < v) gamma = -gamma;
+    const double p = gamma - dv + theta;
+    const double q = gamma - dv + gamma + du;
+    const double r = p / q;
+    if (r < 0.0 && gamma != 0.0) return v - r * d;
+    return (v > u) ? hi : lo;
+}
+
+inline double quad_min(double u, double fu, double du, double v, double fv) {  // line.rs:692-695
+    const double a = v - u;
+    return u + du / ((fu - fv) / a + du) / 2.0 * a;
+}
+
+inline double secant_min(double u, double du, double v, double dv) {  // line.rs:706-709
+    const double a = u - v;
+    return v + dv / (dv - du) * a;
+}
+
+// Updates the bracket [best, other] and the trial step t.  Returns nullptr, or the bail! message.
+const char* safeguarded_step(Endpoint& best, Endpoint& other, double& t, double ft, double dt, double tmin,
+                             double tmax, bool& bracketed) {
+    const bool opposite = (dt * (best.dg / std::fabs(best.dg))) < 0.0;  // line.rs:461
+
+    if (bracketed) {  // line.rs:470-481
+        if (t <= std::fmin(best.st, other.st) || std::fmax(best.st, other.st) <= t)
+            return "The line-search step went out of the interval of uncertainty.";
+        if (0.0 <= best.dg * (t - best.st))
+            return "The current search direction increases the objective function value.";
+        if (tmax < tmin)
+            return "A logic error occurred; alternatively, the interval of uncertainty became too small.";
+    }
+
+    double next;
+    bool clamp_to_bracket;
+    if (best.f < ft) {  // case 1: higher value -> minimum bracketed                line.rs:484-498
+        bracketed = true;
+        const double mc = cubic_min(best.st, best.f, best.dg, t, ft, dt);
+        const double mq = quad_min(best.st, best.f, best.dg, t, ft);
+        next = (std::fabs(mc - best.st) < std::fabs(mq - best.st)) ? mc : mc + 0.5 * (mq - mc);
+        clamp_to_bracket = true;
+    } else if (opposite) {  // case 2: lower value, derivative changed sign          line.rs:499-513
+        bracketed = true;
+        const double mc = cubic_min(best.st, best.f, best.dg, t, ft, dt);
+        const double mq = secant_min(best.st, best.dg, t, dt);
+        next = (std::fabs(mc - t) > std::fabs(mq - t)) ? mc : mq;
+        clamp_to_bracket = false;
+    } else if (std::fabs(dt) < std::fabs(best.dg)) {  // case 3: derivative shrinks   line.rs:514-538
+        const double mc = cubic_min_bounded(best.st, best.f, best.dg, t, ft, dt, tmin, tmax);
+        const double mq = secant_min(best.st, best.dg, t, dt);
+        if (bracketed)
+            next = (std::fabs(t - mc) < std::fabs(t - mq)) ? mc : mq;
+        else
+            next = (std::fabs(t - mc) > std::fabs(t - mq)) ? mc : mq;
+        clamp_to_bracket = true;
+    } else {  // case 4: derivative does not shrink                                   line.rs:539-553
+        if (bracketed)
+            next = cubic_min(t, ft, dt, other.st, other.f, other.dg);
+        else
+            next = (best.st < t) ? tmax : tmin;
+        clamp_to_bracket = false;
+    }
+
+    if (best.f < ft) {  // line.rs:563-579
+        other = {t, ft, dt};
+    } else {
+        if (opposite) other = best;
+        best = {t, ft, dt};
+    }
+
+    if (tmax < next) next = tmax;  // line.rs:582-587
+    if (next < tmin) next = tmin;
+
+    if (bracketed && clamp_to_bracket) {  // line.rs:591-600
+        const double mq = best.st + 0.66 * (other.st - best.st);
+        if (best.st < other.st) {
+            if (mq < next) next = mq;
+        } else if (next < mq) {
+            next = mq;
+        }
+    }
+    t = next;
+    return nullptr;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// LbfgsState + Problem, device resident
+// ------------------------------------------------------------------------------------------------
+struct lbfgs_state {
+    lbfgs_hip_ctx* ctx = nullptr;
+    lbfgs_param vars{};
+    lbfgs_evaluator eval{};
+    lbfgs_hip_shard shard{};
+    // Problem (core.rs:10-52)
+    lbfgs_hip_vec *x = nullptr, *gx = nullptr, *xp = nullptr, *gp = nullptr, *pg = nullptr, *wp = nullptr,
+                  *d = nullptr;
+    double fx = 0.0;
+    uint64_t neval = 0;
+    uint64_t owl_start = 0, owl_end = 0;
+    bool owl_range_known = false;
+    double xnorm2 = 0.0, gnorm2 = 0.0;  // squared norms at the current point
+    bool norms_valid = false;
+    std::vector<double> host_x, host_g;  // staging for the host closure
+    // LbfgsState (lbfgs.rs:425-439)
+    lbfgs_hip_history* hist = nullptr;
+    int end = 0;
+    double step = 0.0;
+    uint64_t k = 0;
+    uint64_t ncall = 0;
+    double last_gamma = 0.0;
+    std::string err, ls_err;
+
+    bool owlqn() const { return vars.orthantwise != 0; }
+    const lbfgs_hip_vec* grad_for_direction() const { return owlqn() ? pg : gx; }  // core.rs:96-100
+};
+
+namespace {
+
+int fail(lbfgs_state* st, int code, const std::string& msg) {
+    st->err = msg;
+    return code;
+}
+
+int backend(lbfgs_state* st, int rc) {
+    if (rc != LBFGS_HIP_OK) st->err = std::string("backend: ") + lbfgs_hip_last_error(st->ctx);
+    return rc;
+}
+#define TRY(expr)                                  \
+    do {                                           \
+        int rc_ = (expr);                          \
+        if (rc_ != LBFGS_OK) return rc_;           \
+    } while (0)
+#define TRYB(st, expr) TRY(backend(st, (expr)))
+
+// orthantwise.rs:59-67 (global indices)
+int owl_range(lbfgs_state* st) {
+    if (st->owl_range_known) return LBFGS_OK;
+    const uint64_t n = st->shard.n_global;
+    uint64_t e = (st->vars.owl_end < 0) ? n : (uint64_t)st->vars.owl_end;
+    if (e > n) e = n;
+    st->owl_start = st->vars.owl_start;
+    st->owl_end = e;
+    if (!(st->owl_start < st->owl_end)) {
+        char b[128];
+        snprintf(b, sizeof(b), "invalid start for orthantwise: %llu (end = %llu)", (unsigned long long)st->owl_start,
+                 (unsigned long long)st->owl_end);
+        return fail(st, LBFGS_PANIC_OWLQN_RANGE, b);
+    }
+    st->owl_range_known = true;
+    return LBFGS_OK;
+}
+
+// The user's closure (core.rs:120).  Leaves f in board[S_F]; g in st->gx.
+int call_user_evaluate(lbfgs_state* st) {
+    const uint64_t nl = st->shard.n_local;
+    const bool multi = st->shard.world > 1;
+    if (st->eval.kind == LBFGS_EVAL_BUILTIN)
+        return backend(st, lbfgs_hip_objective_eval(&st->eval.builtin, st->x, st->gx, S_F));
+    int failed = 0;
+    double f;
+    if (st->eval.kind == LBFGS_EVAL_HOST) {
+        st->host_x.resize(nl);
+        st->host_g.resize(nl);
+        TRYB(st, lbfgs_hip_vec_download(st->x, st->host_x.data(), nl));
+        f = st->eval.host(st->eval.user, st->host_x.data(), st->host_g.data(), nl, &failed);
+        if (!failed) TRYB(st, lbfgs_hip_vec_upload(st->gx, st->host_g.data(), nl));
+    } else {
+        TRYB(st, lbfgs_hip_sync(st->ctx));
+        f = st->eval.device(st->eval.user, lbfgs_hip_vec_ptr(st->x), lbfgs_hip_vec_ptr(st->gx), nl,
+                            lbfgs_hip_stream(st->ctx), &failed);
+    }
+    if (multi) {  // partial f per shard; a failure on any rank fails all
+        double v[2] = {failed ? 0.0 : f, failed ? 1.0 : 0.0};
+        TRYB(st, lbfgs_hip_scalars_write(st->ctx, S_F, 1, &v[0]));
+        TRYB(st, lbfgs_hip_scalars_write(st->ctx, S_FAILED, 1, &v[1]));
+        TRYB(st, lbfgs_hip_scalars_allreduce(st->ctx, S_F, 1));
+        TRYB(st, lbfgs_hip_scalars_allreduce(st->ctx, S_FAILED, 1));
+        double nf = 0.0;
+        TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_FAILED, 1, &nf));
+        if (nf != 0.0) return fail(st, LBFGS_ERR_EVALUATE, "evaluate failed");
+        return LBFGS_OK;
+    }
+    if (failed) return fail(st, LBFGS_ERR_EVALUATE, "evaluate failed");
+    return backend(st, lbfgs_hip_scalars_write(st->ctx, S_F, 1, &f));
+}
+
+// Problem::evaluate (core.rs:119-132) at the current x; optionally also g.d.  One host sync.
+int evaluate_here(lbfgs_state* st, bool want_dg, double* dg_out) {
+    TRY(call_user_evaluate(st));
+    if (st->owlqn()) {
+        TRY(owl_range(st));  // start_end() asserts on first use, after the closure ran (orthantwise.rs:64)
+        TRYB(st, lbfgs_hip_owlqn_post_eval(st->x, st->gx, st->pg, st->vars.owl_c, st->owl_start, st->owl_end, S_L1));
+    }
+    if (want_dg) TRYB(st, lbfgs_hip_vecdot(st->gx, st->d, S_DG));  // core.rs:114-116: raw gradient
+    double b[5] = {0, 0, 0, 0, 0};
+    TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_F, 5, b));
+    st->fx = b[S_F];
+    if (st->owlqn()) {
+        st->fx += b[S_L1];  // core.rs:124
+        st->gnorm2 = b[S_PGN2];
+        st->xnorm2 = b[S_XN2_OWL];
+        st->norms_valid = true;
+    } else {
+        st->norms_valid = false;
+    }
+    if (dg_out) *dg_out = b[S_DG];
+    st->neval += 1;
+    return LBFGS_OK;
+}
+
+// take_line_step + evaluate + dg_unchecked (line.rs:283-288 / :740-753) for one trial step.
+int trial(lbfgs_state* st, double t, bool want_dg, double* dg_out) {
+    if (st->eval.kind == LBFGS_EVAL_BUILTIN && st->eval.fuse_line_eval && !st->owlqn()) {
+        TRYB(st, lbfgs_hip_objective_line_eval(&st->eval.builtin, st->x, st->xp, st->d, t, st->gx, S_F));
+        double b[2];
+        TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_F, 2, b));
+        st->fx = b[0];
+        if (dg_out) *dg_out = b[1];
+        st->norms_valid = false;
+        st->neval += 1;
+        return LBFGS_OK;
+    }
+    TRYB(st, lbfgs_hip_line_step(st->x, st->xp, st->d, t, st->owlqn() ? st->wp : nullptr, st->owl_start,
+                                 st->owl_end));  // core.rs:155-164
+    return evaluate_here(st, want_dg, dg_out);
+}
+
+int ensure_norms(lbfgs_state* st) {
+    if (st->norms_valid) return LBFGS_OK;
+    TRYB(st, lbfgs_hip_norms_sq(st->x, st->owlqn() ? st->pg : st->gx, S_NORMS));  // core.rs:183-194
+    double b[2];
+    TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_NORMS, 2, b));
+    st->xnorm2 = b[0];
+    st->gnorm2 = b[1];
+    st->norms_valid = true;
+    return LBFGS_OK;
+}
+
+// Progress::new (core.rs:253-268)
+int get_progress(lbfgs_state* st, lbfgs_progress* p) {
+    TRY(ensure_norms(st));
+    p->fx = st->fx;
+    p->xnorm = std::sqrt(st->xnorm2);  // math.rs:73-76
+    p->gnorm = std::sqrt(st->gnorm2);
+    p->neval = st->neval;
+    p->ncall = st->ncall;
+    p->step = st->step;
+    p->niter = st->k;
+    return LBFGS_OK;
+}
+
+// Problem::revert (core.rs:201-204): fx and pg are NOT restored
+int revert(lbfgs_state* st) {
+    TRYB(st, lbfgs_hip_veccpy(st->x, st->xp));
+    TRYB(st, lbfgs_hip_veccpy(st->gx, st->gp));
+    st->norms_valid = false;
+    return LBFGS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// line searches.  Return LBFGS_OK with *ncall, or a hard error; a search failure (the
+// reference's bail!) is reported through *bail and handled by the caller (line.rs:213-220).
+// ------------------------------------------------------------------------------------------------
+int dginit(lbfgs_state* st, double* out) {  // core.rs:78-92 (the gradient of the SAVED point)
+    TRYB(st, lbfgs_hip_vecdot(st->owlqn() ? st->pg : st->gp, st->d, S_DGINIT));
+    return backend(st, lbfgs_hip_scalars_read(st->ctx, S_DGINIT, 1, out));
+}
+
+int search_morethuente(lbfgs_state* st, double& stp, uint64_t* ncall, const char** bail) {  // line.rs:226-399
+    const lbfgs_param& pr = st->vars;
+    double dg0;
+    TRY(dginit(st, &dg0));
+    const double f0 = st->fx;
+    const double dgtest = pr.ftol * dg0;
+    bool bracketed = false, stage1 = true;
+    double width = pr.max_step - pr.min_step;
+    double prev_width = 2.0 * width;
+    Endpoint best{0.0, f0, dg0}, other{0.0, f0, dg0};
+
+    for (uint64_t count = 1; count < pr.max_linesearch; ++count) {
+        double stmin, stmax;
+        if (bracketed) {
+            stmin = (best.st <= other.st) ? best.st : other.st;
+            stmax = (best.st >= other.st) ? best.st : other.st;
+        } else {
+            stmin = best.st;
+            stmax = stp + 4.0 * (stp - best.st);
+        }
+        if (stp < pr.min_step) stp = pr.min_step;
+        if (pr.max_step < stp) stp = pr.max_step;
+
+        // unusual termination: fall back to the best step so far (line.rs:277-281; uinfo is always 0)
+        const bool tight = bracketed && (stmax - stmin <= pr.xtol * stmax);
+        if ((bracketed && (stp <= stmin || stmax <= stp || pr.max_linesearch <= count + 1)) || tight) stp = best.st;
+
+        double dg;
+        int rc = trial(st, stp, true, &dg);
+        if (rc == LBFGS_ERR_EVALUATE) {
+            *bail = "evaluate failed";
+            return LBFGS_OK;
+        }
+        TRY(rc);
+        const double f = st->fx;
+        const double ftest1 = f0 + stp * dgtest;
+
+        // the reference re-tests with the CURRENT stp (line.rs:292-302)
+        if (bracketed && (stp <= stmin || stmax <= stp)) {
+            *bail = "A rounding error occurred; alternatively, no line-search step satisfies the sufficient decrease and curvature conditions.";
+            return LBFGS_OK;
+        }
+        if (tight) {
+            *bail = "Relative width of the interval of uncertainty is at most xtol.";
+            return LBFGS_OK;
+        }
+        if (stp == pr.max_step && f <= ftest1 && dg <= dgtest) {
+            *bail = "The line-search step became larger than LineSearch::max_step.";
+            return LBFGS_OK;
+        }
+        if (stp == pr.min_step && (ftest1 < f || dgtest <= dg)) {
+            *bail = "The line-search step became smaller than LineSearch::min_step.";
+            return LBFGS_OK;
+        }
+        if (std::fabs(dg) <= pr.gtol * -dg0) {  // line.rs:315: the curvature test alone ends the search
+            *ncall = count;
+            return LBFGS_OK;
+        }
+
+        if (stage1 && f <= ftest1 && std::fmin(pr.ftol, pr.gtol) * dg0 <= dg) stage1 = false;  // line.rs:324
+
+        const char* msg;
+        if (stage1 && ftest1 < f && f <= best.f) {  // modified function (line.rs:333-363)
+            Endpoint bm{best.st, best.f - best.st * dgtest, best.dg - dgtest};
+            Endpoint om{other.st, other.f - other.st * dgtest, other.dg - dgtest};
+            msg = safeguarded_step(bm, om, stp, f - stp * dgtest, dg - dgtest, stmin, stmax, bracketed);
+            if (msg) {
+                *bail = msg;
+                return LBFGS_OK;
+            }
+            best = {bm.st, bm.f + bm.st * dgtest, bm.dg + dgtest};
+            other = {om.st, om.f + om.st * dgtest, om.dg + dgtest};
+        } else {
+            msg = safeguarded_step(best, other, stp, f, dg, stmin, stmax, bracketed);
+            if (msg) {
+                *bail = msg;
+                return LBFGS_OK;
+            }
+        }
+        if (!bracketed) continue;
+        if (0.66 * prev_width <= std::fabs(other.st - best.st)) stp = best.st + 0.5 * (other.st - best.st);
+        prev_width = width;
+        width = std::fabs(other.st - best.st);
+    }
+    *ncall = pr.max_linesearch;  // line.rs:398
+    return LBFGS_OK;
+}
+
+int search_backtracking(lbfgs_state* st, double& stp, uint64_t* ncall, const char** bail) {  // line.rs:716-784
+    const lbfgs_param& pr = st->vars;
+    double dg0;
+    TRY(dginit(st, &dg0));
+    const double dec = 0.5, inc = 2.1;
+    const double f0 = st->fx;
+    const double dgtest = pr.ftol * dg0;
+    const bool owl = st->owlqn();
+    if (owl) TRYB(st, lbfgs_hip_orthant_select(st->wp, st->xp, st->pg));  // line.rs:735, core.rs:167-180
+
+    const bool armijo_exit = pr.ls_algorithm == LBFGS_LS_BACKTRACKING_ARMIJO || owl;
+    const bool want_dg = !armijo_exit || pr.gradient_only;
+    for (uint64_t count = 1; count < pr.max_linesearch; ++count) {
+        double dg = 0.0;
+        int rc = trial(st, stp, want_dg, &dg);
+        if (rc == LBFGS_ERR_EVALUATE) {
+            *bail = "evaluate failed";
+            return LBFGS_OK;
+        }
+        TRY(rc);
+        double width;
+        if (st->fx > f0 + stp * dgtest) {
+            width = dec;
+        } else if (armijo_exit) {
+            *ncall = count;
+            return LBFGS_OK;
+        } else if (dg < pr.gtol * dg0) {
+            width = inc;
+        } else if (pr.ls_algorithm == LBFGS_LS_BACKTRACKING_WOLFE) {
+            *ncall = count;
+            return LBFGS_OK;
+        } else if (dg > -pr.gtol * dg0) {
+            width = dec;
+        } else {
+            *ncall = count;
+            return LBFGS_OK;
+        }
+        if (pr.gradient_only && std::fabs(dg) <= -pr.gtol * std::fabs(dg0)) {  // line.rs:768-774
+            *ncall = count;
+            return LBFGS_OK;
+        }
+        if (stp < pr.min_step) {  // line.rs:776, :166-177
+            *bail = "The line-search step became smaller than LineSearch::min_step.";
+            return LBFGS_OK;
+        }
+        if (stp > pr.max_step) {
+            *bail = "The line-search step became larger than LineSearch::max_step.";
+            return LBFGS_OK;
+        }
+        stp *= width;
+    }
+    *ncall = pr.max_linesearch;
+    return LBFGS_OK;
+}
+
+// LineSearch::find (line.rs:193-223).  Expects xp/gp to hold the base point.
+int line_search_find(lbfgs_state* st, double& step, uint64_t* ncall) {
+    const lbfgs_param& pr = st->vars;
+    if (!sign_positive(step)) {
+        char b[96];
+        snprintf(b, sizeof(b), "A logic error (negative line-search step: %g) occurred.", step);
+        return fail(st, LBFGS_ERR_NEGATIVE_STEP, b);
+    }
+    const char* bail = nullptr;
+    st->ls_err.clear();
+    *ncall = 0;
+    if (pr.ls_algorithm == LBFGS_LS_MORETHUENTE && !st->owlqn()) {
+        if (pr.gradient_only)
+            return fail(st, LBFGS_ERR_GRADONLY_MT,
+                        "Gradient only optimization is incompatible with MoreThuente line search.");
+        TRY(search_morethuente(st, step, ncall, &bail));
+    } else {
+        TRY(search_backtracking(st, step, ncall, &bail));
+    }
+    if (bail) {  // swallowed: revert and report 0 calls (line.rs:213-220)
+        st->ls_err = bail;
+        TRY(revert(st));
+        *ncall = 0;
+    }
+    return LBFGS_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+void lbfgs_param_default(lbfgs_param* p) {  // lbfgs.rs:161-176, line.rs:151-162, orthantwise.rs:47-55
+    memset(p, 0, sizeof(*p));
+    p->m = 6;
+    p->epsilon = 1e-5;
+    p->delta = 1e-5;
+    p->initial_inverse_hessian = 1.0;
+    p->max_step_size = 1.0;
+    p->constrain_step_size = 1;
+    p->ls_algorithm = LBFGS_LS_MORETHUENTE;
+    p->ftol = 1e-4;
+    p->gtol = 0.9;
+    p->xtol = 2.220446049250313e-16;
+    p->min_step = 1e-20;
+    p->max_step = 1e20;
+    p->max_linesearch = 20;
+    p->owl_c = 1.0;
+    p->owl_end = -1;
+}
+
+void lbfgs_state_free(lbfgs_state* st) {
+    if (!st) return;
+    lbfgs_hip_history_destroy(st->hist);
+    lbfgs_hip_vec* vs[] = {st->x, st->gx, st->xp, st->gp, st->pg, st->wp, st->d};
+    for (auto* v : vs) lbfgs_hip_vec_free(v);
+    delete st;
+}
+
+static std::string g_build_error;
+
+int lbfgs_build(lbfgs_state** out, lbfgs_hip_ctx* ctx, const lbfgs_param* param, const double* x0,
+                const lbfgs_evaluator* eval) {
+    if (!out || !ctx || !param || !eval || param->m < 1) return LBFGS_ERR_PARAM;
+    *out = nullptr;
+    lbfgs_state* st = new (std::nothrow) lbfgs_state();
+    if (!st) return LBFGS_HIP_ERR_NOMEM;
+    st->ctx = ctx;
+    st->vars = *param;
+    st->eval = *eval;
+    auto bail_out = [&](int rc) {
+        g_build_error = st->err;
+        lbfgs_state_free(st);
+        return rc;
+    };
+    int rc = backend(st, lbfgs_hip_get_shard(ctx, &st->shard));
+    if (rc != LBFGS_OK) return bail_out(rc);
+    // Problem::new (core.rs:59-75): zeroed vectors.  pg/wp only exist under OWL-QN.
+    lbfgs_hip_vec** need[] = {&st->x, &st->gx, &st->xp, &st->gp, &st->d};
+    for (auto** v : need)
+        if ((rc = backend(st, lbfgs_hip_vec_alloc(ctx, v))) != LBFGS_OK) return bail_out(rc);
+    if (st->owlqn()) {
+        if ((rc = backend(st, lbfgs_hip_vec_alloc(ctx, &st->pg))) != LBFGS_OK) return bail_out(rc);
+        if ((rc = backend(st, lbfgs_hip_vec_alloc(ctx, &st->wp))) != LBFGS_OK) return bail_out(rc);
+    }
+    // lbfgs.rs:449: m zeroed (s, y) pairs
+    if ((rc = backend(st, lbfgs_hip_history_create(ctx, (int)param->m, &st->hist))) != LBFGS_OK) return bail_out(rc);
+    if ((rc = backend(st, lbfgs_hip_vec_upload(st->x, x0, st->shard.n_local))) != LBFGS_OK) return bail_out(rc);
+
+    if ((rc = evaluate_here(st, false, nullptr)) != LBFGS_OK) return bail_out(rc);  // lbfgs.rs:454
+    // lbfgs.rs:457: d = -g (or -pg)
+    if ((rc = backend(st, lbfgs_hip_vecncpy(st->d, st->grad_for_direction()))) != LBFGS_OK) return bail_out(rc);
+    // lbfgs.rs:461: step = (1/||d||) * h0, and ||d|| = ||g|| exactly (d = -g)
+    if ((rc = ensure_norms(st)) != LBFGS_OK) return bail_out(rc);
+    st->step = (1.0 / std::sqrt(st->gnorm2)) * param->initial_inverse_hessian;
+    st->end = 0;
+    st->k = 0;
+    st->ncall = 0;
+    *out = st;
+    return LBFGS_OK;
+}
+
+int lbfgs_is_converged(lbfgs_state* st, int* converged) {  // lbfgs.rs:489-494, 697-748
+    if (!st || !converged) return LBFGS_ERR_PARAM;
+    lbfgs_progress p;
+    TRY(get_progress(st, &p));
+    const lbfgs_param& v = st->vars;
+    *converged = 0;
+    if (v.max_iterations != 0 && p.niter >= v.max_iterations) *converged = 1;         // :726-735
+    else if (v.max_evaluations != 0 && p.neval >= v.max_evaluations) *converged = 1;  // :739-748
+    else if (p.gnorm / std::fmax(p.xnorm, 1.0) <= v.epsilon) *converged = 1;          // :715
+    return LBFGS_OK;
+}
+
+int lbfgs_line_search(lbfgs_state* st, double* step, uint64_t* ncall) {
+    if (!st || !step || !ncall) return LBFGS_ERR_PARAM;
+    // stand-alone use (line.rs:8-32 doctest): the base point is the current one
+    TRYB(st, lbfgs_hip_veccpy(st->xp, st->x));
+    TRYB(st, lbfgs_hip_veccpy(st->gp, st->gx));
+    return line_search_find(st, *step, ncall);
+}
+
+int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
+    if (!st) return LBFGS_ERR_PARAM;
+    st->k += 1;
+    if (st->k == 1) return out ? get_progress(st, out) : LBFGS_OK;  // :507-510
+
+    // save_state (core.rs:207-210) without moving bytes: the current point becomes (xp, gp) by
+    // exchanging buffers; every trial then writes x = xp + t*d and a fresh gx.
+    TRYB(st, lbfgs_hip_vec_swap(st->x, st->xp));
+    TRYB(st, lbfgs_hip_vec_swap(st->gx, st->gp));
+    st->norms_valid = false;
+
+    uint64_t ncall = 0;
+    TRY(line_search_find(st, st->step, &ncall));  // :517-521
+    st->ncall = ncall;
+    const double step_ls = st->step;
+
+    // IterationData::update (:525-533, :640-692)
+    const int damping = st->vars.damping;
+    TRYB(st, lbfgs_hip_history_update(st->hist, st->end, st->x, st->xp, st->gx, st->gp, st->step, damping, S_UPD));
+    double u[6] = {0, 0, 0, 0, 0, 0};
+    TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_UPD, damping ? 6 : 5, u));
+    const double snorm = std::sqrt(u[0]), ys = u[1], yy = u[2];
+    if (!(snorm != 0.0)) {
+        char b[96];
+        snprintf(b, sizeof(b), "x not changed with step %g", st->step);
+        return fail(st, LBFGS_ERR_X_NOT_CHANGED, b);  // :646
+    }
+    if (!(yy != 0.0)) return fail(st, LBFGS_ERR_GX_NOT_CHANGED, "gx not changed");  // :655
+    if (!st->owlqn()) {
+        st->xnorm2 = u[3];
+        st->gnorm2 = u[4];
+        st->norms_valid = true;
+    }
+    if (damping) {  // :664-689 (sigma2 = 0.6, sigma3 = 3.0)
+        const double sigma2 = 0.6, sbs = u[5];
+        if (ys < (1.0 - sigma2) * sbs) {  // case 1: y is replaced; ys and gamma are NOT refreshed (:656, :691)
+            const double theta = sigma2 * sbs / (sbs - ys);
+            TRYB(st, lbfgs_hip_history_damp(st->hist, st->end, st->gp, st->step, theta));
+        }
+        // case 2 (:681-685) computes a vector and drops it: nothing to do
+    }
+    st->last_gamma = ys / yy;  // :691 (the device forms the same quotient from the board)
+
+    // update_search_direction + two-loop + dnorm (:536-543), fused on the device
+    int new_end = st->end;
+    TRYB(st, lbfgs_hip_two_loop(st->hist, st->d, st->grad_for_direction(), st->k - 1, st->end, S_UPD + 1, S_UPD + 2,
+                                S_DNORM2, &new_end));
+    st->end = new_end;
+    double dn2;
+    TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_DNORM2, 1, &dn2));
+    const double dnorm = std::sqrt(dn2);
+    if (!sign_positive(dnorm)) return fail(st, LBFGS_ERR_INVALID_DNORM, "invalid norm value");  // :544
+    st->step = st->vars.constrain_step_size ? std::fmin(st->vars.max_step_size, dnorm) / dnorm : 1.0;  // :547-551
+
+    if (st->owlqn()) {  // :554, orthantwise.rs:140-161
+        TRYB(st, lbfgs_hip_constrain_direction(st->d, st->pg, st->owl_start, st->owl_end, S_DNORM2C));
+        double c2;
+        TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_DNORM2C, 1, &c2));
+        if (std::sqrt(c2) == 0.0)
+            return fail(st, LBFGS_PANIC_ZERO_DIRECTION, "invalid direction vector after constraints");
+    }
+    if (out) {
+        TRY(get_progress(st, out));
+        out->step = step_ls;  // :557
+    }
+    return LBFGS_OK;
+}
+
+int lbfgs_get_report(lbfgs_state* st, lbfgs_report* out) {  // lbfgs.rs:497-499, core.rs:288-298
+    if (!st || !out) return LBFGS_ERR_PARAM;
+    TRY(ensure_norms(st));
+    out->fx = st->fx;
+    out->xnorm = std::sqrt(st->xnorm2);
+    out->gnorm = std::sqrt(st->gnorm2);
+    out->neval = st->neval;
+    return LBFGS_OK;
+}
+
+const char* lbfgs_state_error(const lbfgs_state* st) { return st ? st->err.c_str() : g_build_error.c_str(); }
+const char* lbfgs_state_ls_error(const lbfgs_state* st) { return st ? st->ls_err.c_str() : ""; }
+
+static lbfgs_hip_vec* pick(lbfgs_state* st, int which) {
+    switch (which) {
+        case LBFGS_VEC_X: return st->x;
+        case LBFGS_VEC_GX: return st->gx;
+        case LBFGS_VEC_XP: return st->xp;
+        case LBFGS_VEC_GP: return st->gp;
+        case LBFGS_VEC_PG: return st->pg;
+        case LBFGS_VEC_WP: return st->wp;
+        case LBFGS_VEC_D: return st->d;
+        default: break;
+    }
+    const int m = (int)st->vars.m;
+    if (which >= LBFGS_VEC_S0 && which < LBFGS_VEC_S0 + m) return lbfgs_hip_history_s(st->hist, which - LBFGS_VEC_S0);
+    if (which >= LBFGS_VEC_Y0 && which < LBFGS_VEC_Y0 + m) return lbfgs_hip_history_y(st->hist, which - LBFGS_VEC_Y0);
+    return nullptr;
+}
+
+int lbfgs_state_download(lbfgs_state* st, int which, double* host) {
+    if (!st || !host) return LBFGS_ERR_PARAM;
+    lbfgs_hip_vec* v = pick(st, which);
+    if (!v) return fail(st, LBFGS_ERR_PARAM, "no such vector");
+    return backend(st, lbfgs_hip_vec_download(v, host, st->shard.n_local));
+}
+
+void* lbfgs_state_devptr(lbfgs_state* st, int which) {
+    lbfgs_hip_vec* v = st ? pick(st, which) : nullptr;
+    return v ? lbfgs_hip_vec_ptr(v) : nullptr;
+}
+
+int lbfgs_state_info(lbfgs_state* st, uint64_t* k, uint64_t* end, double* step, double* gamma) {
+    if (!st) return LBFGS_ERR_PARAM;
+    if (k) *k = st->k;
+    if (end) *end = (uint64_t)st->end;
+    if (step) *step = st->step;
+    if (gamma) *gamma = st->last_gamma;
+    return LBFGS_OK;
+}
+
+lbfgs_hip_history* lbfgs_state_history(lbfgs_state* st) { return st ? st->hist : nullptr; }
+
+int lbfgs_minimize(lbfgs_hip_ctx* ctx, const lbfgs_param* param, double* x, const lbfgs_evaluator* eval,
+                   lbfgs_progress_cb progress, void* progress_user, lbfgs_report* report, char* errbuf,
+                   size_t errbuf_len) {  // lbfgs.rs:399-421
+    lbfgs_state* st = nullptr;
+    auto note = [&](const char* m) {
+        if (errbuf && errbuf_len) snprintf(errbuf, errbuf_len, "%s", m);
+    };
+    int rc = lbfgs_build(&st, ctx, param, x, eval);
+    if (rc != LBFGS_OK) {
+        note(lbfgs_state_error(nullptr));
+        return rc;
+    }
+    for (;;) {
+        int conv = 0;
+        if ((rc = lbfgs_is_converged(st, &conv)) != LBFGS_OK) break;
+        if (conv) break;
+        lbfgs_progress p;
+        if ((rc = lbfgs_propagate(st, &p)) != LBFGS_OK) break;
+        if (progress && progress(progress_user, &p)) break;
+    }
+    if (rc == LBFGS_OK && report) rc = lbfgs_get_report(st, report);
+    // the caller's x always receives the current point (`x: &mut [f64]` is updated in place)
+    int rc2 = lbfgs_state_download(st, LBFGS_VEC_X, x);
+    if (rc != LBFGS_OK) note(st->err.c_str());
+    else if (rc2 != LBFGS_OK) { note(st->err.c_str()); rc = rc2; }
+    lbfgs_state_free(st);
+    return rc;
+}
+
+}  // extern "C"

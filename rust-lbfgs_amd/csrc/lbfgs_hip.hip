@@ -1,0 +1,959 @@
+// rust-lbfgs_amd/csrc/lbfgs_hip.hip -- implementation of include/lbfgs_hip.h for gfx950 (MI355X).
+//
+// Context (device, stream, scalar board, reduction scratch, communicator), device vectors,
+// and one launch wrapper per C-ABI entry point.  The kernels are instantiations of the
+// streaming skeleton in stream.h over the element operators in ops.h.
+//
+// There is deliberately NO CPU fallback: without a GPU lbfgs_hip_ctx_create() fails with
+// LBFGS_HIP_ERR_NO_DEVICE.
+#include "../../include/lbfgs_hip.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ops.h"
+
+using namespace lh;
+
+// ------------------------------------------------------------------------------------ RCCL (lazy)
+// RCCL is only needed when world > 1, so it is dlopen'ed on first use; a single-GPU process
+// never loads it.
+namespace {
+typedef struct { char internal[128]; } nccl_unique_id_t;
+typedef void* nccl_comm_t;
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(nccl_unique_id_t*) = nullptr;
+    int (*CommInitRank)(nccl_comm_t*, int, nccl_unique_id_t, int) = nullptr;
+    int (*CommDestroy)(nccl_comm_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+Rccl g_rccl;
+const int kNcclDouble = 8, kNcclSum = 0;
+
+bool rccl_load(std::string* err) {
+    if (g_rccl.ok) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) {
+        g_rccl.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.handle) break;
+    }
+    if (!g_rccl.handle) {
+        *err = std::string("cannot dlopen librccl: ") + dlerror();
+        return false;
+    }
+#define LH_SYM(field, name)                                                        \
+    *(void**)(&g_rccl.field) = dlsym(g_rccl.handle, name);                         \
+    if (!g_rccl.field) { *err = std::string("librccl lacks ") + name; return false; }
+    LH_SYM(GetUniqueId, "ncclGetUniqueId")
+    LH_SYM(CommInitRank, "ncclCommInitRank")
+    LH_SYM(CommDestroy, "ncclCommDestroy")
+    LH_SYM(AllReduce, "ncclAllReduce")
+    LH_SYM(GroupStart, "ncclGroupStart")
+    LH_SYM(GroupEnd, "ncclGroupEnd")
+    LH_SYM(GetErrorString, "ncclGetErrorString")
+#undef LH_SYM
+    g_rccl.ok = true;
+    return true;
+}
+std::string g_create_error;  // last error of a failed ctx_create (no ctx to hold it)
+}  // namespace
+
+// ------------------------------------------------------------------------------------ objects
+struct ProfPair {
+    hipEvent_t a, b;
+};
+struct ProfClass {
+    std::vector<ProfPair> pending;
+    uint64_t launches = 0;
+    double ms = 0.0;
+};
+
+struct lbfgs_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    lbfgs_hip_shard shard{};
+    int comm_kind = LBFGS_HIP_COMM_NONE;
+    nccl_comm_t nccl = nullptr;
+    lbfgs_hip_allreduce_cb cb = nullptr;
+    void* cb_user = nullptr;
+    double* board = nullptr;         // LBFGS_HIP_BOARD_SLOTS doubles + 2 ping-pong dots
+    double* partials = nullptr;      // MAX_RED * MAX_GRID
+    unsigned int* ticket = nullptr;
+    double* pinned = nullptr;        // host staging, LBFGS_HIP_BOARD_SLOTS doubles
+    int grid_default = 0;
+    int grid_override = 0;
+    bool prof_on = false;
+    ProfClass prof[LBFGS_HIP_K_CLASSES];
+    std::vector<ProfPair> prof_pool;
+    std::string err;
+};
+
+struct lbfgs_hip_vec {
+    lbfgs_hip_ctx* ctx;
+    double* p;
+};
+
+struct lbfgs_hip_history {
+    lbfgs_hip_ctx* ctx;
+    int m;
+    std::vector<lbfgs_hip_vec*> s, y;
+    double* ys;     // device, m
+    double* alpha;  // device, m
+};
+
+namespace {
+
+int fail(lbfgs_hip_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) return fail(ctx, LBFGS_HIP_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+inline bool slot_ok(int first, int count) {
+    return first >= 0 && count >= 0 && first + count <= LBFGS_HIP_BOARD_SLOTS;
+}
+
+int grid_for(const lbfgs_hip_ctx* ctx) {
+    int g = ctx->grid_override > 0 ? ctx->grid_override : ctx->grid_default;
+    if (g > MAX_GRID) g = MAX_GRID;
+    if (g < 1) g = 1;
+    return g;
+}
+
+// ---- profiling: one event pair per launch of a timed class --------------------------------
+struct ProfScope {
+    lbfgs_hip_ctx* ctx;
+    int k;
+    ProfPair pr{};
+    bool active = false;
+    ProfScope(lbfgs_hip_ctx* c, int kclass) : ctx(c), k(kclass) {
+        if (!ctx->prof_on) return;
+        if (!ctx->prof_pool.empty()) {
+            pr = ctx->prof_pool.back();
+            ctx->prof_pool.pop_back();
+        } else {
+            if (hipEventCreate(&pr.a) != hipSuccess || hipEventCreate(&pr.b) != hipSuccess) return;
+        }
+        active = true;
+        (void)hipEventRecord(pr.a, ctx->stream);
+    }
+    ~ProfScope() {
+        if (!active) return;
+        (void)hipEventRecord(pr.b, ctx->stream);
+        ctx->prof[k].pending.push_back(pr);
+    }
+};
+
+// ---- closing a reduction across ranks --------------------------------------------------------
+// `ptrs` are device addresses (board or history scalars) just written by the last workgroup.
+int allreduce(lbfgs_hip_ctx* ctx, double* const* ptrs, int count) {
+    if (ctx->comm_kind == LBFGS_HIP_COMM_NONE || count == 0) return LBFGS_HIP_OK;
+    ProfScope ps(ctx, LBFGS_HIP_K_COMM);
+    if (ctx->comm_kind == LBFGS_HIP_COMM_RCCL) {
+        // coalesce runs of consecutive addresses into one message each; group them into one launch
+        int rc = g_rccl.GroupStart();
+        if (rc != 0) return fail(ctx, LBFGS_HIP_ERR_COMM, "ncclGroupStart: %s", g_rccl.GetErrorString(rc));
+        int i = 0;
+        while (i < count) {
+            int j = i + 1;
+            while (j < count && ptrs[j] == ptrs[j - 1] + 1) ++j;
+            rc = g_rccl.AllReduce(ptrs[i], ptrs[i], (size_t)(j - i), kNcclDouble, kNcclSum, ctx->nccl, ctx->stream);
+            if (rc != 0) {
+                g_rccl.GroupEnd();
+                return fail(ctx, LBFGS_HIP_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString(rc));
+            }
+            i = j;
+        }
+        rc = g_rccl.GroupEnd();
+        if (rc != 0) return fail(ctx, LBFGS_HIP_ERR_COMM, "ncclGroupEnd: %s", g_rccl.GetErrorString(rc));
+        return LBFGS_HIP_OK;
+    }
+    // host callback: stage through pinned memory (synchronises the stream)
+    for (int i = 0; i < count; ++i)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + i, ptrs[i], sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->cb(ctx->cb_user, ctx->pinned, count) != 0)
+        return fail(ctx, LBFGS_HIP_ERR_COMM, "all-reduce callback failed");
+    for (int i = 0; i < count; ++i)
+        HIP_TRY(ctx, hipMemcpyAsync(ptrs[i], ctx->pinned + i, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    // the staging buffer is reused by the next call: make sure the uploads have left it
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LBFGS_HIP_OK;
+}
+
+// ---- launch one operator ---------------------------------------------------------------------
+template <class Op>
+int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out) {
+    RedCtl red{};
+    red.partials = ctx->partials;
+    red.ticket = ctx->ticket;
+    for (int k = 0; k < Op::NRED; ++k) red.out[k] = red_out[k];
+    const uint64_t n = ctx->shard.n_local;
+    {
+        ProfScope ps(ctx, kclass);
+        hipLaunchKernelGGL((stream_kernel<Op>), dim3(grid_for(ctx)), dim3(BLOCK), 0, ctx->stream, op, n,
+                           ctx->shard.offset, red);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    if (Op::NRED > 0) return allreduce(ctx, red_out, Op::NRED);
+    return LBFGS_HIP_OK;
+}
+
+inline bool same_ctx(const lbfgs_hip_vec* a, const lbfgs_hip_vec* b) { return a && b && a->ctx == b->ctx; }
+
+}  // namespace
+
+// ---- helpers of the C-ABI functions below (templates need C++ linkage) -----------------------
+namespace {
+template <bool NEG_SRC, bool SCALE, int VMODE>
+int two_loop_step(lbfgs_hip_history* h, const double* src, const double* u, const double* v, double* dst,
+                  const double* dot_in, int j, int mode_b, const double* gnum, const double* gden, double* out,
+                  int kclass) {
+    OpTwoLoopStep<NEG_SRC, SCALE, VMODE> op{};
+    op.in[0] = src; op.in[1] = u; op.in[2] = v;
+    op.out[0] = dst;
+    op.dot_in = dot_in;
+    op.ys_j = h->ys + j;
+    op.alpha_j = h->alpha + j;
+    op.gamma_num = gnum;
+    op.gamma_den = gden;
+    op.mode_b = mode_b;
+    double* outs[1] = {out};
+    return launch(h->ctx, kclass, op, outs);
+}
+}  // namespace
+
+namespace {
+int rosen_shape_ok(lbfgs_hip_ctx* ctx) {
+    if ((ctx->shard.n_local & 1) || (ctx->shard.offset & 1))
+        return fail(ctx, LBFGS_HIP_ERR_ARG, "Rosenbrock couples (x[2i], x[2i+1]): shard size and offset must be even");
+    return LBFGS_HIP_OK;
+}
+}  // namespace
+
+namespace {
+int prof_drain(lbfgs_hip_ctx* ctx) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& pc : ctx->prof) {
+        for (auto& pr : pc.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) {
+                pc.ms += ms;
+                pc.launches += 1;
+            }
+            ctx->prof_pool.push_back(pr);
+        }
+        pc.pending.clear();
+    }
+    return LBFGS_HIP_OK;
+}
+}  // namespace
+
+// ==================================================================================== context
+extern "C" {
+
+int lbfgs_hip_abi_version(void) { return LBFGS_HIP_ABI_VERSION; }
+
+int lbfgs_hip_device_count(int* count) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(nullptr, LBFGS_HIP_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = c;
+    return LBFGS_HIP_OK;
+}
+
+int lbfgs_hip_rccl_unique_id(void* out128) {
+    std::string err;
+    if (!out128) return fail(nullptr, LBFGS_HIP_ERR_ARG, "null id buffer");
+    if (!rccl_load(&err)) return fail(nullptr, LBFGS_HIP_ERR_COMM, "%s", err.c_str());
+    nccl_unique_id_t id;
+    int rc = g_rccl.GetUniqueId(&id);
+    if (rc != 0) return fail(nullptr, LBFGS_HIP_ERR_COMM, "ncclGetUniqueId: %s", g_rccl.GetErrorString(rc));
+    memcpy(out128, &id, sizeof(id));
+    return LBFGS_HIP_OK;
+}
+
+int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfgs_hip_shard* shard,
+                         const lbfgs_hip_comm* comm, void* stream) {
+    if (!out) return fail(nullptr, LBFGS_HIP_ERR_ARG, "null out");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, LBFGS_HIP_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(nullptr, LBFGS_HIP_ERR_ARG, "device %d out of range (%d)", device, ndev);
+
+    lbfgs_hip_ctx* ctx = new (std::nothrow) lbfgs_hip_ctx();
+    if (!ctx) return fail(nullptr, LBFGS_HIP_ERR_NOMEM, "out of host memory");
+    ctx->device = device;
+    if (shard) {
+        ctx->shard = *shard;
+        if (shard->world < 1 || shard->rank < 0 || shard->rank >= shard->world ||
+            shard->offset + shard->n_local > shard->n_global) {
+            delete ctx;
+            return fail(nullptr, LBFGS_HIP_ERR_ARG, "inconsistent shard");
+        }
+    } else {
+        ctx->shard.rank = 0;
+        ctx->shard.world = 1;
+        ctx->shard.n_global = n;
+        ctx->shard.offset = 0;
+        ctx->shard.n_local = n;
+    }
+#define CTX_TRY(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            int rc_ = fail(nullptr, LBFGS_HIP_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));   \
+            lbfgs_hip_ctx_destroy(ctx);                                                            \
+            return rc_;                                                                            \
+        }                                                                                          \
+    } while (0)
+    CTX_TRY(hipSetDevice(device));
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        CTX_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    hipDeviceProp_t prop;
+    CTX_TRY(hipGetDeviceProperties(&prop, device));
+    ctx->grid_default = prop.multiProcessorCount * 8;  // 8 x 256-thread workgroups per CU = 32 waves/CU
+    CTX_TRY(hipMalloc(&ctx->board, (LBFGS_HIP_BOARD_SLOTS + 2) * sizeof(double)));
+    CTX_TRY(hipMemsetAsync(ctx->board, 0, (LBFGS_HIP_BOARD_SLOTS + 2) * sizeof(double), ctx->stream));
+    CTX_TRY(hipMalloc(&ctx->partials, (size_t)MAX_RED * MAX_GRID * sizeof(double)));
+    CTX_TRY(hipMalloc(&ctx->ticket, 64));
+    CTX_TRY(hipMemsetAsync(ctx->ticket, 0, 64, ctx->stream));
+    CTX_TRY(hipHostMalloc(&ctx->pinned, LBFGS_HIP_BOARD_SLOTS * sizeof(double), hipHostMallocDefault));
+    CTX_TRY(hipStreamSynchronize(ctx->stream));
+#undef CTX_TRY
+
+    const int kind = comm ? comm->kind : LBFGS_HIP_COMM_NONE;
+    if (ctx->shard.world > 1 && kind == LBFGS_HIP_COMM_NONE) {
+        lbfgs_hip_ctx_destroy(ctx);
+        return fail(nullptr, LBFGS_HIP_ERR_ARG, "world > 1 needs a communicator");
+    }
+    if (kind == LBFGS_HIP_COMM_RCCL) {
+        std::string err;
+        if (!comm->rccl_unique_id || !rccl_load(&err)) {
+            lbfgs_hip_ctx_destroy(ctx);
+            return fail(nullptr, LBFGS_HIP_ERR_COMM, "RCCL unavailable: %s", err.c_str());
+        }
+        nccl_unique_id_t id;
+        memcpy(&id, comm->rccl_unique_id, sizeof(id));
+        int rc = g_rccl.CommInitRank(&ctx->nccl, ctx->shard.world, id, ctx->shard.rank);
+        if (rc != 0) {
+            int r = fail(nullptr, LBFGS_HIP_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(rc));
+            ctx->nccl = nullptr;
+            lbfgs_hip_ctx_destroy(ctx);
+            return r;
+        }
+        ctx->comm_kind = LBFGS_HIP_COMM_RCCL;
+    } else if (kind == LBFGS_HIP_COMM_CALLBACK) {
+        if (!comm->callback) {
+            lbfgs_hip_ctx_destroy(ctx);
+            return fail(nullptr, LBFGS_HIP_ERR_ARG, "callback communicator without a callback");
+        }
+        ctx->cb = comm->callback;
+        ctx->cb_user = comm->callback_user;
+        ctx->comm_kind = LBFGS_HIP_COMM_CALLBACK;
+    }
+    *out = ctx;
+    return LBFGS_HIP_OK;
+}
+
+void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->nccl && g_rccl.ok) g_rccl.CommDestroy(ctx->nccl);
+    for (auto& pc : ctx->prof)
+        for (auto& pr : pc.pending) { (void)hipEventDestroy(pr.a); (void)hipEventDestroy(pr.b); }
+    for (auto& pr : ctx->prof_pool) { (void)hipEventDestroy(pr.a); (void)hipEventDestroy(pr.b); }
+    if (ctx->board) (void)hipFree(ctx->board);
+    if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->ticket) (void)hipFree(ctx->ticket);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* lbfgs_hip_last_error(const lbfgs_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int lbfgs_hip_sync(lbfgs_hip_ctx* ctx) {
+    if (!ctx) return LBFGS_HIP_ERR_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LBFGS_HIP_OK;
+}
+
+void* lbfgs_hip_stream(lbfgs_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int lbfgs_hip_get_shard(const lbfgs_hip_ctx* ctx, lbfgs_hip_shard* out) {
+    if (!ctx || !out) return LBFGS_HIP_ERR_ARG;
+    *out = ctx->shard;
+    return LBFGS_HIP_OK;
+}
+
+int lbfgs_hip_set_grid(lbfgs_hip_ctx* ctx, int blocks) {
+    if (!ctx || blocks < 0 || blocks > MAX_GRID) return LBFGS_HIP_ERR_ARG;
+    ctx->grid_override = blocks;
+    return LBFGS_HIP_OK;
+}
+
+// ==================================================================================== vectors
+int lbfgs_hip_vec_alloc(lbfgs_hip_ctx* ctx, lbfgs_hip_vec** out) {
+    if (!ctx || !out) return LBFGS_HIP_ERR_ARG;
+    *out = nullptr;
+    lbfgs_hip_vec* v = new (std::nothrow) lbfgs_hip_vec();
+    if (!v) return fail(ctx, LBFGS_HIP_ERR_NOMEM, "out of host memory");
+    v->ctx = ctx;
+    size_t bytes = (size_t)ctx->shard.n_local * sizeof(double);
+    bytes = (bytes + 255) / 256 * 256;
+    if (bytes == 0) bytes = 256;
+    hipError_t e = hipMalloc(&v->p, bytes);
+    if (e != hipSuccess) {
+        delete v;
+        return fail(ctx, LBFGS_HIP_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    }
+    e = hipMemsetAsync(v->p, 0, bytes, ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(v->p);
+        delete v;
+        return fail(ctx, LBFGS_HIP_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    *out = v;
+    return LBFGS_HIP_OK;
+}
+
+void lbfgs_hip_vec_free(lbfgs_hip_vec* v) {
+    if (!v) return;
+    (void)hipStreamSynchronize(v->ctx->stream);
+    (void)hipFree(v->p);
+    delete v;
+}
+
+int lbfgs_hip_vec_upload(lbfgs_hip_vec* v, const double* host, uint64_t count) {
+    if (!v || (!host && count)) return LBFGS_HIP_ERR_ARG;
+    lbfgs_hip_ctx* ctx = v->ctx;
+    if (count != ctx->shard.n_local) return fail(ctx, LBFGS_HIP_ERR_ARG, "upload of %llu elements into a shard of %llu",
+                                                 (unsigned long long)count, (unsigned long long)ctx->shard.n_local);
+    if (count == 0) return LBFGS_HIP_OK;
+    HIP_TRY(ctx, hipMemcpyAsync(v->p, host, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host buffer may be pageable and reused by the caller
+    return LBFGS_HIP_OK;
+}
+
+int lbfgs_hip_vec_download(const lbfgs_hip_vec* v, double* host, uint64_t count) {
+    if (!v || (!host && count)) return LBFGS_HIP_ERR_ARG;
+    lbfgs_hip_ctx* ctx = v->ctx;
+    if (count != ctx->shard.n_local) return fail(ctx, LBFGS_HIP_ERR_ARG, "download of %llu elements from a shard of %llu",
+                                                 (unsigned long long)count, (unsigned long long)ctx->shard.n_local);
+    if (count == 0) return LBFGS_HIP_OK;
+    HIP_TRY(ctx, hipMemcpyAsync(host, v->p, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LBFGS_HIP_OK;
+}
+
+void* lbfgs_hip_vec_ptr(lbfgs_hip_vec* v) { return v ? (void*)v->p : nullptr; }
+
+int lbfgs_hip_vec_swap(lbfgs_hip_vec* a, lbfgs_hip_vec* b) {
+    if (!same_ctx(a, b)) return LBFGS_HIP_ERR_ARG;
+    double* t = a->p;
+    a->p = b->p;
+    b->p = t;
+    return LBFGS_HIP_OK;
+}
+
+// ==================================================================================== board
+int lbfgs_hip_scalars_read(lbfgs_hip_ctx* ctx, int first, int count, double* host) {
+    if (!ctx || !host || !slot_ok(first, count)) return LBFGS_HIP_ERR_ARG;
+    if (count == 0) return lbfgs_hip_sync(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, ctx->board + first, count * sizeof(double), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(host, ctx->pinned, count * sizeof(double));
+    return LBFGS_HIP_OK;
+}
+
+int lbfgs_hip_scalars_write(lbfgs_hip_ctx* ctx, int first, int count, const double* host) {
+    if (!ctx || !host || !slot_ok(first, count)) return LBFGS_HIP_ERR_ARG;
+    if (count == 0) return LBFGS_HIP_OK;
+    memcpy(ctx->pinned, host, count * sizeof(double));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->board + first, ctx->pinned, count * sizeof(double), hipMemcpyHostToDevice,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LBFGS_HIP_OK;
+}
+
+void* lbfgs_hip_scalars_ptr(lbfgs_hip_ctx* ctx) { return ctx ? (void*)ctx->board : nullptr; }
+
+int lbfgs_hip_scalars_allreduce(lbfgs_hip_ctx* ctx, int first, int count) {
+    if (!ctx || !slot_ok(first, count) || count > MAX_RED) return LBFGS_HIP_ERR_ARG;
+    double* ptrs[MAX_RED];
+    for (int i = 0; i < count; ++i) ptrs[i] = ctx->board + first + i;
+    return allreduce(ctx, ptrs, count);
+}
+
+// ==================================================================================== primitives
+int lbfgs_hip_vec_fill(lbfgs_hip_vec* v, double value) {
+    if (!v) return LBFGS_HIP_ERR_ARG;
+    OpFill op{};
+    op.out[0] = v->p;
+    op.c = value;
+    return launch(v->ctx, LBFGS_HIP_K_BLAS1, op, nullptr);
+}
+
+int lbfgs_hip_vecadd(lbfgs_hip_vec* y, const lbfgs_hip_vec* x, double c) {
+    if (!same_ctx(y, x)) return LBFGS_HIP_ERR_ARG;
+    OpAxpy op{};
+    op.in[0] = y->p; op.in[1] = x->p; op.out[0] = y->p;
+    op.c_host = c; op.c_dev = nullptr;
+    return launch(y->ctx, LBFGS_HIP_K_BLAS1, op, nullptr);
+}
+
+int lbfgs_hip_vecadd_dev(lbfgs_hip_vec* y, const lbfgs_hip_vec* x, int c_slot) {
+    if (!same_ctx(y, x) || !slot_ok(c_slot, 1)) return LBFGS_HIP_ERR_ARG;
+    OpAxpy op{};
+    op.in[0] = y->p; op.in[1] = x->p; op.out[0] = y->p;
+    op.c_host = 0.0; op.c_dev = y->ctx->board + c_slot;
+    return launch(y->ctx, LBFGS_HIP_K_BLAS1, op, nullptr);
+}
+
+int lbfgs_hip_vecdot(const lbfgs_hip_vec* x, const lbfgs_hip_vec* y, int out_slot) {
+    if (!same_ctx(x, y) || !slot_ok(out_slot, 1)) return LBFGS_HIP_ERR_ARG;
+    OpDot op{};
+    op.in[0] = x->p; op.in[1] = y->p;
+    double* outs[1] = {x->ctx->board + out_slot};
+    return launch(x->ctx, LBFGS_HIP_K_BLAS1, op, outs);
+}
+
+int lbfgs_hip_vecscale(lbfgs_hip_vec* y, double c) {
+    if (!y) return LBFGS_HIP_ERR_ARG;
+    OpScale op{};
+    op.in[0] = y->p; op.out[0] = y->p; op.c = c;
+    return launch(y->ctx, LBFGS_HIP_K_BLAS1, op, nullptr);
+}
+
+int lbfgs_hip_veccpy(lbfgs_hip_vec* y, const lbfgs_hip_vec* x) {
+    if (!same_ctx(y, x)) return LBFGS_HIP_ERR_ARG;
+    OpCopy<false> op{};
+    op.in[0] = x->p; op.out[0] = y->p;
+    return launch(y->ctx, LBFGS_HIP_K_BLAS1, op, nullptr);
+}
+
+int lbfgs_hip_vecncpy(lbfgs_hip_vec* y, const lbfgs_hip_vec* x) {
+    if (!same_ctx(y, x)) return LBFGS_HIP_ERR_ARG;
+    OpCopy<true> op{};
+    op.in[0] = x->p; op.out[0] = y->p;
+    return launch(y->ctx, LBFGS_HIP_K_BLAS1, op, nullptr);
+}
+
+int lbfgs_hip_vecdiff(lbfgs_hip_vec* z, const lbfgs_hip_vec* x, const lbfgs_hip_vec* y) {
+    if (!same_ctx(z, x) || !same_ctx(z, y)) return LBFGS_HIP_ERR_ARG;
+    OpDiff op{};
+    op.in[0] = x->p; op.in[1] = y->p; op.out[0] = z->p;
+    return launch(z->ctx, LBFGS_HIP_K_BLAS1, op, nullptr);
+}
+
+int lbfgs_hip_vec2norm_sq(const lbfgs_hip_vec* x, int out_slot) {
+    if (!x || !slot_ok(out_slot, 1)) return LBFGS_HIP_ERR_ARG;
+    OpNrm2 op{};
+    op.in[0] = x->p;
+    double* outs[1] = {x->ctx->board + out_slot};
+    return launch(x->ctx, LBFGS_HIP_K_BLAS1, op, outs);
+}
+
+// ==================================================================================== fused ops
+int lbfgs_hip_line_step(lbfgs_hip_vec* x, const lbfgs_hip_vec* xp, const lbfgs_hip_vec* d, double step,
+                        const lbfgs_hip_vec* wp, uint64_t start, uint64_t end) {
+    if (!same_ctx(x, xp) || !same_ctx(x, d) || (wp && !same_ctx(x, wp))) return LBFGS_HIP_ERR_ARG;
+    if (wp) {
+        OpLineStep<true> op{};
+        op.in[0] = xp->p; op.in[1] = d->p; op.in[2] = wp->p; op.out[0] = x->p;
+        op.step = step; op.start = start; op.end = end;
+        return launch(x->ctx, LBFGS_HIP_K_LINE, op, nullptr);
+    }
+    OpLineStep<false> op{};
+    op.in[0] = xp->p; op.in[1] = d->p; op.in[2] = nullptr; op.out[0] = x->p;
+    op.step = step; op.start = 0; op.end = 0;
+    return launch(x->ctx, LBFGS_HIP_K_LINE, op, nullptr);
+}
+
+int lbfgs_hip_norms_sq(const lbfgs_hip_vec* x, const lbfgs_hip_vec* g, int out_slot) {
+    if (!same_ctx(x, g) || !slot_ok(out_slot, 2)) return LBFGS_HIP_ERR_ARG;
+    OpNorms2 op{};
+    op.in[0] = x->p; op.in[1] = g->p;
+    double* outs[2] = {x->ctx->board + out_slot, x->ctx->board + out_slot + 1};
+    return launch(x->ctx, LBFGS_HIP_K_BLAS1, op, outs);
+}
+
+// ---- history ---------------------------------------------------------------------------------
+int lbfgs_hip_history_create(lbfgs_hip_ctx* ctx, int m, lbfgs_hip_history** out) {
+    if (!ctx || !out || m < 1 || m > 64) return LBFGS_HIP_ERR_ARG;
+    *out = nullptr;
+    lbfgs_hip_history* h = new (std::nothrow) lbfgs_hip_history();
+    if (!h) return fail(ctx, LBFGS_HIP_ERR_NOMEM, "out of host memory");
+    h->ctx = ctx;
+    h->m = m;
+    h->ys = h->alpha = nullptr;
+    int rc = LBFGS_HIP_OK;
+    for (int i = 0; i < m && rc == LBFGS_HIP_OK; ++i) {
+        lbfgs_hip_vec *s = nullptr, *y = nullptr;
+        rc = lbfgs_hip_vec_alloc(ctx, &s);
+        if (rc == LBFGS_HIP_OK) {
+            h->s.push_back(s);
+            rc = lbfgs_hip_vec_alloc(ctx, &y);
+            if (rc == LBFGS_HIP_OK) h->y.push_back(y);
+        }
+    }
+    if (rc == LBFGS_HIP_OK) {
+        hipError_t e = hipMalloc(&h->ys, 2 * (size_t)m * sizeof(double));
+        if (e != hipSuccess) rc = fail(ctx, LBFGS_HIP_ERR_NOMEM, "hipMalloc history scalars: %s", hipGetErrorString(e));
+        else {
+            h->alpha = h->ys + m;
+            e = hipMemsetAsync(h->ys, 0, 2 * (size_t)m * sizeof(double), ctx->stream);
+            if (e != hipSuccess) rc = fail(ctx, LBFGS_HIP_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+        }
+    }
+    if (rc != LBFGS_HIP_OK) {
+        lbfgs_hip_history_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return LBFGS_HIP_OK;
+}
+
+void lbfgs_hip_history_destroy(lbfgs_hip_history* h) {
+    if (!h) return;
+    for (auto* v : h->s) lbfgs_hip_vec_free(v);
+    for (auto* v : h->y) lbfgs_hip_vec_free(v);
+    if (h->ys) {
+        (void)hipStreamSynchronize(h->ctx->stream);
+        (void)hipFree(h->ys);
+    }
+    delete h;
+}
+
+lbfgs_hip_vec* lbfgs_hip_history_s(lbfgs_hip_history* h, int slot) {
+    return (h && slot >= 0 && slot < h->m) ? h->s[slot] : nullptr;
+}
+lbfgs_hip_vec* lbfgs_hip_history_y(lbfgs_hip_history* h, int slot) {
+    return (h && slot >= 0 && slot < h->m) ? h->y[slot] : nullptr;
+}
+
+int lbfgs_hip_history_scalars_read(lbfgs_hip_history* h, double* ys, double* alpha) {
+    if (!h) return LBFGS_HIP_ERR_ARG;
+    lbfgs_hip_ctx* ctx = h->ctx;
+    if (2 * h->m > LBFGS_HIP_BOARD_SLOTS) return LBFGS_HIP_ERR_ARG;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, h->ys, 2 * (size_t)h->m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ys) memcpy(ys, ctx->pinned, h->m * sizeof(double));
+    if (alpha) memcpy(alpha, ctx->pinned + h->m, h->m * sizeof(double));
+    return LBFGS_HIP_OK;
+}
+
+int lbfgs_hip_history_scalars_write(lbfgs_hip_history* h, const double* ys, const double* alpha) {
+    if (!h) return LBFGS_HIP_ERR_ARG;
+    lbfgs_hip_ctx* ctx = h->ctx;
+    if (ys) HIP_TRY(ctx, hipMemcpyAsync(h->ys, ys, h->m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (alpha) HIP_TRY(ctx, hipMemcpyAsync(h->alpha, alpha, h->m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LBFGS_HIP_OK;
+}
+
+int lbfgs_hip_history_update(lbfgs_hip_history* h, int slot, const lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
+                             const lbfgs_hip_vec* g, const lbfgs_hip_vec* gp, double step, int damping,
+                             int out_slot) {
+    if (!h || slot < 0 || slot >= h->m || !x || !xp || !g || !gp) return LBFGS_HIP_ERR_ARG;
+    lbfgs_hip_ctx* ctx = h->ctx;
+    if (x->ctx != ctx || xp->ctx != ctx || g->ctx != ctx || gp->ctx != ctx) return LBFGS_HIP_ERR_ARG;
+    if (!slot_ok(out_slot, damping ? 6 : 5)) return LBFGS_HIP_ERR_ARG;
+    double* b = ctx->board + out_slot;
+    int rc;
+    if (damping) {
+        OpHistUpdate<true> op{};
+        op.in[0] = x->p; op.in[1] = xp->p; op.in[2] = g->p; op.in[3] = gp->p;
+        op.out[0] = h->s[slot]->p; op.out[1] = h->y[slot]->p;
+        op.neg_step = -step;
+        double* outs[6] = {b, b + 1, b + 2, b + 3, b + 4, b + 5};
+        rc = launch(ctx, LBFGS_HIP_K_UPDATE, op, outs);
+    } else {
+        OpHistUpdate<false> op{};
+        op.in[0] = x->p; op.in[1] = xp->p; op.in[2] = g->p; op.in[3] = gp->p;
+        op.out[0] = h->s[slot]->p; op.out[1] = h->y[slot]->p;
+        op.neg_step = 0.0;
+        double* outs[5] = {b, b + 1, b + 2, b + 3, b + 4};
+        rc = launch(ctx, LBFGS_HIP_K_UPDATE, op, outs);
+    }
+    if (rc != LBFGS_HIP_OK) return rc;
+    // lbfgs.rs:656 self.ys = ys (the GLOBAL y.s, i.e. after the all-reduce)
+    HIP_TRY(ctx, hipMemcpyAsync(h->ys + slot, b + 1, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return LBFGS_HIP_OK;
+}
+
+int lbfgs_hip_history_damp(lbfgs_hip_history* h, int slot, const lbfgs_hip_vec* gp, double step, double theta) {
+    if (!h || slot < 0 || slot >= h->m || !gp || gp->ctx != h->ctx) return LBFGS_HIP_ERR_ARG;
+    OpDamp op{};
+    op.in[0] = gp->p; op.in[1] = h->y[slot]->p; op.out[0] = h->y[slot]->p;
+    op.neg_step = -step;
+    op.one_minus_theta = 1.0 - theta;
+    op.theta = theta;
+    return launch(h->ctx, LBFGS_HIP_K_UPDATE, op, nullptr);
+}
+
+// ---- two-loop recursion ------------------------------------------------------------------------
+
+int lbfgs_hip_two_loop(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
+                       int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int* new_end) {
+    if (!h || !d || !g || d->ctx != h->ctx || g->ctx != h->ctx || end < 0 || end >= h->m || !new_end)
+        return LBFGS_HIP_ERR_ARG;
+    if (!slot_ok(gamma_num_slot, 1) || !slot_ok(gamma_den_slot, 1) || !slot_ok(dnorm_slot, 1)) return LBFGS_HIP_ERR_ARG;
+    lbfgs_hip_ctx* ctx = h->ctx;
+    ProfScope whole(ctx, LBFGS_HIP_K_TWOLOOP_ALL);
+    const int m = h->m;
+    const int e1 = (end + 1) % m;                                   // lbfgs.rs:577
+    const int bound = (int)((uint64_t)m < k ? (uint64_t)m : k);     // lbfgs.rs:579
+    *new_end = e1;
+    const double* gnum = ctx->board + gamma_num_slot;
+    const double* gden = ctx->board + gamma_den_slot;
+    double* dn = ctx->board + dnorm_slot;
+    double* dots = ctx->board + LBFGS_HIP_BOARD_SLOTS;  // 2 private ping-pong slots past the public board
+    if (bound == 0) {
+        // no corrections yet: d = -g, then d *= gamma (lbfgs.rs:591) and ||d||^2
+        int rc = lbfgs_hip_vecncpy(d, g);
+        if (rc != LBFGS_HIP_OK) return rc;
+        OpScaleDevNorm op{};
+        op.in[0] = d->p; op.out[0] = d->p; op.gn = gnum; op.gd = gden;
+        double* outs[1] = {dn};
+        return launch(ctx, LBFGS_HIP_K_TWOLOOP_EDGE, op, outs);
+    }
+    // slot visited at first-loop step i (i = 0..bound-1): j_i = (e1 - 1 - i) mod m   (lbfgs.rs:583)
+    auto jat = [&](int i) { return ((e1 - 1 - i) % m + m) % m; };
+    int pp = 0;
+    int rc;
+    {   // alpha_0 numerator: s_{j0} . (-g)                                         2r
+        OpTwoLoopFirst op{};
+        op.in[0] = g->p; op.in[1] = h->s[jat(0)]->p;
+        double* outs[1] = {dots + pp};
+        rc = launch(ctx, LBFGS_HIP_K_TWOLOOP_EDGE, op, outs);
+        if (rc != LBFGS_HIP_OK) return rc;
+    }
+    // first loop, steps 1..bound-1: q -= alpha_{i-1} y_{j_{i-1}} ; next numerator s_{j_i} . q     3r 1w
+    for (int i = 1; i < bound; ++i) {
+        const int jp = jat(i - 1), jn = jat(i);
+        const double* src = (i == 1) ? g->p : d->p;
+        if (i == 1)
+            rc = two_loop_step<true, false, 0>(h, src, h->y[jp]->p, h->s[jn]->p, d->p, dots + pp, jp, 0, gnum, gden,
+                                               dots + (pp ^ 1), LBFGS_HIP_K_TWOLOOP_STEP);
+        else
+            rc = two_loop_step<false, false, 0>(h, src, h->y[jp]->p, h->s[jn]->p, d->p, dots + pp, jp, 0, gnum, gden,
+                                                dots + (pp ^ 1), LBFGS_HIP_K_TWOLOOP_STEP);
+        if (rc != LBFGS_HIP_OK) return rc;
+        pp ^= 1;
+    }
+    {   // transition: q = gamma*(q - alpha_last y_last) ; beta numerator y_last . q      2r 1w
+        const int jl = jat(bound - 1);
+        if (bound == 1)
+            rc = two_loop_step<true, true, 1>(h, g->p, h->y[jl]->p, nullptr, d->p, dots + pp, jl, 0, gnum, gden,
+                                              dots + (pp ^ 1), LBFGS_HIP_K_TWOLOOP_EDGE);
+        else
+            rc = two_loop_step<false, true, 1>(h, d->p, h->y[jl]->p, nullptr, d->p, dots + pp, jl, 0, gnum, gden,
+                                               dots + (pp ^ 1), LBFGS_HIP_K_TWOLOOP_EDGE);
+        if (rc != LBFGS_HIP_OK) return rc;
+        pp ^= 1;
+    }
+    // second loop (lbfgs.rs:594-601), slots in the reverse order: j = jat(bound-1) ... jat(0)
+    for (int i = bound - 1; i >= 1; --i) {
+        const int j = jat(i), jn = jat(i - 1);  // q += (alpha_j - beta_j) s_j ; next numerator y_{jn} . q   3r 1w
+        rc = two_loop_step<false, false, 0>(h, d->p, h->s[j]->p, h->y[jn]->p, d->p, dots + pp, j, 1, gnum, gden,
+                                            dots + (pp ^ 1), LBFGS_HIP_K_TWOLOOP_STEP);
+        if (rc != LBFGS_HIP_OK) return rc;
+        pp ^= 1;
+    }
+    // last step: q += (alpha_{j0} - beta_{j0}) s_{j0} ; ||d||^2 (lbfgs.rs:543)          2r 1w
+    return two_loop_step<false, false, 2>(h, d->p, h->s[jat(0)]->p, nullptr, d->p, dots + pp, jat(0), 1, gnum, gden, dn,
+                                          LBFGS_HIP_K_TWOLOOP_EDGE);
+}
+
+// Unfused reference sequence (lbfgs.rs:582-601 as written: dot, axpy, ..., scale, dot, axpy, ...)
+
+int lbfgs_hip_two_loop_unfused(lbfgs_hip_history* h, lbfgs_hip_vec* d, uint64_t k, int end, int gamma_num_slot,
+                               int gamma_den_slot, int* new_end) {
+    if (!h || !d || d->ctx != h->ctx || end < 0 || end >= h->m || !new_end) return LBFGS_HIP_ERR_ARG;
+    if (!slot_ok(gamma_num_slot, 1) || !slot_ok(gamma_den_slot, 1)) return LBFGS_HIP_ERR_ARG;
+    lbfgs_hip_ctx* ctx = h->ctx;
+    const int m = h->m;
+    const int e1 = (end + 1) % m;
+    const int bound = (int)((uint64_t)m < k ? (uint64_t)m : k);
+    *new_end = e1;
+    double* dot = ctx->board + LBFGS_HIP_BOARD_SLOTS;
+    int j = e1, rc;
+    for (int it = 0; it < bound; ++it) {
+        j = (j + m - 1) % m;
+        OpDot dt{};
+        dt.in[0] = h->s[j]->p; dt.in[1] = d->p;
+        double* outs[1] = {dot};
+        if ((rc = launch(ctx, LBFGS_HIP_K_BLAS1, dt, outs)) != LBFGS_HIP_OK) return rc;
+        OpAxpyAlpha ax{};
+        ax.in[0] = d->p; ax.in[1] = h->y[j]->p; ax.out[0] = d->p;
+        ax.dot_in = dot; ax.ys_j = h->ys + j; ax.alpha_j = h->alpha + j; ax.mode_b = 0;
+        if ((rc = launch(ctx, LBFGS_HIP_K_BLAS1, ax, nullptr)) != LBFGS_HIP_OK) return rc;
+    }
+    OpScaleDev sc{};
+    sc.in[0] = d->p; sc.out[0] = d->p; sc.gn = ctx->board + gamma_num_slot; sc.gd = ctx->board + gamma_den_slot;
+    if ((rc = launch(ctx, LBFGS_HIP_K_BLAS1, sc, nullptr)) != LBFGS_HIP_OK) return rc;
+    for (int it = 0; it < bound; ++it) {
+        OpDot dt{};
+        dt.in[0] = h->y[j]->p; dt.in[1] = d->p;
+        double* outs[1] = {dot};
+        if ((rc = launch(ctx, LBFGS_HIP_K_BLAS1, dt, outs)) != LBFGS_HIP_OK) return rc;
+        OpAxpyAlpha ax{};
+        ax.in[0] = d->p; ax.in[1] = h->s[j]->p; ax.out[0] = d->p;
+        ax.dot_in = dot; ax.ys_j = h->ys + j; ax.alpha_j = h->alpha + j; ax.mode_b = 1;
+        if ((rc = launch(ctx, LBFGS_HIP_K_BLAS1, ax, nullptr)) != LBFGS_HIP_OK) return rc;
+        j = (j + 1) % m;
+    }
+    return LBFGS_HIP_OK;
+}
+
+// ==================================================================================== OWL-QN
+int lbfgs_hip_owlqn_post_eval(const lbfgs_hip_vec* x, const lbfgs_hip_vec* g, lbfgs_hip_vec* pg, double c,
+                              uint64_t start, uint64_t end, int out_slot) {
+    if (!same_ctx(x, g) || !same_ctx(x, pg) || !slot_ok(out_slot, 3)) return LBFGS_HIP_ERR_ARG;
+    OpOwlPost op{};
+    op.in[0] = x->p; op.in[1] = g->p; op.out[0] = pg->p;
+    op.c = c; op.start = start; op.end = end;
+    double* b = x->ctx->board + out_slot;
+    double* outs[3] = {b, b + 1, b + 2};
+    return launch(x->ctx, LBFGS_HIP_K_OWLQN, op, outs);
+}
+
+int lbfgs_hip_orthant_select(lbfgs_hip_vec* wp, const lbfgs_hip_vec* xp, const lbfgs_hip_vec* pg) {
+    if (!same_ctx(wp, xp) || !same_ctx(wp, pg)) return LBFGS_HIP_ERR_ARG;
+    OpOrthantSelect op{};
+    op.in[0] = xp->p; op.in[1] = pg->p; op.out[0] = wp->p;
+    return launch(wp->ctx, LBFGS_HIP_K_OWLQN, op, nullptr);
+}
+
+int lbfgs_hip_constrain_direction(lbfgs_hip_vec* d, const lbfgs_hip_vec* pg, uint64_t start, uint64_t end,
+                                  int out_slot) {
+    if (!same_ctx(d, pg) || !slot_ok(out_slot, 1)) return LBFGS_HIP_ERR_ARG;
+    OpConstrainDir op{};
+    op.in[0] = d->p; op.in[1] = pg->p; op.out[0] = d->p;
+    op.start = start; op.end = end;
+    double* outs[1] = {d->ctx->board + out_slot};
+    return launch(d->ctx, LBFGS_HIP_K_OWLQN, op, outs);
+}
+
+// ==================================================================================== objectives
+
+int lbfgs_hip_objective_eval(const lbfgs_hip_objective* obj, const lbfgs_hip_vec* x, lbfgs_hip_vec* g, int out_slot) {
+    if (!obj || !same_ctx(x, g) || !slot_ok(out_slot, 1)) return LBFGS_HIP_ERR_ARG;
+    lbfgs_hip_ctx* ctx = x->ctx;
+    double* outs[1] = {ctx->board + out_slot};
+    switch (obj->kind) {
+        case LBFGS_HIP_OBJ_QUADRATIC: {
+            OpObjEval<ObjQuadratic> op{};
+            op.in[0] = x->p; op.out[0] = g->p; op.obj = {obj->seed_a, obj->seed_b};
+            return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
+        }
+        case LBFGS_HIP_OBJ_LOGISTIC: {
+            OpObjEval<ObjLogistic> op{};
+            op.in[0] = x->p; op.out[0] = g->p; op.obj = {obj->seed_a, obj->seed_b};
+            return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
+        }
+        case LBFGS_HIP_OBJ_ROSENBROCK: {
+            int rc = rosen_shape_ok(ctx);
+            if (rc != LBFGS_HIP_OK) return rc;
+            OpRosenEval op{};
+            op.in[0] = x->p; op.out[0] = g->p;
+            return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
+        }
+        default:
+            return fail(ctx, LBFGS_HIP_ERR_ARG, "unknown objective kind %d", obj->kind);
+    }
+}
+
+int lbfgs_hip_objective_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
+                                  const lbfgs_hip_vec* d, double step, lbfgs_hip_vec* g, int out_slot) {
+    if (!obj || !same_ctx(x, xp) || !same_ctx(x, d) || !same_ctx(x, g) || !slot_ok(out_slot, 2)) return LBFGS_HIP_ERR_ARG;
+    lbfgs_hip_ctx* ctx = x->ctx;
+    double* outs[2] = {ctx->board + out_slot, ctx->board + out_slot + 1};
+    switch (obj->kind) {
+        case LBFGS_HIP_OBJ_QUADRATIC: {
+            OpObjLineEval<ObjQuadratic> op{};
+            op.in[0] = xp->p; op.in[1] = d->p; op.out[0] = x->p; op.out[1] = g->p;
+            op.step = step; op.obj = {obj->seed_a, obj->seed_b};
+            return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
+        }
+        case LBFGS_HIP_OBJ_LOGISTIC: {
+            OpObjLineEval<ObjLogistic> op{};
+            op.in[0] = xp->p; op.in[1] = d->p; op.out[0] = x->p; op.out[1] = g->p;
+            op.step = step; op.obj = {obj->seed_a, obj->seed_b};
+            return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
+        }
+        case LBFGS_HIP_OBJ_ROSENBROCK: {
+            int rc = rosen_shape_ok(ctx);
+            if (rc != LBFGS_HIP_OK) return rc;
+            OpRosenLineEval op{};
+            op.in[0] = xp->p; op.in[1] = d->p; op.out[0] = x->p; op.out[1] = g->p;
+            op.step = step;
+            return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
+        }
+        default:
+            return fail(ctx, LBFGS_HIP_ERR_ARG, "unknown objective kind %d", obj->kind);
+    }
+}
+
+// ==================================================================================== measurement
+int lbfgs_hip_prof_enable(lbfgs_hip_ctx* ctx, int on) {
+    if (!ctx) return LBFGS_HIP_ERR_ARG;
+    ctx->prof_on = on != 0;
+    return LBFGS_HIP_OK;
+}
+
+
+int lbfgs_hip_prof_reset(lbfgs_hip_ctx* ctx) {
+    if (!ctx) return LBFGS_HIP_ERR_ARG;
+    int rc = prof_drain(ctx);
+    for (auto& pc : ctx->prof) {
+        pc.launches = 0;
+        pc.ms = 0.0;
+    }
+    return rc;
+}
+
+int lbfgs_hip_prof_read(lbfgs_hip_ctx* ctx, int kclass, uint64_t* launches, double* total_ms) {
+    if (!ctx || kclass < 0 || kclass >= LBFGS_HIP_K_CLASSES) return LBFGS_HIP_ERR_ARG;
+    int rc = prof_drain(ctx);
+    if (launches) *launches = ctx->prof[kclass].launches;
+    if (total_ms) *total_ms = ctx->prof[kclass].ms;
+    return rc;
+}
+
+}  // extern "C"

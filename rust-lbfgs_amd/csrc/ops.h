@@ -1,0 +1,447 @@
+// rust-lbfgs_amd/csrc/ops.h -- element operators of the L-BFGS / OWL-QN hot path.
+//
+// Each operator states what ONE element does; stream.h turns it into a
+// bandwidth-bound kernel.  Arithmetic keeps the reference's roundings: the
+// translation unit is compiled with -ffp-contract=off, so `y + c*x` is a
+// multiply then an add exactly as in the reference's src/math.rs:35.
+// Citations are file:line in the reference crate (ybyygu/rust-lbfgs).
+#pragma once
+#include "stream.h"
+
+namespace lh {
+
+struct NoCoef {};
+
+// orthantwise.rs:174-180: NaN and +-0 -> 0, else the sign
+__device__ __forceinline__ double signum0(double x) {
+    if (x != x || x == 0.0) return 0.0;
+    return (__double_as_longlong(x) < 0) ? -1.0 : 1.0;
+}
+
+// ---------------------------------------------------------------- math.rs primitives
+struct OpDot {  // math.rs:40-42
+    static constexpr int NIN = 2, NOUT = 0, NRED = 1;
+    const double* in[2];
+    double* out[1];
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double*, double* acc, uint64_t) const { acc[0] += v[0] * v[1]; }
+};
+
+struct OpNrm2 {  // math.rs:73-76 (squared)
+    static constexpr int NIN = 1, NOUT = 0, NRED = 1;
+    const double* in[1];
+    double* out[1];
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double*, double* acc, uint64_t) const { acc[0] += v[0] * v[0]; }
+};
+
+struct OpNorms2 {  // core.rs:261-262 ||x||^2 and ||g||^2 in one pass
+    static constexpr int NIN = 2, NOUT = 0, NRED = 2;
+    const double* in[2];
+    double* out[1];
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double*, double* acc, uint64_t) const {
+        acc[0] += v[0] * v[0];
+        acc[1] += v[1] * v[1];
+    }
+};
+
+struct OpAxpy {  // math.rs:33-37  y += c*x ; c from the host or from the board
+    static constexpr int NIN = 2, NOUT = 1, NRED = 0;
+    const double* in[2];  // y, x
+    double* out[1];       // y
+    double c_host;
+    const double* c_dev;  // nullable
+    typedef double Coef;
+    __device__ Coef setup() const { return c_dev ? *c_dev : c_host; }
+    __device__ void elem(const Coef& c, const double* v, double* w, double*, uint64_t) const { w[0] = v[0] + c * v[1]; }
+};
+
+struct OpScale {  // math.rs:45-49
+    static constexpr int NIN = 1, NOUT = 1, NRED = 0;
+    const double* in[1];
+    double* out[1];
+    double c;
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double* w, double*, uint64_t) const { w[0] = v[0] * c; }
+};
+
+template <bool NEG>
+struct OpCopy {  // math.rs:52-56 / 59-63
+    static constexpr int NIN = 1, NOUT = 1, NRED = 0;
+    const double* in[1];
+    double* out[1];
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double* w, double*, uint64_t) const { w[0] = NEG ? -v[0] : v[0]; }
+};
+
+struct OpDiff {  // math.rs:66-70  z = x - y
+    static constexpr int NIN = 2, NOUT = 1, NRED = 0;
+    const double* in[2];
+    double* out[1];
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double* w, double*, uint64_t) const { w[0] = v[0] - v[1]; }
+};
+
+// ---------------------------------------------------------------- line step
+// core.rs:155-164: x = xp (veccpy) ; x += step*d (vecadd) ; [project onto wp on [start,end)]
+template <bool PROJECT>
+struct OpLineStep {
+    static constexpr int NIN = PROJECT ? 3 : 2, NOUT = 1, NRED = 0;
+    const double* in[3];  // xp, d, wp
+    double* out[1];       // x
+    double step;
+    uint64_t start, end;  // global
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double* w, double*, uint64_t gi) const {
+        double x = v[0] + step * v[1];
+        if constexpr (PROJECT) {
+            // orthantwise.rs:165-171
+            if (gi >= start && gi < end && signum0(x) != signum0(v[2])) x = 0.0;
+        }
+        w[0] = x;
+    }
+};
+
+// ---------------------------------------------------------------- history update
+// lbfgs.rs:640-673, one pass: s = x-xp, y = g-gp, ||s||^2, y.s, y.y, ||x||^2, ||g||^2 [, s.bs]
+template <bool DAMP>
+struct OpHistUpdate {
+    static constexpr int NIN = 4, NOUT = 2, NRED = DAMP ? 6 : 5;
+    const double* in[4];  // x, xp, g, gp
+    double* out[2];       // s, y
+    double neg_step;      // -step (lbfgs.rs:671)
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double* w, double* acc, uint64_t) const {
+        const double s = v[0] - v[1];
+        const double y = v[2] - v[3];
+        w[0] = s;
+        w[1] = y;
+        acc[0] += s * s;
+        acc[1] += y * s;
+        acc[2] += y * y;
+        acc[3] += v[0] * v[0];
+        acc[4] += v[2] * v[2];
+        if constexpr (DAMP) acc[5] += s * (v[3] * neg_step);
+    }
+};
+
+// lbfgs.rs:675-680 damping case 1: bs = gp*(-step); bs *= (1-theta); bs += theta*y; y = bs
+struct OpDamp {
+    static constexpr int NIN = 2, NOUT = 1, NRED = 0;
+    const double* in[2];  // gp, y
+    double* out[1];       // y
+    double neg_step, one_minus_theta, theta;
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double* w, double*, uint64_t) const {
+        double bs = v[0] * neg_step;
+        bs = bs * one_minus_theta;
+        w[0] = bs + theta * v[1];
+    }
+};
+
+// ---------------------------------------------------------------- two-loop recursion (lbfgs.rs:569-604)
+// First dot: alpha_0 numerator = s . d with d = -g folded in (core.rs:95-101).  2r.
+struct OpTwoLoopFirst {
+    static constexpr int NIN = 2, NOUT = 0, NRED = 1;
+    const double* in[2];  // g, s
+    double* out[1];
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double*, double* acc, uint64_t) const { acc[0] += v[1] * (-v[0]); }
+};
+
+// One fused step:   q = [ -src | src ] + c*u ;  [ q *= gamma ] ;  dst = q ;  sum += w*q
+//   VMODE 0: w is a third stream v        (3r 1w)  -- the dominant kernel
+//   VMODE 1: w = u  (gamma transition)    (2r 1w)
+//   VMODE 2: w = q  (last step, ||d||^2)  (2r 1w)
+// The coefficient is formed on the device from the previous reduction (no host round trip):
+//   mode A (first loop, lbfgs.rs:587-589):  alpha_j = dot/ys_j ; c = -alpha_j   (alpha_j is stored)
+//   mode B (second loop, lbfgs.rs:597-599): beta = dot/ys_j ;    c = alpha_j - beta
+struct TwoLoopCoef {
+    double c, gamma;
+};
+template <bool NEG_SRC, bool SCALE, int VMODE>
+struct OpTwoLoopStep {
+    static constexpr int NIN = (VMODE == 0) ? 3 : 2, NOUT = 1, NRED = 1;
+    const double* in[3];  // src, u, v
+    double* out[1];       // dst (= d)
+    const double* dot_in; // previous reduction (global sum)
+    const double* ys_j;   // ys of the slot whose coefficient this step applies
+    double* alpha_j;      // alpha of that slot (written in mode A, read in mode B)
+    const double* gamma_num;
+    const double* gamma_den;
+    int mode_b;
+    typedef TwoLoopCoef Coef;
+    __device__ Coef setup() const {
+        Coef cf;
+        const double r = *dot_in / *ys_j;
+        if (mode_b) {
+            cf.c = *alpha_j - r;
+        } else {
+            cf.c = -r;
+            if (blockIdx.x == 0 && threadIdx.x == 0) *alpha_j = r;
+        }
+        cf.gamma = SCALE ? (*gamma_num / *gamma_den) : 1.0;  // lbfgs.rs:691 ys/yy
+        return cf;
+    }
+    __device__ void elem(const Coef& cf, const double* v, double* w, double* acc, uint64_t) const {
+        const double src = NEG_SRC ? -v[0] : v[0];
+        double q = src + cf.c * v[1];          // math.rs:35
+        if constexpr (SCALE) q = q * cf.gamma; // math.rs:47
+        w[0] = q;
+        const double wv = (VMODE == 0) ? v[2] : (VMODE == 1 ? v[1] : q);
+        acc[0] += wv * q;                      // math.rs:41
+    }
+};
+
+// ---------------------------------------------------------------- OWL-QN (orthantwise.rs, core.rs)
+// core.rs:123-126 after the user's evaluate: sum c*|x| (orthantwise.rs:70-79), pseudo-gradient
+// (orthantwise.rs:82-112), ||pg||^2 (core.rs:185) and ||x||^2 (core.rs:193).  2r 1w.
+struct OpOwlPost {
+    static constexpr int NIN = 2, NOUT = 1, NRED = 3;
+    const double* in[2];  // x, g
+    double* out[1];       // pg
+    double c;
+    uint64_t start, end;
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double* w, double* acc, uint64_t gi) const {
+        const double x = v[0], g = v[1];
+        double pg = g;
+        if (gi >= start && gi < end) {
+            acc[0] += c * fabs(x);
+            if (x != 0.0) {
+                // f64::signum of a non-zero x (NaN propagates)
+                const double sg = (x != x) ? x : ((__double_as_longlong(x) < 0) ? -1.0 : 1.0);
+                pg = g + sg * c;
+            } else {
+                const double right_partial = g + c, left_partial = g - c;
+                pg = (right_partial < 0.0) ? right_partial : ((left_partial > 0.0) ? left_partial : 0.0);
+            }
+        }
+        w[0] = pg;
+        acc[1] += pg * pg;
+        acc[2] += x * x;
+    }
+};
+
+// core.rs:167-180 over ALL i
+struct OpOrthantSelect {
+    static constexpr int NIN = 2, NOUT = 1, NRED = 0;
+    const double* in[2];  // xp, pg
+    double* out[1];       // wp
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double* w, double*, uint64_t) const {
+        w[0] = (v[0] == 0.0) ? signum0(-v[1]) : signum0(v[0]);
+    }
+};
+
+// orthantwise.rs:140-161: d_i = 0 where signum(d_i) != signum(-pg_i) on [start,end); ||d||^2
+struct OpConstrainDir {
+    static constexpr int NIN = 2, NOUT = 1, NRED = 1;
+    const double* in[2];  // d, pg
+    double* out[1];       // d
+    uint64_t start, end;
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double* w, double* acc, uint64_t gi) const {
+        double d = v[0];
+        if (gi >= start && gi < end && signum0(d) != signum0(-v[1])) d = 0.0;
+        w[0] = d;
+        acc[0] += d * d;
+    }
+};
+
+// ---------------------------------------------------------------- device-resident objectives
+// The synthetic workloads of BASELINE.json configs 2-4.  Data comes from a counter-based hash of
+// the GLOBAL index, built from + and * only, so every rank and the CPU oracle (an independent C
+// restatement in oracle/objectives.c) generate bit-identical a_i, b_i, t_i with nothing stored.
+__device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double hash_u01(uint64_t seed, uint64_t i) {
+    return (double)(mix64(seed, i) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+struct ObjQuadratic {  // f_i = x*(0.5*a*x - b), g_i = a*x - b ; a = 1 + 999*u^2, b = 2*u' - 1
+    uint64_t seed_a, seed_b;
+    __device__ void eval(double x, uint64_t gi, double& f, double& g) const {
+        const double ua = hash_u01(seed_a, gi), ub = hash_u01(seed_b, gi);
+        const double a = 1.0 + 999.0 * (ua * ua);
+        const double b = 2.0 * ub - 1.0;
+        const double t = a * x;
+        g = t - b;
+        f = x * (0.5 * t - b);
+    }
+};
+
+struct ObjLogistic {  // f_i = log(1+exp(-w*x)), w = +-(0.5 + 1.5*u)
+    uint64_t seed_a, seed_b;
+    __device__ void eval(double x, uint64_t gi, double& f, double& g) const {
+        const double a = 0.5 + 1.5 * hash_u01(seed_a, gi);
+        const double w = (mix64(seed_b, gi) >> 63) ? a : -a;
+        const double z = w * x;
+        const double e = exp(-fabs(z));
+        double fi = log1p(e);
+        double sig;
+        if (z >= 0.0) {
+            sig = e / (1.0 + e);
+        } else {
+            sig = 1.0 / (1.0 + e);
+            fi -= z;
+        }
+        g = -w * sig;
+        f = fi;
+    }
+};
+
+template <class Obj>
+struct OpObjEval {  // core.rs:119-121 with the closure resident on the device.  1r 1w.
+    static constexpr int NIN = 1, NOUT = 1, NRED = 1;
+    const double* in[1];  // x
+    double* out[1];       // g
+    Obj obj;
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double* w, double* acc, uint64_t gi) const {
+        double f, g;
+        obj.eval(v[0], gi, f, g);
+        w[0] = g;
+        acc[0] += f;
+    }
+};
+
+template <class Obj>
+struct OpObjLineEval {  // take_line_step + evaluate + dg_unchecked (core.rs:155-158,119-121,114-116).  2r 2w.
+    static constexpr int NIN = 2, NOUT = 2, NRED = 2;
+    const double* in[2];  // xp, d
+    double* out[2];       // x, g
+    double step;
+    Obj obj;
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double* w, double* acc, uint64_t gi) const {
+        const double x = v[0] + step * v[1];
+        double f, g;
+        obj.eval(x, gi, f, g);
+        w[0] = x;
+        w[1] = g;
+        acc[0] += f;
+        acc[1] += g * v[1];
+    }
+};
+
+// src/lib.rs:79-94 default_evaluate: couples (x[2i], x[2i+1]); n and the shard offset must be even.
+struct RosenPair {
+    __device__ static void eval(double x0, double x1, double& f, double& g0, double& g1) {
+        const double t1 = 1.0 - x0;
+        const double t2 = 10.0 * (x1 - x0 * x0);
+        g1 = 20.0 * t2;
+        g0 = -2.0 * (x0 * g1 + t1);
+        f = t1 * t1 + t2 * t2;
+    }
+};
+struct OpRosenEval {
+    static constexpr bool PAIRWISE = true;
+    static constexpr int NIN = 1, NOUT = 1, NRED = 1;
+    const double* in[1];
+    double* out[1];
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void pair(const Coef&, const d2* v, d2* w, double* acc, uint64_t) const {
+        double f, g0, g1;
+        RosenPair::eval(v[0].x, v[0].y, f, g0, g1);
+        w[0].x = g0;
+        w[0].y = g1;
+        acc[0] += f;
+    }
+};
+struct OpRosenLineEval {
+    static constexpr bool PAIRWISE = true;
+    static constexpr int NIN = 2, NOUT = 2, NRED = 2;
+    const double* in[2];  // xp, d
+    double* out[2];       // x, g
+    double step;
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void pair(const Coef&, const d2* v, d2* w, double* acc, uint64_t) const {
+        const double x0 = v[0].x + step * v[1].x, x1 = v[0].y + step * v[1].y;
+        double f, g0, g1;
+        RosenPair::eval(x0, x1, f, g0, g1);
+        w[0].x = x0;
+        w[0].y = x1;
+        w[1].x = g0;
+        w[1].y = g1;
+        acc[0] += f;
+        acc[1] += g0 * v[1].x;
+        acc[1] += g1 * v[1].y;
+    }
+};
+
+// ---------------------------------------------------------------- small helpers used by the C-ABI
+struct OpFill {  // vec![c; n]
+    static constexpr int NIN = 0, NOUT = 1, NRED = 0;
+    const double* in[1];
+    double* out[1];
+    double c;
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double*, double* w, double*, uint64_t) const { w[0] = c; }
+};
+
+struct OpScaleDevNorm {  // d *= gamma (gamma = board ratio) and ||d||^2: two-loop with no corrections stored
+    static constexpr int NIN = 1, NOUT = 1, NRED = 1;
+    const double* in[1];
+    double* out[1];
+    const double *gn, *gd;
+    typedef double Coef;
+    __device__ Coef setup() const { return *gn / *gd; }
+    __device__ void elem(const Coef& c, const double* v, double* w, double* acc, uint64_t) const {
+        w[0] = v[0] * c;
+        acc[0] += w[0] * w[0];
+    }
+};
+
+// the reference's UNFUSED two-loop (lbfgs.rs:582-601 as written), coefficient formed on the device
+struct OpAxpyAlpha {  // y += c*x with c formed on the device like the fused step does
+    static constexpr int NIN = 2, NOUT = 1, NRED = 0;
+    const double* in[2];
+    double* out[1];
+    const double* dot_in;
+    const double* ys_j;
+    double* alpha_j;
+    int mode_b;
+    typedef double Coef;
+    __device__ Coef setup() const {
+        const double r = *dot_in / *ys_j;
+        if (mode_b) return *alpha_j - r;
+        if (blockIdx.x == 0 && threadIdx.x == 0) *alpha_j = r;
+        return -r;
+    }
+    __device__ void elem(const Coef& c, const double* v, double* w, double*, uint64_t) const { w[0] = v[0] + c * v[1]; }
+};
+struct OpScaleDev {
+    static constexpr int NIN = 1, NOUT = 1, NRED = 0;
+    const double* in[1];
+    double* out[1];
+    const double *gn, *gd;
+    typedef double Coef;
+    __device__ Coef setup() const { return *gn / *gd; }
+    __device__ void elem(const Coef& c, const double* v, double* w, double*, uint64_t) const { w[0] = v[0] * c; }
+};
+
+}  // namespace lh

@@ -1,0 +1,94 @@
+"""One process per GPU: contiguous sharding of the n-vector and the scalar all-reduce.
+
+Every hot-path op is element-wise or a sum over i, so rank r owns the contiguous index range
+``shard_range(n, r, world)`` of x, g, xp, gp, d, pg, wp and all 2m history vectors, and the only
+cross-rank traffic is a sum all-reduce of 1-6 f64 scalars per reduction -- RCCL
+``ncclAllReduce(ncclDouble, ncclSum)`` enqueued on the compute stream by liblbfgs_hip.so.
+`torch.distributed` is used here only to rendezvous (share the RCCL unique id), or -- with
+``kind="callback"`` -- as a host all-reduce (gloo) for tests and for machines without RCCL.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from .api import Context, LbfgsError
+
+ALIGN = 256  # shard boundaries are multiples of 256 elements (2 KiB): keeps 16-B loads aligned
+
+
+def shard_range(n, rank, world, align=ALIGN):
+    """[lo, hi) of `rank`: ceil(n/world) rounded up to `align`, last ranks may be short or empty."""
+    per = -(-n // world)
+    per = -(-per // align) * align
+    lo = min(n, rank * per)
+    hi = min(n, lo + per)
+    return lo, hi
+
+
+class CommSpec:
+    """Keeps the ctypes lbfgs_hip_comm and whatever it points at alive."""
+
+    def __init__(self, kind, unique_id=None, callback=None):
+        self.c = _ffi.Comm()
+        self.c.kind = kind
+        self._id = unique_id
+        self._cb = callback
+        if unique_id is not None:
+            self.c.rccl_unique_id = C.cast(unique_id, C.c_void_p)
+        if callback is not None:
+            self.c.callback = callback
+
+
+def rccl_comm(process_group=None):
+    """RCCL communicator: rank 0 makes the unique id, torch.distributed broadcasts it."""
+    import torch.distributed as dist
+
+    L = _ffi.load()
+    buf = (C.c_char * 128)()
+    if dist.get_rank(process_group) == 0:
+        rc = L.lbfgs_hip_rccl_unique_id(buf)
+        if rc != 0:
+            raise LbfgsError(rc, L.lbfgs_hip_last_error(None).decode())
+    obj = [bytes(buf.raw)]
+    dist.broadcast_object_list(obj, src=0, group=process_group)
+    C.memmove(buf, obj[0], 128)
+    return CommSpec(_ffi.COMM_RCCL, unique_id=buf)
+
+
+def callback_comm(process_group=None):
+    """Host all-reduce through torch.distributed (gloo or nccl group): slow, for tests."""
+    import torch
+    import torch.distributed as dist
+
+    def allreduce(_user, buf, count):
+        try:
+            a = np.ctypeslib.as_array(buf, shape=(count,))
+            t = torch.from_numpy(a.copy())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)
+            a[:] = t.numpy()
+            return 0
+        except Exception:
+            return 1
+
+    return CommSpec(_ffi.COMM_CALLBACK, callback=_ffi.ALLREDUCE_CB(allreduce))
+
+
+def sharded_context(n, device=0, kind="rccl", process_group=None, stream=None):
+    """Context for this rank's shard of a global n-vector (world from torch.distributed)."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+    lo, hi = shard_range(n, rank, world)
+    shard = _ffi.Shard(rank, world, n, lo, hi - lo)
+    if world == 1:
+        comm = None
+    elif kind == "rccl":
+        comm = rccl_comm(process_group)
+    elif kind == "callback":
+        comm = callback_comm(process_group)
+    else:
+        raise ValueError(kind)
+    return Context(n, device=device, shard=shard, comm=comm, stream=stream)

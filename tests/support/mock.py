@@ -1,0 +1,46 @@
+"""Build / load the CPU test double of the C-ABI (TEST INFRASTRUCTURE).
+
+tests/support/liblbfgs_solver_mock.so = the product's host orchestration
+(rust-lbfgs_amd/csrc/host/solver.cpp, compiled unchanged) linked against
+tests/support/mock_lbfgs_hip.cpp (the C-ABI restated on the CPU from the oracle's
+primitives) instead of the HIP library.  Used only by the `-m "not gpu"` suite.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+LIB = os.path.join(HERE, "liblbfgs_solver_mock.so")
+SRCS = [
+    os.path.join(ROOT, "rust-lbfgs_amd", "csrc", "host", "solver.cpp"),
+    os.path.join(HERE, "mock_lbfgs_hip.cpp"),
+]
+C_SRCS = [os.path.join(ROOT, "oracle", "lbfgs_oracle.c"), os.path.join(ROOT, "oracle", "objectives.c")]
+HDRS = [os.path.join(ROOT, "include", "lbfgs_hip.h"), os.path.join(ROOT, "include", "lbfgs_solver.h"),
+        os.path.join(ROOT, "oracle", "lbfgs_oracle.h")]
+
+
+def build(force=False):
+    deps = SRCS + C_SRCS + HDRS
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+        return LIB
+    objs = []
+    flags = ["-O2", "-ffp-contract=off", "-fPIC", "-Wall"]
+    for s in C_SRCS:
+        o = os.path.join(HERE, os.path.basename(s) + ".o")
+        subprocess.run(["gcc", "-std=c11", *flags, "-c", s, "-o", o], check=True, capture_output=True)
+        objs.append(o)
+    r = subprocess.run(["g++", "-std=c++17", *flags, "-shared", *SRCS, *objs, "-o", LIB, "-lm", "-Wl,-Bsymbolic"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    return LIB
+
+
+def load():
+    """-> ctypes library with the declarations of rust_lbfgs_amd._ffi attached."""
+    import rust_lbfgs_amd  # noqa: F401  (registers the package alias)
+    from rust_lbfgs_amd import _ffi
+
+    return _ffi.declare(C.CDLL(build()))

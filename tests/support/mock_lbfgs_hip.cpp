@@ -1,0 +1,323 @@
+// tests/support/mock_lbfgs_hip.cpp -- TEST DOUBLE of include/lbfgs_hip.h on the CPU.
+//
+// TEST INFRASTRUCTURE ONLY.  It exists so that the host orchestration
+// (rust-lbfgs_amd/csrc/host/solver.cpp) -- line-search state machines, stop tests,
+// error paths, sharding and the all-reduce plumbing -- can be exercised in the
+// `-m "not gpu"` suite, where there is no GPU.  It is linked ONLY into
+// tests/support/liblbfgs_solver_mock.so, never into the product libraries, and the
+// product never falls back to it: rust-lbfgs_amd/liblbfgs_hip.so has no CPU path.
+//
+// Every operation is composed from the CPU oracle's primitives (oracle/) in the
+// reference's unfused order with sequential sums, so with world == 1 the solver on
+// this mock must reproduce the oracle -- and the reference's 17-digit known answers
+// -- bit for bit.  With world > 1 each rank holds a contiguous shard and scalars are
+// closed through the callback communicator (torch.distributed / gloo in the tests).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lbfgs_hip.h"
+#include "../../oracle/lbfgs_oracle.h"
+
+struct lbfgs_hip_ctx {
+    lbfgs_hip_shard shard{};
+    int comm_kind = LBFGS_HIP_COMM_NONE;
+    lbfgs_hip_allreduce_cb cb = nullptr;
+    void* cb_user = nullptr;
+    double board[LBFGS_HIP_BOARD_SLOTS + 2] = {0};
+    std::string err;
+    uint64_t n_allreduce = 0;
+};
+struct lbfgs_hip_vec {
+    lbfgs_hip_ctx* ctx;
+    std::vector<double>* p;
+};
+struct lbfgs_hip_history {
+    lbfgs_hip_ctx* ctx;
+    int m;
+    std::vector<lbfgs_hip_vec*> s, y;
+    std::vector<double> ys, alpha;
+};
+
+namespace {
+std::string g_err;
+int fail(lbfgs_hip_ctx* c, int code, const char* msg) {
+    (c ? c->err : g_err) = msg;
+    return code;
+}
+bool slot_ok(int first, int count) { return first >= 0 && count >= 0 && first + count <= LBFGS_HIP_BOARD_SLOTS; }
+size_t nl(const lbfgs_hip_ctx* c) { return (size_t)c->shard.n_local; }
+
+int allreduce(lbfgs_hip_ctx* c, double* v, int count) {
+    if (c->comm_kind == LBFGS_HIP_COMM_NONE) return LBFGS_HIP_OK;
+    c->n_allreduce += 1;
+    if (c->cb(c->cb_user, v, count) != 0) return fail(c, LBFGS_HIP_ERR_COMM, "all-reduce callback failed");
+    return LBFGS_HIP_OK;
+}
+int gdot(lbfgs_hip_ctx* c, const double* a, const double* b, double* out) {
+    *out = oracle_vecdot(a, b, nl(c));
+    return allreduce(c, out, 1);
+}
+// clamp a global [start,end) to this shard, in local indices
+void local_range(const lbfgs_hip_ctx* c, uint64_t start, uint64_t end, size_t* ls, size_t* le) {
+    const uint64_t lo = c->shard.offset, hi = c->shard.offset + c->shard.n_local;
+    uint64_t s = start < lo ? lo : start, e = end > hi ? hi : end;
+    if (s >= e) { *ls = *le = 0; return; }
+    *ls = (size_t)(s - lo);
+    *le = (size_t)(e - lo);
+}
+}  // namespace
+
+extern "C" {
+
+int lbfgs_hip_abi_version(void) { return LBFGS_HIP_ABI_VERSION; }
+int lbfgs_hip_device_count(int* count) { *count = 0; return LBFGS_HIP_OK; }
+int lbfgs_hip_rccl_unique_id(void*) { return fail(nullptr, LBFGS_HIP_ERR_COMM, "mock: no RCCL"); }
+
+int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int, uint64_t n, const lbfgs_hip_shard* shard, const lbfgs_hip_comm* comm,
+                         void*) {
+    auto* c = new lbfgs_hip_ctx();
+    if (shard) c->shard = *shard;
+    else c->shard = {0, 1, n, 0, n};
+    int kind = comm ? comm->kind : LBFGS_HIP_COMM_NONE;
+    if (kind == LBFGS_HIP_COMM_RCCL) { delete c; return fail(nullptr, LBFGS_HIP_ERR_COMM, "mock: no RCCL"); }
+    if (c->shard.world > 1 && kind != LBFGS_HIP_COMM_CALLBACK) { delete c; return fail(nullptr, LBFGS_HIP_ERR_ARG, "world > 1 needs a communicator"); }
+    if (kind == LBFGS_HIP_COMM_CALLBACK) { c->comm_kind = kind; c->cb = comm->callback; c->cb_user = comm->callback_user; }
+    *out = c;
+    return LBFGS_HIP_OK;
+}
+void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* c) { delete c; }
+const char* lbfgs_hip_last_error(const lbfgs_hip_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+int lbfgs_hip_sync(lbfgs_hip_ctx*) { return LBFGS_HIP_OK; }
+void* lbfgs_hip_stream(lbfgs_hip_ctx*) { return nullptr; }
+int lbfgs_hip_get_shard(const lbfgs_hip_ctx* c, lbfgs_hip_shard* out) { *out = c->shard; return LBFGS_HIP_OK; }
+int lbfgs_hip_set_grid(lbfgs_hip_ctx*, int) { return LBFGS_HIP_OK; }
+
+int lbfgs_hip_vec_alloc(lbfgs_hip_ctx* c, lbfgs_hip_vec** out) {
+    *out = new lbfgs_hip_vec{c, new std::vector<double>(nl(c) ? nl(c) : 1, 0.0)};
+    return LBFGS_HIP_OK;
+}
+void lbfgs_hip_vec_free(lbfgs_hip_vec* v) { if (v) { delete v->p; delete v; } }
+int lbfgs_hip_vec_upload(lbfgs_hip_vec* v, const double* h, uint64_t n) {
+    if (n != v->ctx->shard.n_local) return fail(v->ctx, LBFGS_HIP_ERR_ARG, "size mismatch");
+    memcpy(v->p->data(), h, n * sizeof(double));
+    return LBFGS_HIP_OK;
+}
+int lbfgs_hip_vec_download(const lbfgs_hip_vec* v, double* h, uint64_t n) {
+    if (n != v->ctx->shard.n_local) return fail(v->ctx, LBFGS_HIP_ERR_ARG, "size mismatch");
+    memcpy(h, v->p->data(), n * sizeof(double));
+    return LBFGS_HIP_OK;
+}
+int lbfgs_hip_vec_fill(lbfgs_hip_vec* v, double c) { for (auto& e : *v->p) e = c; return LBFGS_HIP_OK; }
+void* lbfgs_hip_vec_ptr(lbfgs_hip_vec* v) { return v->p->data(); }
+int lbfgs_hip_vec_swap(lbfgs_hip_vec* a, lbfgs_hip_vec* b) { std::swap(a->p, b->p); return LBFGS_HIP_OK; }
+
+int lbfgs_hip_scalars_read(lbfgs_hip_ctx* c, int f, int n, double* h) {
+    if (!slot_ok(f, n)) return LBFGS_HIP_ERR_ARG;
+    memcpy(h, c->board + f, n * sizeof(double));
+    return LBFGS_HIP_OK;
+}
+int lbfgs_hip_scalars_write(lbfgs_hip_ctx* c, int f, int n, const double* h) {
+    if (!slot_ok(f, n)) return LBFGS_HIP_ERR_ARG;
+    memcpy(c->board + f, h, n * sizeof(double));
+    return LBFGS_HIP_OK;
+}
+void* lbfgs_hip_scalars_ptr(lbfgs_hip_ctx* c) { return c->board; }
+int lbfgs_hip_scalars_allreduce(lbfgs_hip_ctx* c, int f, int n) {
+    if (!slot_ok(f, n)) return LBFGS_HIP_ERR_ARG;
+    return allreduce(c, c->board + f, n);
+}
+
+int lbfgs_hip_vecadd(lbfgs_hip_vec* y, const lbfgs_hip_vec* x, double c) { oracle_vecadd(y->p->data(), x->p->data(), c, nl(y->ctx)); return 0; }
+int lbfgs_hip_vecadd_dev(lbfgs_hip_vec* y, const lbfgs_hip_vec* x, int s) { return lbfgs_hip_vecadd(y, x, y->ctx->board[s]); }
+int lbfgs_hip_vecdot(const lbfgs_hip_vec* x, const lbfgs_hip_vec* y, int s) { return gdot(x->ctx, x->p->data(), y->p->data(), x->ctx->board + s); }
+int lbfgs_hip_vecscale(lbfgs_hip_vec* y, double c) { oracle_vecscale(y->p->data(), c, nl(y->ctx)); return 0; }
+int lbfgs_hip_veccpy(lbfgs_hip_vec* y, const lbfgs_hip_vec* x) { oracle_veccpy(y->p->data(), x->p->data(), nl(y->ctx)); return 0; }
+int lbfgs_hip_vecncpy(lbfgs_hip_vec* y, const lbfgs_hip_vec* x) { oracle_vecncpy(y->p->data(), x->p->data(), nl(y->ctx)); return 0; }
+int lbfgs_hip_vecdiff(lbfgs_hip_vec* z, const lbfgs_hip_vec* x, const lbfgs_hip_vec* y) { oracle_vecdiff(z->p->data(), x->p->data(), y->p->data(), nl(z->ctx)); return 0; }
+int lbfgs_hip_vec2norm_sq(const lbfgs_hip_vec* x, int s) { return gdot(x->ctx, x->p->data(), x->p->data(), x->ctx->board + s); }
+
+int lbfgs_hip_line_step(lbfgs_hip_vec* x, const lbfgs_hip_vec* xp, const lbfgs_hip_vec* d, double step,
+                        const lbfgs_hip_vec* wp, uint64_t start, uint64_t end) {
+    lbfgs_hip_ctx* c = x->ctx;
+    oracle_veccpy(x->p->data(), xp->p->data(), nl(c));
+    oracle_vecadd(x->p->data(), d->p->data(), step, nl(c));
+    if (wp) {
+        size_t ls, le;
+        local_range(c, start, end, &ls, &le);
+        oracle_project(x->p->data(), wp->p->data(), ls, le, 0);
+    }
+    return LBFGS_HIP_OK;
+}
+int lbfgs_hip_norms_sq(const lbfgs_hip_vec* x, const lbfgs_hip_vec* g, int s) {
+    lbfgs_hip_ctx* c = x->ctx;
+    c->board[s] = oracle_vecdot(x->p->data(), x->p->data(), nl(c));
+    c->board[s + 1] = oracle_vecdot(g->p->data(), g->p->data(), nl(c));
+    return allreduce(c, c->board + s, 2);
+}
+
+int lbfgs_hip_history_create(lbfgs_hip_ctx* c, int m, lbfgs_hip_history** out) {
+    auto* h = new lbfgs_hip_history{c, m, {}, {}, std::vector<double>(m, 0.0), std::vector<double>(m, 0.0)};
+    for (int i = 0; i < m; ++i) {
+        lbfgs_hip_vec *s, *y;
+        lbfgs_hip_vec_alloc(c, &s);
+        lbfgs_hip_vec_alloc(c, &y);
+        h->s.push_back(s);
+        h->y.push_back(y);
+    }
+    *out = h;
+    return LBFGS_HIP_OK;
+}
+void lbfgs_hip_history_destroy(lbfgs_hip_history* h) {
+    if (!h) return;
+    for (auto* v : h->s) lbfgs_hip_vec_free(v);
+    for (auto* v : h->y) lbfgs_hip_vec_free(v);
+    delete h;
+}
+lbfgs_hip_vec* lbfgs_hip_history_s(lbfgs_hip_history* h, int i) { return (i >= 0 && i < h->m) ? h->s[i] : nullptr; }
+lbfgs_hip_vec* lbfgs_hip_history_y(lbfgs_hip_history* h, int i) { return (i >= 0 && i < h->m) ? h->y[i] : nullptr; }
+int lbfgs_hip_history_scalars_read(lbfgs_hip_history* h, double* ys, double* alpha) {
+    if (ys) memcpy(ys, h->ys.data(), h->m * sizeof(double));
+    if (alpha) memcpy(alpha, h->alpha.data(), h->m * sizeof(double));
+    return LBFGS_HIP_OK;
+}
+int lbfgs_hip_history_scalars_write(lbfgs_hip_history* h, const double* ys, const double* alpha) {
+    if (ys) memcpy(h->ys.data(), ys, h->m * sizeof(double));
+    if (alpha) memcpy(h->alpha.data(), alpha, h->m * sizeof(double));
+    return LBFGS_HIP_OK;
+}
+
+int lbfgs_hip_history_update(lbfgs_hip_history* h, int slot, const lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
+                             const lbfgs_hip_vec* g, const lbfgs_hip_vec* gp, double step, int damping, int o) {
+    lbfgs_hip_ctx* c = h->ctx;
+    const size_t n = nl(c);
+    double* s = h->s[slot]->p->data();
+    double* y = h->y[slot]->p->data();
+    oracle_vecdiff(s, x->p->data(), xp->p->data(), n);
+    oracle_vecdiff(y, g->p->data(), gp->p->data(), n);
+    double* b = c->board + o;
+    b[0] = oracle_vecdot(s, s, n);
+    b[1] = oracle_vecdot(y, s, n);
+    b[2] = oracle_vecdot(y, y, n);
+    b[3] = oracle_vecdot(x->p->data(), x->p->data(), n);
+    b[4] = oracle_vecdot(g->p->data(), g->p->data(), n);
+    int cnt = 5;
+    if (damping) {
+        std::vector<double> bs(gp->p->begin(), gp->p->begin() + n);
+        oracle_vecscale(bs.data(), -step, n);
+        b[5] = oracle_vecdot(s, bs.data(), n);
+        cnt = 6;
+    }
+    int rc = allreduce(c, b, cnt);
+    h->ys[slot] = b[1];
+    return rc;
+}
+int lbfgs_hip_history_damp(lbfgs_hip_history* h, int slot, const lbfgs_hip_vec* gp, double step, double theta) {
+    const size_t n = nl(h->ctx);
+    std::vector<double> bs(gp->p->begin(), gp->p->begin() + n);
+    oracle_vecscale(bs.data(), -step, n);
+    oracle_vecscale(bs.data(), 1.0 - theta, n);
+    oracle_vecadd(bs.data(), h->y[slot]->p->data(), theta, n);
+    oracle_veccpy(h->y[slot]->p->data(), bs.data(), n);
+    return LBFGS_HIP_OK;
+}
+
+int lbfgs_hip_two_loop_unfused(lbfgs_hip_history* h, lbfgs_hip_vec* d, uint64_t k, int end, int gn, int gd,
+                               int* new_end) {
+    lbfgs_hip_ctx* c = h->ctx;
+    const size_t n = nl(c);
+    const int m = h->m;
+    const int e1 = (end + 1) % m;
+    const int bound = (int)((uint64_t)m < k ? (uint64_t)m : k);
+    double* dd = d->p->data();
+    int j = e1, rc;
+    for (int it = 0; it < bound; ++it) {
+        j = (j + m - 1) % m;
+        double dot;
+        if ((rc = gdot(c, h->s[j]->p->data(), dd, &dot)) != 0) return rc;
+        h->alpha[j] = dot / h->ys[j];
+        oracle_vecadd(dd, h->y[j]->p->data(), -h->alpha[j], n);
+    }
+    oracle_vecscale(dd, c->board[gn] / c->board[gd], n);
+    for (int it = 0; it < bound; ++it) {
+        double dot;
+        if ((rc = gdot(c, h->y[j]->p->data(), dd, &dot)) != 0) return rc;
+        const double beta = dot / h->ys[j];
+        oracle_vecadd(dd, h->s[j]->p->data(), h->alpha[j] - beta, n);
+        j = (j + 1) % m;
+    }
+    *new_end = e1;
+    return LBFGS_HIP_OK;
+}
+int lbfgs_hip_two_loop(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end, int gn,
+                       int gd, int dn, int* new_end) {
+    oracle_vecncpy(d->p->data(), g->p->data(), nl(h->ctx));
+    int rc = lbfgs_hip_two_loop_unfused(h, d, k, end, gn, gd, new_end);
+    if (rc != 0) return rc;
+    return gdot(h->ctx, d->p->data(), d->p->data(), h->ctx->board + dn);
+}
+
+int lbfgs_hip_owlqn_post_eval(const lbfgs_hip_vec* x, const lbfgs_hip_vec* g, lbfgs_hip_vec* pg, double cc,
+                              uint64_t start, uint64_t end, int o) {
+    lbfgs_hip_ctx* c = x->ctx;
+    size_t ls, le;
+    local_range(c, start, end, &ls, &le);
+    double* b = c->board + o;
+    b[0] = oracle_x1norm(cc, ls, le, x->p->data());
+    oracle_pseudo_gradient(cc, ls, le, pg->p->data(), x->p->data(), g->p->data(), nl(c));
+    b[1] = oracle_vecdot(pg->p->data(), pg->p->data(), nl(c));
+    b[2] = oracle_vecdot(x->p->data(), x->p->data(), nl(c));
+    return allreduce(c, b, 3);
+}
+int lbfgs_hip_orthant_select(lbfgs_hip_vec* wp, const lbfgs_hip_vec* xp, const lbfgs_hip_vec* pg) {
+    oracle_orthant_select(wp->p->data(), xp->p->data(), pg->p->data(), nl(wp->ctx));
+    return LBFGS_HIP_OK;
+}
+int lbfgs_hip_constrain_direction(lbfgs_hip_vec* d, const lbfgs_hip_vec* pg, uint64_t start, uint64_t end, int o) {
+    size_t ls, le;
+    local_range(d->ctx, start, end, &ls, &le);
+    oracle_project(d->p->data(), pg->p->data(), ls, le, 1);
+    return gdot(d->ctx, d->p->data(), d->p->data(), d->ctx->board + o);
+}
+
+static int eval_obj(const lbfgs_hip_objective* obj, lbfgs_hip_ctx* c, const double* x, double* g, double* f) {
+    oracle_hashed_obj u{c->shard.offset, obj->seed_a, obj->seed_b};
+    int failed = 0;
+    switch (obj->kind) {
+        case LBFGS_HIP_OBJ_QUADRATIC: *f = oracle_obj_quadratic(&u, x, g, nl(c), &failed); break;
+        case LBFGS_HIP_OBJ_LOGISTIC: *f = oracle_obj_logistic(&u, x, g, nl(c), &failed); break;
+        case LBFGS_HIP_OBJ_ROSENBROCK:
+            if ((c->shard.n_local & 1) || (c->shard.offset & 1)) return fail(c, LBFGS_HIP_ERR_ARG, "Rosenbrock needs even shards");
+            *f = oracle_obj_rosenbrock(nullptr, x, g, nl(c), &failed);
+            break;
+        default: return fail(c, LBFGS_HIP_ERR_ARG, "unknown objective");
+    }
+    return LBFGS_HIP_OK;
+}
+int lbfgs_hip_objective_eval(const lbfgs_hip_objective* obj, const lbfgs_hip_vec* x, lbfgs_hip_vec* g, int o) {
+    lbfgs_hip_ctx* c = x->ctx;
+    int rc = eval_obj(obj, c, x->p->data(), g->p->data(), c->board + o);
+    return rc ? rc : allreduce(c, c->board + o, 1);
+}
+int lbfgs_hip_objective_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
+                                  const lbfgs_hip_vec* d, double step, lbfgs_hip_vec* g, int o) {
+    lbfgs_hip_ctx* c = x->ctx;
+    lbfgs_hip_line_step(x, xp, d, step, nullptr, 0, 0);
+    int rc = eval_obj(obj, c, x->p->data(), g->p->data(), c->board + o);
+    if (rc) return rc;
+    c->board[o + 1] = oracle_vecdot(g->p->data(), d->p->data(), nl(c));
+    return allreduce(c, c->board + o, 2);
+}
+
+int lbfgs_hip_prof_enable(lbfgs_hip_ctx*, int) { return LBFGS_HIP_OK; }
+int lbfgs_hip_prof_reset(lbfgs_hip_ctx*) { return LBFGS_HIP_OK; }
+int lbfgs_hip_prof_read(lbfgs_hip_ctx* c, int k, uint64_t* launches, double* ms) {
+    // the mock reports its all-reduce count through the COMM class (used by the sharding tests)
+    if (launches) *launches = (k == LBFGS_HIP_K_COMM) ? c->n_allreduce : 0;
+    if (ms) *ms = 0.0;
+    return LBFGS_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,397 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): element-wise results bit-exact (same roundings, no FMA);
+every reduction, per-iteration f, ||g|| and the search direction within RTOL = 1e-10 relative
+of the oracle -- the only difference is the summation ORDER (fixed tree vs the reference's
+sequential sum, src/math.rs:41).
+
+Dry-run of the test logic without a GPU: LBFGS_TEST_BACKEND=mock pytest -m gpu ... (the CPU
+test double; proves nothing about the kernels).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import rust_lbfgs_amd as R
+from oracle import oracle as O
+from rust_lbfgs_amd import _ffi, hotpath as H, objectives
+from rust_lbfgs_amd.math import DeviceVec
+from tests import problems as P
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+KA = json.load(open(os.path.join(P.GOLDEN, "reference_known_answers.json")))
+TRACES = json.load(open(os.path.join(P.GOLDEN, "oracle_traces.json")))
+
+SIZES = [1, 2, 3, 64, 255, 256, 257, 511, 512, 513, 1000, 4097, 65536 + 1, 262144 * 3 + 5]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def product_library():
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        from tests.support import mock
+
+        prev = _ffi.use_library_for_tests(mock.load())
+        yield
+        _ffi.use_library_for_tests(prev)
+    else:
+        _ffi.use_library_for_tests(None)
+        _ffi.load()  # raises if the HIP extension is not built
+        yield
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    den = np.max(np.abs(b)) if b.size else 0.0
+    if den == 0.0:
+        return float(np.max(np.abs(a - b))) if a.size else 0.0
+    return float(np.max(np.abs(a - b)) / den)
+
+
+def rnd(n, seed):
+    r = np.random.default_rng(seed)
+    return r.standard_normal(n) * np.exp(r.uniform(-3, 3, n))
+
+
+# ---------------------------------------------------------------------------------------------
+# src/math.rs:84-122: the reference's own primitive test, on the device
+# ---------------------------------------------------------------------------------------------
+def test_lbfgs_math_reference_unit_test():
+    ka = KA["math_rs_84_122"]
+    with R.Context(3) as ctx:
+        x = DeviceVec(ctx, ka["vecadd"]["x"])
+        y = DeviceVec(ctx, ka["vecadd"]["y"])
+        y.vecadd(x, ka["vecadd"]["c"])
+        assert y.to_numpy().tolist() == ka["vecadd"]["expect"]
+        assert y.vecdot(x) == ka["vecdot"]["expect"]
+        y.vecscale(ka["vecscale"]["c"])
+        assert y.to_numpy().tolist() == ka["vecscale"]["expect"]
+        z = DeviceVec(ctx)
+        z.vecdiff(x, y)
+        assert z.to_numpy().tolist() == ka["vecdiff_x_minus_y"]["expect"]
+        y.veccpy(x)
+        assert y.to_numpy().tolist() == x.to_numpy().tolist()
+        y.vecncpy(x)
+        assert y.to_numpy().tolist() == ka["vecncpy"]["expect"]
+        for v in (x, y, z):
+            v.free()
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_primitives_vs_oracle(n):
+    a, b = rnd(n, 1), rnd(n, 2)
+    with R.Context(n) as ctx:
+        x, y, z = DeviceVec(ctx, a), DeviceVec(ctx, b), DeviceVec(ctx)
+        # element-wise: bit-exact
+        ya = b.copy(); O.vecadd(ya, a, -0.37); y.vecadd(x, -0.37)
+        assert np.array_equal(y.to_numpy(), ya)
+        O.vecscale(ya, 1.7); y.vecscale(1.7)
+        assert np.array_equal(y.to_numpy(), ya)
+        za = np.zeros(n); O.vecdiff(za, a, ya); z.vecdiff(x, y)
+        assert np.array_equal(z.to_numpy(), za)
+        z.vecncpy(x)
+        assert np.array_equal(z.to_numpy(), -a)
+        z.veccpy(y)
+        assert np.array_equal(z.to_numpy(), ya)
+        z.fill(2.5)
+        assert np.all(z.to_numpy() == 2.5)
+        # reductions: 1e-10 relative to the sequential oracle (scale: sum |x_i y_i|)
+        scale = float(np.sum(np.abs(a * ya)))
+        assert abs(x.vecdot(y) - O.vecdot(a, ya)) <= RTOL * scale
+        assert abs(x.vec2norm() - O.vec2norm(a)) <= RTOL * O.vec2norm(a)
+        assert abs(x.vec2norminv() - O.vec2norminv(a)) <= RTOL * O.vec2norminv(a)
+        # device-side coefficient
+        ctx.set_scalars(40, [0.125])
+        yb = ya.copy(); O.vecadd(yb, a, 0.125); y.vecadd_slot(x, 40)
+        assert np.array_equal(y.to_numpy(), yb)
+        # exact integer-valued sum: every order gives the same result
+        x.fill(1.0); y.fill(3.0)
+        assert x.vecdot(y) == 3.0 * n
+        H.norms_sq(x, y, 14)
+        assert ctx.scalars(14, 2).tolist() == [float(n), 9.0 * n]
+        for v in (x, y, z):
+            v.free()
+
+
+def test_reductions_are_deterministic():
+    n = 1_000_003
+    a, b = rnd(n, 3), rnd(n, 4)
+    with R.Context(n) as ctx:
+        x, y = DeviceVec(ctx, a), DeviceVec(ctx, b)
+        vals = {x.vecdot(y) for _ in range(5)}
+        assert len(vals) == 1
+        x.free(); y.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# fused operators vs the oracle's unfused sequence
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 7, 256, 1001, 70001])
+def test_line_step_and_owlqn_ops(n):
+    xp_h, d_h = rnd(n, 5), rnd(n, 6)
+    r = np.random.default_rng(9)
+    xp_h[r.random(n) < 0.3] = 0.0  # exact zeros exercise signum(0) / the x == 0 pseudo-gradient branch
+    g_h = rnd(n, 7)
+    start, end = (n // 5, n - n // 7) if n > 10 else (0, n)
+    with R.Context(n) as ctx:
+        x, xp, d, g, pg, wp = (DeviceVec(ctx) for _ in range(6))
+        xp.upload(xp_h); d.upload(d_h); g.upload(g_h)
+        # take_line_step without projection: x = xp ; x += t*d  (bit-exact)
+        H.line_step(x, xp, d, 0.3)
+        xo = xp_h.copy(); O.vecadd(xo, d_h, 0.3)
+        assert np.array_equal(x.to_numpy(), xo)
+        # evaluate tail: l1, pseudo-gradient, norms
+        c = 0.75
+        H.owlqn_post_eval(xp, g, pg, c, start, end, 2)
+        pgo = np.zeros(n)
+        O.lib().oracle_pseudo_gradient(c, start, end, O._dp(pgo), O._dp(xp_h), O._dp(g_h), n)
+        assert np.array_equal(pg.to_numpy(), pgo)
+        l1, pgn2, xn2 = ctx.scalars(2, 3)
+        l1o = O.lib().oracle_x1norm(c, start, end, O._dp(xp_h))
+        assert abs(l1 - l1o) <= RTOL * max(l1o, 1e-300)
+        assert abs(pgn2 - O.vecdot(pgo, pgo)) <= RTOL * O.vecdot(pgo, pgo)
+        assert abs(xn2 - O.vecdot(xp_h, xp_h)) <= RTOL * max(O.vecdot(xp_h, xp_h), 1e-300)
+        # orthant choice over ALL i, then the projected line step on [start, end)
+        H.orthant_select(wp, xp, pg)
+        wpo = np.zeros(n)
+        O.lib().oracle_orthant_select(O._dp(wpo), O._dp(xp_h), O._dp(pgo), n)
+        assert np.array_equal(wp.to_numpy(), wpo)
+        H.line_step(x, xp, d, 0.3, wp, start, end)
+        O.lib().oracle_project(O._dp(xo), O._dp(wpo), start, end, 0)
+        assert np.array_equal(x.to_numpy(), xo)
+        # constrain_search_direction
+        H.constrain_direction(d, pg, start, end, 13)
+        do = d_h.copy()
+        O.lib().oracle_project(O._dp(do), O._dp(pgo), start, end, 1)
+        assert np.array_equal(d.to_numpy(), do)
+        assert abs(ctx.scalars(13)[0] - O.vecdot(do, do)) <= RTOL * max(O.vecdot(do, do), 1e-300)
+        for v in (x, xp, d, g, pg, wp):
+            v.free()
+
+
+@pytest.mark.parametrize("n", [2, 513, 40001])
+@pytest.mark.parametrize("damping", [False, True])
+def test_history_update(n, damping):
+    xh, xph, gh, gph = rnd(n, 11), rnd(n, 12), rnd(n, 13), rnd(n, 14)
+    step = 0.61
+    with R.Context(n) as ctx:
+        x, xp, g, gp = (DeviceVec(ctx, a) for a in (xh, xph, gh, gph))
+        hist = H.History(ctx, 3)
+        hist.update(1, x, xp, g, gp, step, damping, 6)
+        so, yo = np.zeros(n), np.zeros(n)
+        rc, ys_o, gamma_o, aux = O.history_update(so, yo, xh, xph, gh, gph, step, False)  # undamped s, y
+        assert rc == 0
+        assert np.array_equal(hist.s(1).to_numpy(), so)
+        assert np.array_equal(hist.y(1).to_numpy(), yo)
+        b = ctx.scalars(6, 6)
+        assert abs(np.sqrt(b[0]) - aux[0]) <= RTOL * aux[0]
+        assert abs(b[1] - aux[1]) <= RTOL * float(np.sum(np.abs(so * yo)))
+        assert abs(b[2] - aux[2]) <= RTOL * aux[2]
+        assert abs(b[3] - O.vecdot(xh, xh)) <= RTOL * O.vecdot(xh, xh)
+        assert abs(b[4] - O.vecdot(gh, gh)) <= RTOL * O.vecdot(gh, gh)
+        assert hist.scalars()[0][1] == b[1]  # ys stored in the slot (lbfgs.rs:656)
+        if damping:
+            bs = gph * (-step)
+            assert abs(b[5] - O.vecdot(so, bs)) <= RTOL * float(np.sum(np.abs(so * bs)))
+            theta = 0.3
+            hist.damp(1, gp, step, theta)
+            yd = bs.copy(); O.vecscale(yd, 1.0 - theta); O.vecadd(yd, yo, theta)
+            assert np.array_equal(hist.y(1).to_numpy(), yd)
+        hist.free()
+        for v in (x, xp, g, gp):
+            v.free()
+
+
+def _random_history(n, m, seed):
+    r = np.random.default_rng(seed)
+    S = [r.standard_normal(n) for _ in range(m)]
+    # y = B s with a positive diagonal B keeps ys > 0 like a real run
+    B = np.exp(r.uniform(-1.5, 1.5, n))
+    Y = [B * s + 0.01 * r.standard_normal(n) for s in S]
+    ys = np.array([O.vecdot(Y[j], S[j]) for j in range(m)])
+    return S, Y, ys
+
+
+@pytest.mark.parametrize("n,m,k,end", [(1, 1, 1, 0), (100, 6, 1, 0), (100, 6, 3, 2), (100, 6, 6, 5), (100, 6, 40, 3),
+                                       (4097, 7, 7, 6), (4097, 7, 100, 2), (70001, 10, 10, 9), (70001, 10, 23, 4),
+                                       (70001, 3, 2, 1), (513, 1, 5, 0), (262145, 10, 11, 0)])
+def test_two_loop_fused_vs_oracle(n, m, k, end):
+    """lbfgs.rs:569-604 on identical inputs: direction within 1e-10 relative, alpha within 1e-10."""
+    S, Y, ys = _random_history(n, m, 100 + n + m)
+    g = rnd(n, 21)
+    gamma_num, gamma_den = ys[end], O.vecdot(Y[end], Y[end])
+    # oracle
+    d_o = -g
+    alpha_o = np.zeros(m)
+    end_o = O.two_loop(S, Y, ys, alpha_o, d_o, gamma_num / gamma_den, m, k, end)
+    with R.Context(n) as ctx:
+        hist = H.History(ctx, m)
+        for j in range(m):
+            hist.s(j).upload(S[j]); hist.y(j).upload(Y[j])
+        hist.set_scalars(ys=ys, alpha=np.zeros(m))
+        ctx.set_scalars(7, [gamma_num, gamma_den])
+        gv, d = DeviceVec(ctx, g), DeviceVec(ctx)
+        new_end = hist.two_loop(d, gv, k, end, 7, 8, 12)
+        assert new_end == end_o
+        d_f = d.to_numpy()
+        assert rel(d_f, d_o) <= RTOL
+        _, alpha_f = hist.scalars()
+        assert rel(alpha_f, alpha_o) <= RTOL
+        dn2 = ctx.scalars(12)[0]
+        assert abs(dn2 - O.vecdot(d_o, d_o)) <= RTOL * O.vecdot(d_o, d_o)
+        # on-device cross-check: the reference's unfused sequence of primitives
+        hist.set_scalars(alpha=np.zeros(m))
+        d.vecncpy(gv)
+        assert hist.two_loop_unfused(d, k, end, 7, 8) == end_o
+        assert rel(d.to_numpy(), d_o) <= RTOL
+        assert rel(d.to_numpy(), d_f) <= 1e-12
+        hist.free(); gv.free(); d.free()
+
+
+def test_two_loop_linearity_and_determinism():
+    """H is linear: two_loop(4*g) == 4*two_loop(g) bit for bit (power-of-two scaling commutes with rounding)."""
+    n, m = 300_001, 10
+    S, Y, ys = _random_history(n, m, 5)
+    g = rnd(n, 22)
+    with R.Context(n) as ctx:
+        hist = H.History(ctx, m)
+        for j in range(m):
+            hist.s(j).upload(S[j]); hist.y(j).upload(Y[j])
+        hist.set_scalars(ys=ys)
+        ctx.set_scalars(7, [ys[3], O.vecdot(Y[3], Y[3])])
+        gv, d = DeviceVec(ctx, g), DeviceVec(ctx)
+        hist.two_loop(d, gv, 50, 3)
+        d1 = d.to_numpy()
+        hist.two_loop(d, gv, 50, 3)
+        assert np.array_equal(d.to_numpy(), d1)
+        gv.upload(4.0 * g)
+        hist.two_loop(d, gv, 50, 3)
+        assert np.array_equal(d.to_numpy(), 4.0 * d1)
+        hist.free(); gv.free(); d.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# device-resident objectives
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [2, 1000, 50001 * 2])
+def test_builtin_objectives(n):
+    xh, dh = 0.3 * rnd(n, 31), rnd(n, 32)
+    with R.Context(n) as ctx:
+        x, xp, d, g = DeviceVec(ctx), DeviceVec(ctx, xh), DeviceVec(ctx, dh), DeviceVec(ctx)
+        for dev, orc, exact_g in ((objectives.Quadratic(), O.quadratic(), True), (objectives.Logistic(), O.logistic(), False),
+                                  (objectives.Rosenbrock(), O.rosenbrock(), True)):
+            fo, go = O.eval_builtin(orc, xh)
+            H.objective_eval(dev, xp, g, 0)
+            f = ctx.scalars(0)[0]
+            gd = g.to_numpy()
+            if exact_g:
+                assert np.array_equal(gd, go)  # same hashed data, same roundings
+            else:
+                assert rel(gd, go) <= 1e-14  # libm (glibc vs ocml) exp/log1p differ by an ulp
+            assert abs(f - fo) <= RTOL * float(np.sum(np.abs(O.eval_builtin(orc, xh)[0]))) + RTOL * abs(fo)
+            # fused line step + evaluate + g.d
+            t = 0.01
+            xt = xh.copy(); O.vecadd(xt, dh, t)
+            fo, go = O.eval_builtin(orc, xt)
+            H.objective_line_eval(dev, x, xp, d, t, g, 0)
+            assert np.array_equal(x.to_numpy(), xt)
+            f, dg = ctx.scalars(0, 2)
+            assert abs(f - fo) <= RTOL * max(abs(fo), 1.0)
+            assert abs(dg - O.vecdot(go, dh)) <= RTOL * float(np.sum(np.abs(go * dh)))
+        for v in (x, xp, d, g):
+            v.free()
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's integration tests, through the drop-in closure API (tests/simple.rs, tests/owlqn.rs)
+# ---------------------------------------------------------------------------------------------
+def test_lbfgs_rosenbrock():
+    """tests/simple.rs:17-55 as written (defaults; OWL-QN continued from the converged x)."""
+    x = P.rosenbrock_x0()
+    prb = R.lbfgs().minimize(x, R.default_evaluate(), R.default_progress())
+    ka = KA["simple_rs_rosenbrock"]["assert_37_40"]
+    assert abs(prb.fx - ka["fx"]) <= ka["abs_tol"]
+    assert np.all(np.abs(x - 1.0) <= ka["abs_tol"])
+    prb = R.lbfgs().with_orthantwise(1.0, 0, 99).minimize(x, R.default_evaluate(), R.default_progress())
+    kb = KA["simple_rs_owlqn"]["assert_52_54"]
+    assert abs(prb.fx - kb["fx"]) <= kb["abs_tol"]
+    assert abs(x[0] - kb["x0"]) <= kb["abs_tol"] and abs(x[1] - kb["x1"]) <= kb["abs_tol"]
+
+
+def test_lbfgs_booth():
+    """tests/simple.rs:58-83"""
+    x = np.array([-1.2, 1.0])
+    R.lbfgs().minimize(x, P.booth, R.default_progress())
+    assert abs(x[0] - 1.0) <= 1e-6 and abs(x[1] - 3.0) <= 1e-6
+
+
+def test_owlqn_poisson():
+    """tests/owlqn.rs:6-63"""
+    ev, n = P.poisson_problem()
+    x = np.zeros(n)
+    prb = R.lbfgs().with_orthantwise(1.0, 1, 21).with_epsilon(1e-4).minimize(x, ev)
+    assert abs(prb.fx - KA["owlqn_rs_60"]["fx"]) <= KA["owlqn_rs_60"]["abs_tol"]
+
+
+def test_17_digit_vectors_within_tolerance():
+    """tests/simple.rs:33-35: the GPU run (tree sums) lands on the reference's digits to ~1e-8 relative in x."""
+    ka = KA["simple_rs_rosenbrock"]["comment_33_35"]
+    x = P.rosenbrock_x0()
+    rep = R.lbfgs().with_max_step_size(1e20).minimize(x, R.default_evaluate())
+    assert abs(x[0] - ka["x0"]) <= 1e-8 and abs(x[1] - ka["x1"]) <= 1e-8
+    assert abs(rep.xnorm - ka["xnorm"]) <= 1e-8
+    assert rep.fx <= 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# per-iteration parity of whole runs against the committed oracle traces
+# ---------------------------------------------------------------------------------------------
+def _configure(b, spec):
+    for name, args in spec:
+        b = getattr(b, name)(*args)
+    return b
+
+
+def _evaluator(kind):
+    return {
+        "rosenbrock_closure": lambda: R.default_evaluate(),
+        "rosenbrock": lambda: objectives.Rosenbrock(),
+        "quadratic": lambda: objectives.Quadratic(),
+        "quadratic_unfused": lambda: objectives.Quadratic(fuse_line_eval=False),
+        "logistic": lambda: objectives.Logistic(),
+        "booth": lambda: P.booth,
+        "poisson": lambda: P.poisson_problem()[0],
+    }[kind]()
+
+
+@pytest.mark.parametrize("case", sorted(TRACES["cases"].keys()))
+def test_trajectory_matches_oracle_trace(case):
+    """Free-running trajectories: every iteration's f, ||x||, ||g||, step, ncall, neval and the head/tail
+    of d against tests/golden/oracle_traces.json.  Tolerances are per case (stored with the trace):
+    1e-10 relative while the run is well conditioned; a looser bound only where the trace says the
+    problem amplifies the summation-order noise (near-converged Rosenbrock: f -> 1e-15)."""
+    tr = TRACES["cases"][case]
+    n = tr["n"]
+    x = np.array(tr["x0"]) if "x0" in tr else (P.rosenbrock_x0(n) if tr["x0_kind"] == "rosenbrock" else np.zeros(n))
+    b = _configure(R.lbfgs(), tr["builder"])
+    rows = tr["rows"]
+    rt = tr["rtol"]
+    with b.build(x, _evaluator(tr["evaluate"])) as st:
+        for row in rows:
+            assert not st.is_converged()
+            p = st.propagate()
+            assert p.niter == row["niter"]
+            assert p.ncall == row["ncall"] and p.neval == row["neval"], (case, row["niter"])
+            fscale = max(abs(row["fx"]), tr["f_floor"])
+            assert abs(p.fx - row["fx"]) <= rt * fscale, (case, row["niter"], p.fx, row["fx"])
+            assert abs(p.xnorm - row["xnorm"]) <= rt * max(row["xnorm"], 1e-300)
+            assert abs(p.gnorm - row["gnorm"]) <= rt * max(row["gnorm"], tr["g_floor"]), (case, row["niter"])
+            assert abs(p.step - row["step"]) <= rt * abs(row["step"])
+            d = st.download("d")
+            dref = np.array(row["d_head"] + row["d_tail"])
+            dgot = np.concatenate([d[: len(row["d_head"])], d[len(d) - len(row["d_tail"]):]])
+            assert np.max(np.abs(dgot - dref)) <= rt * max(row["dnorm_inf"], tr["g_floor"]), (case, row["niter"])
+        if tr["converged_after"] is not None:
+            assert st.is_converged() == tr["converged_after"]

@@ -1,0 +1,232 @@
+"""Host orchestration (rust-lbfgs_amd/csrc/host/solver.cpp) on the CPU test double of the C-ABI.
+
+The mock backend computes every vector op with the oracle's primitives (sequential sums),
+so the product's host logic -- More-Thuente / backtracking state machines, step clamp, stop
+tests, damping decisions, OWL-QN sequencing, error paths -- must reproduce the oracle's
+trajectory BIT FOR BIT, and with it the reference's 17-digit known answers.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import rust_lbfgs_amd as R
+from oracle import oracle as O
+from rust_lbfgs_amd import _ffi, objectives
+from tests import problems as P
+from tests.support import mock
+
+KA = json.load(open(os.path.join(P.GOLDEN, "reference_known_answers.json")))
+
+
+@pytest.fixture(autouse=True)
+def on_mock():
+    prev = _ffi.use_library_for_tests(mock.load())
+    yield
+    _ffi.use_library_for_tests(prev)
+
+
+def run_pair(configure, x0, oracle_eval, product_eval, max_rows=10_000):
+    """Run oracle and product with the same settings; return both per-iteration traces."""
+    xo, xp = x0.copy(), x0.copy()
+    ro, rp = [], []
+    fields = ("niter", "neval", "ncall", "fx", "xnorm", "gnorm", "step")
+    rep_o = configure(O.lbfgs()).minimize(xo, oracle_eval, lambda p: ro.append(tuple(p[f] for f in fields)) and False)
+    rep_p = configure(R.lbfgs()).minimize(xp, product_eval,
+                                          lambda p: rp.append(tuple(getattr(p, f) for f in fields)) and False)
+    return (xo, ro, rep_o), (xp, rp, rep_p)
+
+
+def assert_identical(a, b):
+    (xo, ro, rep_o), (xp, rp, rep_p) = a, b
+    assert len(ro) == len(rp)
+    for u, v in zip(ro, rp):
+        assert u == v
+    assert np.array_equal(xo, xp)
+    assert (rep_o["fx"], rep_o["xnorm"], rep_o["gnorm"], rep_o["neval"]) == (rep_p.fx, rep_p.xnorm, rep_p.gnorm,
+                                                                           rep_p.neval)
+
+
+def test_rosenbrock_17_digits_through_product_host_logic():
+    """tests/simple.rs:33-35,48-50 reproduced by solver.cpp (not by the oracle's own loop)."""
+    ka = KA["simple_rs_rosenbrock"]["comment_33_35"]
+    x = P.rosenbrock_x0()
+    last = {}
+    rep = R.lbfgs().with_max_step_size(1e20).minimize(x, R.default_evaluate(),
+                                                      lambda p: last.update(n=p.niter, s=p.step) and False)
+    assert last["n"] == 38 and last["s"] == ka["step"]
+    assert rep.fx == ka["fx"] and x[0] == ka["x0"] and x[1] == ka["x1"]
+    assert rep.xnorm == ka["xnorm"] and rep.gnorm == ka["gnorm"]
+    kb = KA["simple_rs_owlqn"]["comment_48_50"]
+    rep = R.lbfgs().with_max_step_size(1e20).with_orthantwise(1.0, 0, 99).minimize(x, R.default_evaluate())
+    assert rep.fx == kb["fx"] and x[0] == kb["x0"] and x[1] == kb["x1"]
+    assert rep.xnorm == kb["xnorm"] and rep.gnorm == kb["gnorm"]
+
+
+@pytest.mark.parametrize("name,configure", [
+    ("defaults", lambda b: b),
+    ("m10", lambda b: b.with_m(10)),
+    ("m3_unclamped", lambda b: b.with_m(3).with_max_step_size(1e20)),
+    ("armijo", lambda b: b.with_linesearch_algorithm("BacktrackingArmijo")),
+    ("wolfe", lambda b: b.with_linesearch_algorithm("BacktrackingWolfe")),
+    ("strongwolfe", lambda b: b.with_linesearch_algorithm("BacktrackingStrongWolfe")),
+    ("damping", lambda b: b.with_damping(True)),
+    ("gtol01", lambda b: b.with_linesearch_gtol(0.1)),
+    ("owlqn", lambda b: b.with_orthantwise(1.0, 0, 99)),
+    ("owlqn_tail", lambda b: b.with_orthantwise(0.5, 10, None)),
+    ("max_eval", lambda b: b.with_max_evaluations(17)),
+    ("h0", lambda b: b.with_initial_step_size(0.3).with_max_step_size(2.5)),
+])
+def test_rosenbrock_trajectories_identical(name, configure):
+    a, b = run_pair(configure, P.rosenbrock_x0(), O.rosenbrock(), R.default_evaluate())
+    assert len(a[1]) > 3
+    assert_identical(a, b)
+
+
+def test_builtin_objectives_identical():
+    for obj_o, obj_p, cfg in [
+        (O.quadratic(), objectives.Quadratic(), lambda b: b.with_m(7).with_epsilon(1e-9).with_max_iterations(40)),
+        (O.quadratic(), objectives.Quadratic(fuse_line_eval=False), lambda b: b.with_max_iterations(25)),
+        (O.logistic(), objectives.Logistic(), lambda b: b.with_orthantwise(0.5, 0, None).with_max_iterations(40)),
+        (O.rosenbrock(), objectives.Rosenbrock(), lambda b: b),
+    ]:
+        a, b = run_pair(cfg, np.zeros(1000) if obj_o.name != "oracle_obj_rosenbrock" else P.rosenbrock_x0(), obj_o, obj_p)
+        assert len(a[1]) > 5
+        assert_identical(a, b)
+
+
+def test_booth_and_poisson():
+    a, b = run_pair(lambda b: b, np.array([-1.2, 1.0]), P.booth, P.booth)
+    assert_identical(a, b)
+    ev, n = P.poisson_problem()
+    ka = KA["owlqn_rs_60"]
+    a, b = run_pair(lambda b: b.with_orthantwise(1.0, 1, 21).with_epsilon(1e-4), np.zeros(n), ev, ev)
+    assert_identical(a, b)
+    assert abs(b[2].fx - ka["fx"]) <= ka["abs_tol"]
+
+
+def test_lj38_damped():
+    """examples/lj.rs objective with with_damping(true) (BASELINE config 5, parity-size case)."""
+    rng = np.random.default_rng(7)
+    x0 = (rng.random(38 * 3) * 3.2 + 48.4)
+    f = lambda x, g: (lambda fg: (g.__setitem__(slice(None), fg[1]), fg[0])[1])(O.eval_builtin(O.lj(), np.ascontiguousarray(x)))
+    cfg = lambda b: b.with_damping(True).with_max_iterations(60)
+    a, b = run_pair(cfg, x0, O.lj(), f)
+    assert len(a[1]) >= 5
+    assert_identical(a, b)
+
+
+def test_progress_cancel_and_lazy_vectors():
+    x = P.rosenbrock_x0()
+    seen = []
+
+    def prg(p):
+        seen.append(p.niter)
+        if p.niter == 3:
+            assert p.x.shape == (100,) and p.gx.shape == (100,)
+            return True
+        return False
+
+    R.lbfgs().minimize(x, R.default_evaluate(), prg)
+    assert seen == [1, 2, 3]
+
+
+def test_state_api_and_line_search_doctest():
+    """build/is_converged/propagate/report (lbfgs.rs:443-565) and LineSearch::find (line.rs:8-32)."""
+    x = P.rosenbrock_x0()
+    so = O.lbfgs().build(x.copy(), O.rosenbrock())
+    with R.lbfgs().build(x, R.default_evaluate()) as sp:
+        for _ in range(6):
+            assert so.is_converged() == sp.is_converged()
+            po, pp = so.propagate(), sp.propagate()
+            assert (po["fx"], po["gnorm"], po["step"], po["ncall"]) == (pp.fx, pp.gnorm, pp.step, pp.ncall)
+            info = sp.info()
+            assert info["end"] == so.end and info["k"] == so.k and info["step"] == so.step
+            assert np.array_equal(sp.download("d"), so.vec("d"))
+        ys, al = sp.history_scalars()
+        for j in range(6):
+            assert ys[j] == so.ys(j) and al[j] == so.alpha(j)
+            assert np.array_equal(sp.download(f"s{j}"), so.hist(j, "s"))
+            assert np.array_equal(sp.download(f"y{j}"), so.hist(j, "y"))
+        r = sp.report()
+        ro = so.report()
+        assert (r.fx, r.xnorm, r.gnorm, r.neval) == (ro["fx"], ro["xnorm"], ro["gnorm"], ro["neval"])
+    so.close()
+    # stand-alone line search right after build
+    x = P.rosenbrock_x0()
+    with R.lbfgs().build(x, R.default_evaluate()) as sp:
+        step0 = sp.info()["step"]
+        ncall, step = sp.line_search(step0)
+        assert ncall >= 1 and step > 0
+
+
+def test_error_paths():
+    # Err from evaluate in build propagates (lbfgs.rs:454)
+    def bad(x, g):
+        raise ValueError("boom")
+
+    with pytest.raises(R.LbfgsError) as e:
+        R.lbfgs().minimize(P.rosenbrock_x0(), bad)
+    assert e.value.code == _ffi.ERR_EVALUATE
+    # Err inside the line search is swallowed -> revert -> "x not changed" (line.rs:213-220, lbfgs.rs:646)
+    calls = {"n": 0}
+
+    def flaky(x, g):
+        calls["n"] += 1
+        if calls["n"] == 3:
+            raise ValueError("late")
+        return P.rosenbrock(x, g)
+
+    with pytest.raises(R.LbfgsError) as e:
+        R.lbfgs().minimize(P.rosenbrock_x0(), flaky)
+    assert e.value.code == _ffi.ERR_X_NOT_CHANGED
+    with pytest.raises(O.OracleError) as eo:
+        calls["n"] = 0
+        O.lbfgs().minimize(P.rosenbrock_x0(), flaky)
+    assert eo.value.code == -4
+    # gradient_only + MoreThuente (line.rs:208)
+    b = R.lbfgs().with_gradient_only().with_linesearch_algorithm("MoreThuente")
+    with pytest.raises(R.LbfgsError) as e:
+        b.minimize(P.rosenbrock_x0(), R.default_evaluate())
+    assert e.value.code == _ffi.ERR_GRADONLY_MT
+    # orthantwise start >= end panics (orthantwise.rs:64)
+    with pytest.raises(R.LbfgsPanic):
+        R.lbfgs().with_orthantwise(1.0, 100, 100).minimize(P.rosenbrock_x0(), R.default_evaluate())
+    # setter assertions (lbfgs.rs:195-361) and unimplemented!() (:379)
+    with pytest.raises(AssertionError):
+        R.lbfgs().with_epsilon(-1.0)
+    with pytest.raises(AssertionError):
+        R.lbfgs().with_linesearch_gtol(1.5)
+    with pytest.raises(NotImplementedError):
+        R.lbfgs().with_linesearch_algorithm("Newton")
+
+
+def test_gradient_only_matches_oracle():
+    a, b = run_pair(lambda b: b.with_gradient_only().with_max_iterations(30), P.rosenbrock_x0(), O.rosenbrock(),
+                    R.default_evaluate())
+    assert_identical(a, b)
+
+
+def test_c_minimize_entry_point():
+    """lbfgs_minimize (C) == the Python loop over build/propagate."""
+    import ctypes as C
+
+    L = _ffi.load()
+    x = P.rosenbrock_x0()
+    ctx = R.Context(len(x))
+    b = R.lbfgs()
+    from rust_lbfgs_amd.api import _make_evaluator
+
+    ev, keep, _ = _make_evaluator(R.default_evaluate())
+    rep = _ffi.CReport()
+    err = C.create_string_buffer(256)
+    niters = []
+    cb = _ffi.PROGRESS_CB(lambda u, p: (niters.append(p.contents.niter), 0)[1])
+    rc = L.lbfgs_minimize(ctx._h, C.byref(b.param), x.ctypes.data_as(C.POINTER(C.c_double)), C.byref(ev), cb, None,
+                          C.byref(rep), err, 256)
+    assert rc == 0, err.value
+    x2 = P.rosenbrock_x0()
+    rep2 = R.lbfgs().minimize(x2, R.default_evaluate())
+    assert np.array_equal(x, x2) and rep.fx == rep2.fx and niters[-1] == 35
+    ctx.close()
