@@ -165,6 +165,14 @@ def main():
                 ach = 32.0 * n_local / (avg_ms * 1e-3) / 1e9  # 3 reads + 1 write of f64 per element
                 roof.update(achieved=ach, frac=ach / HBM_PEAK_GBPS, kernel="stream_kernel<OpTwoLoopStep<*,false,0>>",
                             launches=ns, avg_ms=avg_ms, bytes_per_launch=32 * n_local)
+                # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be collected from inside)
+                try:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                    if pm["n_local"] == n_local:
+                        roof["traffic"] = pm["traffic_bytes_per_launch"] / 1e9
+                        roof["traffic_unit"] = "GB per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_bench_n1e8_m10.md)"
+                except Exception:
+                    pass
             if nt:
                 t_tl = ms_all / nt
                 # 8*b passes of 8 bytes: the fused minimum that respects the dot->axpy dependency

@@ -11,9 +11,11 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -95,6 +97,7 @@ struct lbfgs_hip_ctx {
     double* pinned = nullptr;        // host staging, LBFGS_HIP_BOARD_SLOTS doubles
     int grid_default = 0;
     int grid_override = 0;
+    size_t nt_threshold_bytes = (size_t)256 << 20;
     bool prof_on = false;
     ProfClass prof[LBFGS_HIP_K_CLASSES];
     std::vector<ProfPair> prof_pool;
@@ -212,10 +215,17 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out)
     red.ticket = ctx->ticket;
     for (int k = 0; k < Op::NRED; ++k) red.out[k] = red_out[k];
     const uint64_t n = ctx->shard.n_local;
+    constexpr int MAP = tuning<Op>::MAP, UNR = tuning<Op>::UNR;
+    // streaming (`nt`) hints once a vector cannot stay in the 256 MiB Infinity Cache anyway
+    const bool streaming = n * sizeof(double) >= ctx->nt_threshold_bytes;
     {
         ProfScope ps(ctx, kclass);
-        hipLaunchKernelGGL((stream_kernel<Op>), dim3(grid_for(ctx)), dim3(BLOCK), 0, ctx->stream, op, n,
-                           ctx->shard.offset, red);
+        if (streaming)
+            hipLaunchKernelGGL((stream_kernel<Op, UNR, ~0u, ~0u, MAP>), dim3(grid_for(ctx)), dim3(BLOCK), 0, ctx->stream,
+                               op, n, ctx->shard.offset, red);
+        else
+            hipLaunchKernelGGL((stream_kernel<Op, UNR, 0u, 0u, MAP>), dim3(grid_for(ctx)), dim3(BLOCK), 0, ctx->stream,
+                               op, n, ctx->shard.offset, red);
     }
     HIP_TRY(ctx, hipGetLastError());
     if (Op::NRED > 0) return allreduce(ctx, red_out, Op::NRED);
@@ -343,7 +353,11 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     }
     hipDeviceProp_t prop;
     CTX_TRY(hipGetDeviceProperties(&prop, device));
-    ctx->grid_default = prop.multiProcessorCount * 8;  // 8 x 256-thread workgroups per CU = 32 waves/CU
+    // ~0.85 workgroups per CU: measured optimum of the windowed streaming map on MI355X (216 of 256 CUs);
+    // more workgroups only add concurrent DRAM pages (tools/tune_stream.hip)
+    ctx->grid_default = std::max(1, prop.multiProcessorCount * 27 / 32);
+    if (const char* e = getenv("LBFGS_HIP_NT_THRESHOLD_MB")) ctx->nt_threshold_bytes = (size_t)atoll(e) << 20;
+    if (const char* e = getenv("LBFGS_HIP_GRID")) ctx->grid_override = std::min(MAX_GRID, std::max(0, atoi(e)));
     CTX_TRY(hipMalloc(&ctx->board, (LBFGS_HIP_BOARD_SLOTS + 2) * sizeof(double)));
     CTX_TRY(hipMemsetAsync(ctx->board, 0, (LBFGS_HIP_BOARD_SLOTS + 2) * sizeof(double), ctx->stream));
     CTX_TRY(hipMalloc(&ctx->partials, (size_t)MAX_RED * MAX_GRID * sizeof(double)));

@@ -173,6 +173,8 @@ struct TwoLoopCoef {
 template <bool NEG_SRC, bool SCALE, int VMODE>
 struct OpTwoLoopStep {
     static constexpr int NIN = (VMODE == 0) ? 3 : 2, NOUT = 1, NRED = 1;
+    // measured best for the 3r+1w shape on MI355X: fine grid-stride, 2 chunks in flight per stream
+    static constexpr int TUNE_MAP = (VMODE == 0) ? 1 : DEFAULT_MAP, TUNE_UNROLL = (VMODE == 0) ? 2 : UNROLL;
     const double* in[3];  // src, u, v
     double* out[1];       // dst (= d)
     const double* dot_in; // previous reduction (global sum)

@@ -8,9 +8,15 @@
 //   * enough bytes in flight per CU: every thread issues UNROLL independent
 //     16-B loads per input stream before the first use (compiler places the
 //     s_waitcnt at first use);
-//   * a persistent grid of (CUs x blocks-per-CU) workgroups, each owning one
-//     contiguous, evenly sized range of the vector (no tail imbalance, and the
-//     block -> address-range map is identical in every launch);
+//   * FEW, LONG DRAM streams: a persistent grid of ~0.85 workgroups per CU sweeps
+//     each vector as one contiguous window (grid-stride over 4-16 KiB chunks).
+//     Measured on MI355X at n = 1e8 (tools/tune_stream.hip): one contiguous range
+//     per workgroup with 8 workgroups/CU = 5.2 TB/s on the 3r+1w two-loop step;
+//     the windowed map with 216 workgroups and `nt` hints = 6.3 TB/s; pure reads
+//     7.2 TB/s.  More workgroups mean more concurrent DRAM pages, not more speed;
+//   * the `nt` (streaming) cache hint on every load/store once a vector no longer
+//     fits the 256 MiB Infinity Cache; below that, plain accesses let the cache
+//     keep the running vector between consecutive kernels;
 //   * reductions: f64 per-thread accumulators -> wave64 shuffle tree -> LDS ->
 //     one partial per workgroup -> the LAST workgroup to finish (agent-scope
 //     ticket) sums the partials in a FIXED order.  No float atomics, so results
@@ -26,7 +32,8 @@ namespace lh {
 
 constexpr int BLOCK = 256;          // 4 wave64 per workgroup
 constexpr int WAVES = BLOCK / 64;
-constexpr int UNROLL = 4;           // independent 16-B loads per stream per thread
+constexpr int UNROLL = 4;           // default: independent 16-B loads per stream per thread
+constexpr int DEFAULT_MAP = 2;      // default address map (see stream_kernel)
 constexpr int MAX_RED = 6;          // sums a kernel may produce
 constexpr int MAX_GRID = 4096;      // upper bound on workgroups per launch
 
@@ -112,6 +119,35 @@ __device__ __forceinline__ void grid_reduce(double (&acc)[NRED], const RedCtl& r
     }
 }
 
+// 16-byte global access; NT adds the `nt` (streaming, no reuse expected) cache hint
+template <bool NT>
+__device__ __forceinline__ d2 ld16(const double* base, uint64_t pair) {
+    const d2* p = reinterpret_cast<const d2*>(base) + pair;
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st16(double* base, uint64_t pair, d2 v) {
+    d2* p = reinterpret_cast<d2*>(base) + pair;
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+// per-stream hint selection (s is a compile-time constant after unrolling)
+template <unsigned MASK>
+__device__ __forceinline__ d2 ld_masked(const double* base, uint64_t pair, int s) {
+    if constexpr (MASK == 0u) return ld16<false>(base, pair);
+    else if constexpr (MASK == ~0u) return ld16<true>(base, pair);
+    else return ((MASK >> s) & 1u) ? ld16<true>(base, pair) : ld16<false>(base, pair);
+}
+template <unsigned MASK>
+__device__ __forceinline__ void st_masked(double* base, uint64_t pair, d2 v, int s) {
+    if constexpr (MASK == 0u) st16<false>(base, pair, v);
+    else if constexpr (MASK == ~0u) st16<true>(base, pair, v);
+    else if ((MASK >> s) & 1u) st16<true>(base, pair, v);
+    else st16<false>(base, pair, v);
+}
+
 // ---- the skeleton ----------------------------------------------------------------------
 // Op interface:
 //   static constexpr int NIN, NOUT, NRED;
@@ -126,6 +162,18 @@ struct is_pairwise {
     template <class T> static constexpr bool test(decltype(T::PAIRWISE)*) { return T::PAIRWISE; }
     template <class T> static constexpr bool test(...) { return false; }
     static constexpr bool value = test<Op>(nullptr);
+};
+
+// An Op may pin its own (MAP, UNROLL) with `static constexpr int TUNE_MAP, TUNE_UNROLL` (measured per kernel
+// shape with tools/tune_stream.hip); otherwise the defaults apply.
+template <class Op>
+struct tuning {
+    template <class T> static constexpr int map(decltype(T::TUNE_MAP)*) { return T::TUNE_MAP; }
+    template <class T> static constexpr int map(...) { return DEFAULT_MAP; }
+    template <class T> static constexpr int unr(decltype(T::TUNE_UNROLL)*) { return T::TUNE_UNROLL; }
+    template <class T> static constexpr int unr(...) { return UNROLL; }
+    static constexpr int MAP = map<Op>(nullptr);
+    static constexpr int UNR = unr<Op>(nullptr);
 };
 
 template <class Op>
@@ -145,9 +193,17 @@ __device__ __forceinline__ void do_pair(const Op& op, const typename Op::Coef& c
     }
 }
 
-template <class Op>
+// MAP selects the workgroup -> address map:
+//   0  each workgroup owns ONE contiguous, evenly sized range (G*streams concurrent DRAM streams);
+//   1  grid-stride over 4 KiB chunks: at any time the whole grid sweeps one contiguous window
+//      of UNROLL*G chunks per vector (few, long DRAM streams);
+//   2  grid-stride over SPAN*UNROLL*4 KiB super-chunks (each workgroup reads SPAN*UNROLL adjacent
+//      chunks, UNROLL at a time).
+// NTI / NTO are bit masks over the input / output streams: bit s set = stream s uses the `nt` hint.
+template <class Op, int UNR = UNROLL, unsigned NTI = 0, unsigned NTO = 0, int MAP = 0, int SPAN = 1>
 __global__ __launch_bounds__(BLOCK) void stream_kernel(const Op op, const uint64_t n, const uint64_t gofs,
                                                         const RedCtl red) {
+    constexpr int UNROLL = UNR;
     constexpr int NIN = Op::NIN, NOUT = Op::NOUT, NRED = Op::NRED;
     const typename Op::Coef cf = op.setup();
     double acc[NRED ? NRED : 1];
@@ -156,39 +212,59 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const Op op, const uint64
 
     const uint64_t n2 = n >> 1;                           // 16-byte pairs
     const uint64_t nch = (n2 + BLOCK - 1) / BLOCK;        // chunks of BLOCK pairs (4 KiB per stream)
-    const uint64_t c0 = nch * blockIdx.x / gridDim.x;     // this workgroup's contiguous chunk range
-    const uint64_t c1 = nch * (blockIdx.x + 1) / gridDim.x;
     const uint64_t tid = threadIdx.x;
+    const uint64_t G = gridDim.x, B = blockIdx.x;
 
-    uint64_t c = c0;
-    // fast path: UNROLL full chunks, all loads issued before the first use
-    for (; c + UNROLL <= c1 && (c + UNROLL) * BLOCK <= n2; c += UNROLL) {
-        d2 v[UNROLL][NIN ? NIN : 1];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const uint64_t p = (c + u) * BLOCK + tid;
-#pragma unroll
-            for (int s = 0; s < NIN; ++s) v[u][s] = reinterpret_cast<const d2*>(op.in[s])[p];
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const uint64_t p = (c + u) * BLOCK + tid;
-            d2 w[NOUT ? NOUT : 1];
-            do_pair<Op>(op, cf, v[u], w, acc, gofs + 2 * p);
-#pragma unroll
-            for (int s = 0; s < NOUT; ++s) reinterpret_cast<d2*>(op.out[s])[p] = w[s];
-        }
+    // chunk index of this workgroup's u-th chunk in trip t, and the trip count
+    uint64_t c0 = 0, c1 = 0, trips = 0;
+    if constexpr (MAP == 0) {
+        c0 = nch * B / G;                                 // contiguous chunk range [c0, c1)
+        c1 = nch * (B + 1) / G;
+        trips = (c1 - c0 + UNROLL - 1) / UNROLL;
+    } else {
+        const uint64_t per_round = G * UNROLL * (MAP == 2 ? SPAN : 1);
+        trips = (nch + per_round - 1) / per_round * (MAP == 2 ? SPAN : 1);
     }
-    // remainder chunks (at most UNROLL-1 full ones plus the ragged last chunk)
-    for (; c < c1; ++c) {
-        const uint64_t p = c * BLOCK + tid;
-        if (p < n2) {
-            d2 v[NIN ? NIN : 1], w[NOUT ? NOUT : 1];
+    auto chunk_of = [&](uint64_t t, int u) -> uint64_t {
+        if constexpr (MAP == 0) return c0 + t * UNROLL + u;
+        else if constexpr (MAP == 1) return (t * UNROLL + u) * G + B;
+        else return (((t / SPAN) * G + B) * SPAN + (t % SPAN)) * UNROLL + u;
+    };
+    auto chunk_end = [&]() -> uint64_t { return MAP == 0 ? c1 : nch; };
+
+    for (uint64_t t = 0; t < trips; ++t) {
+        const uint64_t last = chunk_of(t, UNROLL - 1);
+        if (last < chunk_end() && (last + 1) * BLOCK <= n2) {
+            // fast path: UNROLL full chunks, all loads issued before the first use
+            d2 v[UNROLL][NIN ? NIN : 1];
 #pragma unroll
-            for (int s = 0; s < NIN; ++s) v[s] = reinterpret_cast<const d2*>(op.in[s])[p];
-            do_pair<Op>(op, cf, v, w, acc, gofs + 2 * p);
+            for (int u = 0; u < UNROLL; ++u) {
+                const uint64_t p = chunk_of(t, u) * BLOCK + tid;
 #pragma unroll
-            for (int s = 0; s < NOUT; ++s) reinterpret_cast<d2*>(op.out[s])[p] = w[s];
+                for (int s = 0; s < NIN; ++s) v[u][s] = ld_masked<NTI>(op.in[s], p, s);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const uint64_t p = chunk_of(t, u) * BLOCK + tid;
+                d2 w[NOUT ? NOUT : 1];
+                do_pair<Op>(op, cf, v[u], w, acc, gofs + 2 * p);
+#pragma unroll
+                for (int s = 0; s < NOUT; ++s) st_masked<NTO>(op.out[s], p, w[s], s);
+            }
+        } else {
+            // ragged end: chunk by chunk, pair by pair
+            for (int u = 0; u < UNROLL; ++u) {
+                const uint64_t c = chunk_of(t, u);
+                const uint64_t p = c * BLOCK + tid;
+                if (c < chunk_end() && p < n2) {
+                    d2 v[NIN ? NIN : 1], w[NOUT ? NOUT : 1];
+#pragma unroll
+                    for (int s = 0; s < NIN; ++s) v[s] = ld_masked<NTI>(op.in[s], p, s);
+                    do_pair<Op>(op, cf, v, w, acc, gofs + 2 * p);
+#pragma unroll
+                    for (int s = 0; s < NOUT; ++s) st_masked<NTO>(op.out[s], p, w[s], s);
+                }
+            }
         }
     }
     // odd n: the last element, scalar (never taken by PAIRWISE ops: their n is even)

@@ -1,0 +1,112 @@
+"""Full-size (BASELINE.json: n = 1e8, m = 10) checks through size-independent properties, all on the device:
+the oracle cannot run at this size in seconds, so parity is carried by (a) the fused two-loop against the
+reference's UNFUSED sequence of primitives on the same device data, (b) linearity of the recursion,
+(c) bitwise determinism, (d) exact integer-valued sums, and (e) `nt`-hinted kernels == plain kernels."""
+import os
+
+import numpy as np
+import pytest
+
+import rust_lbfgs_amd as R
+from rust_lbfgs_amd import hotpath as H, objectives
+from rust_lbfgs_amd.math import DeviceVec
+from tests.test_gpu_parity import product_library  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+N_FULL = int(os.environ.get("LBFGS_TEST_FULL_N", 100_000_000))
+M = 10
+
+
+def _fill_history(ctx, hist, tmp):
+    """Deterministic, well-conditioned (s_j, y_j): s from the hashed quadratic's gradient at a constant
+    point, y = s scaled by hashed positive curvatures (so y.s > 0), all generated on the device."""
+    q = objectives.Quadratic()
+    for j in range(hist.m):
+        tmp.fill(0.25 + 0.1 * j)
+        H.objective_eval(q, tmp, hist.s(j), 0)                 # s_j = a*c_j - b
+        H.objective_eval(q, hist.s(j), hist.y(j), 0)           # y_j = a*s_j - b
+        hist.y(j).vecadd(hist.s(j), 2.0)                       # keep y.s comfortably positive
+    ys = [hist.y(j).vecdot(hist.s(j)) for j in range(hist.m)]
+    assert all(v > 0 for v in ys)
+    hist.set_scalars(ys=np.array(ys), alpha=np.zeros(hist.m))
+    return ys
+
+
+@pytest.mark.parametrize("n", [N_FULL, 12_500_003])
+def test_two_loop_properties_at_full_size(n):
+    with R.Context(n) as ctx:
+        hist = H.History(ctx, M)
+        g, d1, d2, tmp = (DeviceVec(ctx) for _ in range(4))
+        ys = _fill_history(ctx, hist, tmp)
+        tmp.fill(-0.3)
+        H.objective_eval(objectives.Logistic(), tmp, g, 0)     # some non-trivial g
+        yy = hist.y(3).vecdot(hist.y(3))
+        ctx.set_scalars(7, [ys[3], yy])
+        k, end = 37, 3                                          # bound = m = 10, ring wrapped
+        # (a) fused (8b passes) vs the reference's unfused primitive sequence (10b+2 passes)
+        ne1 = hist.two_loop(d1, g, k, end, 7, 8, 12)
+        dn2 = ctx.scalars(12)[0]
+        _, alpha_fused = hist.scalars()
+        d2.vecncpy(g)
+        ne2 = hist.two_loop_unfused(d2, k, end, 7, 8)
+        _, alpha_unfused = hist.scalars()
+        assert ne1 == ne2 == 4
+        tmp.vecdiff(d1, d2)
+        dnorm = d1.vec2norm()
+        assert dnorm > 0 and np.isfinite(dnorm)
+        assert tmp.vec2norm() <= 1e-12 * dnorm
+        assert abs(dn2 - dnorm * dnorm) <= 1e-12 * dn2
+        assert np.max(np.abs(alpha_fused - alpha_unfused)) <= 1e-12 * np.max(np.abs(alpha_unfused))
+        # (c) determinism: the same launch twice is bitwise identical
+        hist.two_loop(d2, g, k, end, 7, 8, 12)
+        tmp.vecdiff(d1, d2)
+        assert tmp.vec2norm() == 0.0
+        assert ctx.scalars(12)[0] == dn2
+        # (b) linearity: H(4g) == 4 H(g) exactly (scaling by a power of two commutes with every rounding)
+        g.vecscale(4.0)
+        hist.two_loop(d2, g, k, end, 7, 8, 12)
+        d1.vecscale(4.0)
+        tmp.vecdiff(d1, d2)
+        assert tmp.vec2norm() == 0.0
+        # (d) integer-valued sums are exact in any order
+        d1.fill(1.0); d2.fill(3.0)
+        assert d1.vecdot(d2) == 3.0 * n
+        assert d2.vec2norm() == np.sqrt(9.0 * n)
+        hist.free()
+        for v in (g, d1, d2, tmp):
+            v.free()
+
+
+def test_streaming_hint_kernels_equal_plain_kernels(monkeypatch):
+    """Above 256 MiB per vector the library launches the `nt`-hinted instantiations.  Force them at a
+    small size and require bit-identical results to the plain ones (same arithmetic, same order)."""
+    n = 3_000_017
+    out = {}
+    for mode, thr in (("plain", "1000000"), ("nt", "0")):
+        monkeypatch.setenv("LBFGS_HIP_NT_THRESHOLD_MB", thr)
+        with R.Context(n) as ctx:
+            hist = H.History(ctx, 4)
+            g, d, tmp, x, xp = (DeviceVec(ctx) for _ in range(5))
+            q = objectives.Quadratic()
+            for j in range(4):
+                tmp.fill(0.5 + j)
+                H.objective_eval(q, tmp, hist.s(j), 0)
+                H.objective_eval(q, hist.s(j), hist.y(j), 0)
+                hist.y(j).vecadd(hist.s(j), 2.0)
+            ys = [hist.y(j).vecdot(hist.s(j)) for j in range(4)]
+            hist.set_scalars(ys=np.array(ys))
+            ctx.set_scalars(7, [ys[1], hist.y(1).vecdot(hist.y(1))])
+            tmp.fill(0.1)
+            H.objective_eval(objectives.Logistic(), tmp, g, 0)
+            hist.two_loop(d, g, 9, 1, 7, 8, 12)
+            xp.fill(0.2)
+            H.objective_line_eval(q, x, xp, d, 1e-3, g, 0)
+            hist.update(2, x, xp, g, d, 0.5, True, 6)
+            out[mode] = (d.to_numpy(), x.to_numpy(), g.to_numpy(), hist.s(2).to_numpy(), hist.y(2).to_numpy(),
+                         ctx.scalars(0, 13))
+            hist.free()
+            for v in (g, d, tmp, x, xp):
+                v.free()
+    for a, b in zip(out["plain"], out["nt"]):
+        assert np.array_equal(a, b)

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 outputs of `bench.py` into profiles/ (kernel stats + PMC HBM traffic).
+
+    python tools/summarize_profile.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir> <n_local> <out.md>
+
+PMC handling follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE
+are collected in SEPARATE passes (TCC slots), both are in KiB; on gfx950 FETCH_SIZE reports exactly
+half of the bytes of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is exact for
+16-byte-per-lane streaming stores.
+"""
+import csv
+import glob
+import re
+import sys
+from collections import defaultdict
+
+# algorithmic passes (reads, writes) of one n-vector per launch, per kernel shape
+PASSES = [
+    (r"OpTwoLoopStep<(true|false), false, 0>", (3, 1), "two-loop step  q+=c*u; out=v.q"),
+    (r"OpTwoLoopStep<(true|false), true, 1>", (2, 1), "two-loop gamma transition"),
+    (r"OpTwoLoopStep<false, false, 2>", (2, 1), "two-loop last step + ||d||^2"),
+    (r"OpTwoLoopFirst", (2, 0), "two-loop first dot s.(-g)"),
+    (r"OpHistUpdate<", (4, 2), "history update s,y + 5 sums"),
+    (r"OpObjLineEval<", (2, 2), "line step + quadratic eval + g.d"),
+    (r"OpObjEval<", (1, 1), "objective eval"),
+    (r"OpDot[,>]", (2, 0), "dot (dginit)"),
+    (r"OpNorms2", (2, 0), "norms"),
+    (r"OpCopy<", (1, 1), "copy / ncopy"),
+]
+
+
+def shape(name):
+    for pat, rw, label in PASSES:
+        if re.search(pat, name):
+            return rw, label
+    return None, None
+
+
+def short(name):
+    m = re.search(r"stream_kernel<lh::(.*?)(, \d+, \d+u, \d+u, \d+, \d+)?>\(", name)
+    return ("stream_kernel<" + m.group(1) + ">") if m else name[:60]
+
+
+def pmc(dirname, counter):
+    agg = defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(dirname + "/*/*_counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                a = agg[short(r["Kernel_Name"])]
+                a[0] += 1
+                a[1] += float(r["Counter_Value"])
+    return {k: v[1] / v[0] for k, v in agg.items()}
+
+
+def main():
+    stats_dir, fdir, wdir, n_local, out = sys.argv[1:6]
+    n_local = int(n_local)
+    fetch = pmc(fdir, "FETCH_SIZE")
+    write = pmc(wdir, "WRITE_SIZE")
+    rows = []
+    for f in glob.glob(stats_dir + "/*/*_kernel_stats.csv"):
+        for r in csv.DictReader(open(f)):
+            rows.append(r)
+    lines = ["| kernel | calls | avg us | algorithmic passes (r+w) | algorithmic GB/launch | GB/s | % of 8 TB/s | "
+             "PMC read GB (FETCH_SIZE x2) | PMC write GB (WRITE_SIZE) | PMC/algorithmic |",
+             "|---|---|---|---|---|---|---|---|---|---|"]
+    for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
+        nm = short(r["Name"])
+        rw, label = shape(r["Name"])
+        avg_us = float(r["AverageNs"]) / 1e3
+        if rw is None:
+            lines.append(f"| `{nm}` | {r['Calls']} | {avg_us:.1f} | - | - | - | - | - | - | - |")
+            continue
+        gb = (rw[0] + rw[1]) * 8 * n_local / 1e9
+        gbps = gb / (avg_us * 1e-6)
+        fr = fetch.get(nm)
+        wr = write.get(nm)
+        fr_gb = fr * 1024 * 2 / 1e9 if fr is not None else None
+        wr_gb = wr * 1024 / 1e9 if wr is not None else None
+        ratio = (fr_gb + wr_gb) / gb if fr_gb is not None and wr_gb is not None else None
+        lines.append(f"| `{nm}` ({label}) | {r['Calls']} | {avg_us:.1f} | {rw[0]}r+{rw[1]}w | {gb:.2f} | {gbps:.0f} | "
+                     f"{gbps / 80:.1f} | {fr_gb:.3f} | {wr_gb:.3f} | {ratio:.3f} |" if ratio is not None else
+                     f"| `{nm}` ({label}) | {r['Calls']} | {avg_us:.1f} | {rw[0]}r+{rw[1]}w | {gb:.2f} | {gbps:.0f} | "
+                     f"{gbps / 80:.1f} | - | - | - |")
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
