@@ -89,7 +89,7 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU
         import torch
         import torch.distributed as dist
 
@@ -199,7 +199,7 @@ def main():
                                    f"x/g/s/y sharded contiguously over {world} GPU(s)",
                        "n": a.n, "m": a.m, "n_local_rank0": n_local, "prefill_iters": prefill,
                        "line_search_trials_per_step": ncalls / max(a.steps, 1), "restarts": restarts,
-                       "allreduce": "rccl" if world > 1 else "none"},
+                       "allreduce": "rccl" if (world > 1 or os.environ.get("LBFGS_FORCE_RCCL") == "1") else "none"},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -172,8 +172,9 @@ int lbfgs_hip_history_update(lbfgs_hip_history* h, int slot, const lbfgs_hip_vec
 int lbfgs_hip_history_damp(lbfgs_hip_history* h, int slot, const lbfgs_hip_vec* gp, double step, double theta);
 
 /* update_search_direction + lbfgs_two_loop_recursion + dnorm
- * (core.rs:95-101, lbfgs.rs:569-604, lbfgs.rs:543), fused to 8*bound passes:
- *   d = -g ; two-loop over the history ; board[dnorm_slot] = ||d||^2.
+ * (core.rs:95-101, lbfgs.rs:569-604, lbfgs.rs:543), fused to 8*bound + 1 passes:
+ *   d = -g ; two-loop over the history ; board[dnorm_slot] = ||d||^2 ; board[dnorm_slot+1] = g.d
+ *   (the dginit of the NEXT line search, core.rs:78-92, free because the last step streams d anyway).
  * gamma is read on the device as board[gamma_num_slot] / board[gamma_den_slot]
  * (ys / yy of the update just done).  k and end are the reference's arguments
  * (k = number of corrections stored so far, end = slot just written); *new_end
@@ -198,7 +199,8 @@ int lbfgs_hip_owlqn_post_eval(const lbfgs_hip_vec* x, const lbfgs_hip_vec* g, lb
 /* Problem::update_orthant_new_point (core.rs:167-180): wp_i = xp_i==0 ? signum(-pg_i) : signum(xp_i), all i */
 int lbfgs_hip_orthant_select(lbfgs_hip_vec* wp, const lbfgs_hip_vec* xp, const lbfgs_hip_vec* pg);
 /* Orthantwise::constrain_search_direction (orthantwise.rs:140-161): d_i = 0 where
- * signum(d_i) != signum(-pg_i) on [start,end); board[out_slot] = ||d||^2 (caller asserts != 0). */
+ * signum(d_i) != signum(-pg_i) on [start,end); board[out_slot] = ||d||^2 (caller asserts != 0);
+ * board[out_slot+1] = pg.d, the dginit of the next line search under OWL-QN (core.rs:90). */
 int lbfgs_hip_constrain_direction(lbfgs_hip_vec* d, const lbfgs_hip_vec* pg, uint64_t start, uint64_t end,
                                   int out_slot);
 

@@ -9,9 +9,9 @@
 // operation -- it selects the trial steps, so a one-ulp difference here would
 // change every later iterate.
 //
-// Host synchronisations per iteration: one per line-search trial (f and g.d),
-// one after the history update (||s||, ys, yy, norms) and one after the two-loop
-// (||d||) -- nothing inside the two-loop recursion.
+// Host synchronisations per iteration: one per line-search trial (f and g.d) and ONE
+// after the two-loop, which fetches ||s||^2, ys, yy, the norms, ||d||^2 and the next
+// line search's g.d together -- nothing inside the two-loop recursion.
 #include "../../../include/lbfgs_solver.h"
 
 #include <cmath>
@@ -30,11 +30,13 @@ enum Slot {
     S_PGN2 = 3,     // ||pg||^2           (OWL-QN)
     S_XN2_OWL = 4,  // ||x||^2            (OWL-QN)
     S_DGINIT = 5,
-    S_UPD = 6,      // ||s||^2, ys, yy, ||x||^2, ||g||^2, s.bs
-    S_DNORM2 = 12,
-    S_DNORM2C = 13,
-    S_NORMS = 14,   // ||x||^2, ||g||^2
-    S_FAILED = 16   // closure failure count (world > 1)
+    // one contiguous block read with ONE synchronisation at the end of an iteration:
+    S_UPD = 6,      // ||s||^2, ys, yy, ||x||^2, ||g||^2, s.bs          (history update)
+    S_DNORM2 = 12,  // ||d||^2, g.d                                      (two-loop, last step)
+    S_DNORM2C = 14, // ||d||^2, pg.d after the orthant projection        (OWL-QN)
+    S_END_BLOCK = 16,
+    S_NORMS = 16,   // ||x||^2, ||g||^2
+    S_FAILED = 18   // closure failure count (world > 1)
 };
 
 inline bool sign_positive(double v) { return !std::signbit(v); }  // f64::is_sign_positive
@@ -179,6 +181,8 @@ struct lbfgs_state {
     uint64_t k = 0;
     uint64_t ncall = 0;
     double last_gamma = 0.0;
+    double dginit_next = 0.0;  // g.d of the direction just built (fused into the two-loop's last kernel)
+    bool dginit_valid = false;
     std::string err, ls_err;
 
     bool owlqn() const { return vars.orthantwise != 0; }
@@ -333,6 +337,11 @@ int revert(lbfgs_state* st) {
 // reference's bail!) is reported through *bail and handled by the caller (line.rs:213-220).
 // ------------------------------------------------------------------------------------------------
 int dginit(lbfgs_state* st, double* out) {  // core.rs:78-92 (the gradient of the SAVED point)
+    if (st->dginit_valid) {  // already produced by the kernel that finished d
+        st->dginit_valid = false;
+        *out = st->dginit_next;
+        return LBFGS_OK;
+    }
     TRYB(st, lbfgs_hip_vecdot(st->owlqn() ? st->pg : st->gp, st->d, S_DGINIT));
     return backend(st, lbfgs_hip_scalars_read(st->ctx, S_DGINIT, 1, out));
 }
@@ -575,6 +584,9 @@ int lbfgs_build(lbfgs_state** out, lbfgs_hip_ctx* ctx, const lbfgs_param* param,
     // lbfgs.rs:461: step = (1/||d||) * h0, and ||d|| = ||g|| exactly (d = -g)
     if ((rc = ensure_norms(st)) != LBFGS_OK) return bail_out(rc);
     st->step = (1.0 / std::sqrt(st->gnorm2)) * param->initial_inverse_hessian;
+    // g.d with d = -g is -(g.g) exactly, in any fixed summation order (core.rs:78-92)
+    st->dginit_next = -st->gnorm2;
+    st->dginit_valid = true;
     st->end = 0;
     st->k = 0;
     st->ncall = 0;
@@ -599,6 +611,7 @@ int lbfgs_line_search(lbfgs_state* st, double* step, uint64_t* ncall) {
     // stand-alone use (line.rs:8-32 doctest): the base point is the current one
     TRYB(st, lbfgs_hip_veccpy(st->xp, st->x));
     TRYB(st, lbfgs_hip_veccpy(st->gp, st->gx));
+    st->dginit_valid = false;
     return line_search_find(st, *step, ncall);
 }
 
@@ -618,51 +631,64 @@ int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
     st->ncall = ncall;
     const double step_ls = st->step;
 
-    // IterationData::update (:525-533, :640-692)
+    // IterationData::update (:525-533, :640-692), then -- without waiting for its scalars --
+    // update_search_direction + two-loop + dnorm (:536-543) and the OWL-QN projection (:554): the
+    // device forms gamma = ys/yy itself, so the whole tail of the iteration is enqueued at once and
+    // its scalars come back in ONE read.  The reference's early exits (:646, :655) need the scalars
+    // first, so whenever they can fire by construction (failed line search => x == xp) or a host
+    // decision sits in between (Powell damping), the early read is kept.
     const int damping = st->vars.damping;
+    const bool early = damping || !st->ls_err.empty();
     TRYB(st, lbfgs_hip_history_update(st->hist, st->end, st->x, st->xp, st->gx, st->gp, st->step, damping, S_UPD));
-    double u[6] = {0, 0, 0, 0, 0, 0};
-    TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_UPD, damping ? 6 : 5, u));
-    const double snorm = std::sqrt(u[0]), ys = u[1], yy = u[2];
-    if (!(snorm != 0.0)) {
-        char b[96];
-        snprintf(b, sizeof(b), "x not changed with step %g", st->step);
-        return fail(st, LBFGS_ERR_X_NOT_CHANGED, b);  // :646
+    double u[S_END_BLOCK - S_UPD] = {0};
+    auto check_update = [&]() -> int {
+        const double snorm = std::sqrt(u[0]), yy = u[2];
+        if (!(snorm != 0.0)) {
+            char b[96];
+            snprintf(b, sizeof(b), "x not changed with step %g", st->step);
+            return fail(st, LBFGS_ERR_X_NOT_CHANGED, b);  // :646
+        }
+        if (!(yy != 0.0)) return fail(st, LBFGS_ERR_GX_NOT_CHANGED, "gx not changed");  // :655
+        return LBFGS_OK;
+    };
+    if (early) {
+        TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_UPD, 6, u));
+        TRY(check_update());
+        if (damping) {  // :664-689 (sigma2 = 0.6, sigma3 = 3.0)
+            const double sigma2 = 0.6, ys = u[1], sbs = u[5];
+            if (ys < (1.0 - sigma2) * sbs) {  // case 1: y is replaced; ys and gamma are NOT refreshed (:656, :691)
+                const double theta = sigma2 * sbs / (sbs - ys);
+                TRYB(st, lbfgs_hip_history_damp(st->hist, st->end, st->gp, st->step, theta));
+            }
+            // case 2 (:681-685) computes a vector and drops it: nothing to do
+        }
     }
-    if (!(yy != 0.0)) return fail(st, LBFGS_ERR_GX_NOT_CHANGED, "gx not changed");  // :655
+    int new_end = st->end;
+    TRYB(st, lbfgs_hip_two_loop(st->hist, st->d, st->grad_for_direction(), st->k - 1, st->end, S_UPD + 1, S_UPD + 2,
+                                S_DNORM2, &new_end));
+    if (st->owlqn())  // :554, orthantwise.rs:140-161 (after dnorm, as in the reference)
+        TRYB(st, lbfgs_hip_constrain_direction(st->d, st->pg, st->owl_start, st->owl_end, S_DNORM2C));
+    TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_UPD, S_END_BLOCK - S_UPD, u));
+    if (!early) TRY(check_update());
+    st->end = new_end;
     if (!st->owlqn()) {
         st->xnorm2 = u[3];
         st->gnorm2 = u[4];
         st->norms_valid = true;
     }
-    if (damping) {  // :664-689 (sigma2 = 0.6, sigma3 = 3.0)
-        const double sigma2 = 0.6, sbs = u[5];
-        if (ys < (1.0 - sigma2) * sbs) {  // case 1: y is replaced; ys and gamma are NOT refreshed (:656, :691)
-            const double theta = sigma2 * sbs / (sbs - ys);
-            TRYB(st, lbfgs_hip_history_damp(st->hist, st->end, st->gp, st->step, theta));
-        }
-        // case 2 (:681-685) computes a vector and drops it: nothing to do
-    }
-    st->last_gamma = ys / yy;  // :691 (the device forms the same quotient from the board)
+    st->last_gamma = u[1] / u[2];  // :691 ys/yy (the device formed the same quotient from the board)
 
-    // update_search_direction + two-loop + dnorm (:536-543), fused on the device
-    int new_end = st->end;
-    TRYB(st, lbfgs_hip_two_loop(st->hist, st->d, st->grad_for_direction(), st->k - 1, st->end, S_UPD + 1, S_UPD + 2,
-                                S_DNORM2, &new_end));
-    st->end = new_end;
-    double dn2;
-    TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_DNORM2, 1, &dn2));
-    const double dnorm = std::sqrt(dn2);
+    const double dnorm = std::sqrt(u[S_DNORM2 - S_UPD]);  // :543
     if (!sign_positive(dnorm)) return fail(st, LBFGS_ERR_INVALID_DNORM, "invalid norm value");  // :544
     st->step = st->vars.constrain_step_size ? std::fmin(st->vars.max_step_size, dnorm) / dnorm : 1.0;  // :547-551
-
-    if (st->owlqn()) {  // :554, orthantwise.rs:140-161
-        TRYB(st, lbfgs_hip_constrain_direction(st->d, st->pg, st->owl_start, st->owl_end, S_DNORM2C));
-        double c2;
-        TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_DNORM2C, 1, &c2));
-        if (std::sqrt(c2) == 0.0)
+    if (st->owlqn()) {
+        if (std::sqrt(u[S_DNORM2C - S_UPD]) == 0.0)
             return fail(st, LBFGS_PANIC_ZERO_DIRECTION, "invalid direction vector after constraints");
+        st->dginit_next = u[S_DNORM2C + 1 - S_UPD];  // pg.d of the projected direction (core.rs:90)
+    } else {
+        st->dginit_next = u[S_DNORM2 + 1 - S_UPD];   // g.d (core.rs:80)
     }
+    st->dginit_valid = true;
     if (out) {
         TRY(get_progress(st, out));
         out->step = step_ls;  // :557

@@ -251,7 +251,7 @@ int two_loop_step(lbfgs_hip_history* h, const double* src, const double* u, cons
     op.gamma_num = gnum;
     op.gamma_den = gden;
     op.mode_b = mode_b;
-    double* outs[1] = {out};
+    double* outs[2] = {out, out + 1};  // VMODE 2 produces two adjacent sums
     return launch(h->ctx, kclass, op, outs);
 }
 }  // namespace
@@ -746,7 +746,7 @@ int lbfgs_hip_two_loop(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
                        int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int* new_end) {
     if (!h || !d || !g || d->ctx != h->ctx || g->ctx != h->ctx || end < 0 || end >= h->m || !new_end)
         return LBFGS_HIP_ERR_ARG;
-    if (!slot_ok(gamma_num_slot, 1) || !slot_ok(gamma_den_slot, 1) || !slot_ok(dnorm_slot, 1)) return LBFGS_HIP_ERR_ARG;
+    if (!slot_ok(gamma_num_slot, 1) || !slot_ok(gamma_den_slot, 1) || !slot_ok(dnorm_slot, 2)) return LBFGS_HIP_ERR_ARG;
     lbfgs_hip_ctx* ctx = h->ctx;
     ProfScope whole(ctx, LBFGS_HIP_K_TWOLOOP_ALL);
     const int m = h->m;
@@ -758,12 +758,10 @@ int lbfgs_hip_two_loop(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
     double* dn = ctx->board + dnorm_slot;
     double* dots = ctx->board + LBFGS_HIP_BOARD_SLOTS;  // 2 private ping-pong slots past the public board
     if (bound == 0) {
-        // no corrections yet: d = -g, then d *= gamma (lbfgs.rs:591) and ||d||^2
-        int rc = lbfgs_hip_vecncpy(d, g);
-        if (rc != LBFGS_HIP_OK) return rc;
+        // no corrections yet: d = (-g)*gamma (core.rs:95-101, lbfgs.rs:591), ||d||^2 and g.d
         OpScaleDevNorm op{};
-        op.in[0] = d->p; op.out[0] = d->p; op.gn = gnum; op.gd = gden;
-        double* outs[1] = {dn};
+        op.in[0] = g->p; op.out[0] = d->p; op.gn = gnum; op.gd = gden;
+        double* outs[2] = {dn, dn + 1};
         return launch(ctx, LBFGS_HIP_K_TWOLOOP_EDGE, op, outs);
     }
     // slot visited at first-loop step i (i = 0..bound-1): j_i = (e1 - 1 - i) mod m   (lbfgs.rs:583)
@@ -809,8 +807,8 @@ int lbfgs_hip_two_loop(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
         if (rc != LBFGS_HIP_OK) return rc;
         pp ^= 1;
     }
-    // last step: q += (alpha_{j0} - beta_{j0}) s_{j0} ; ||d||^2 (lbfgs.rs:543)          2r 1w
-    return two_loop_step<false, false, 2>(h, d->p, h->s[jat(0)]->p, nullptr, d->p, dots + pp, jat(0), 1, gnum, gden, dn,
+    // last step: q += (alpha_{j0} - beta_{j0}) s_{j0} ; ||d||^2 (lbfgs.rs:543) and g.d (core.rs:78-92)   3r 1w
+    return two_loop_step<false, false, 2>(h, d->p, h->s[jat(0)]->p, g->p, d->p, dots + pp, jat(0), 1, gnum, gden, dn,
                                           LBFGS_HIP_K_TWOLOOP_EDGE);
 }
 
@@ -876,11 +874,11 @@ int lbfgs_hip_orthant_select(lbfgs_hip_vec* wp, const lbfgs_hip_vec* xp, const l
 
 int lbfgs_hip_constrain_direction(lbfgs_hip_vec* d, const lbfgs_hip_vec* pg, uint64_t start, uint64_t end,
                                   int out_slot) {
-    if (!same_ctx(d, pg) || !slot_ok(out_slot, 1)) return LBFGS_HIP_ERR_ARG;
+    if (!same_ctx(d, pg) || !slot_ok(out_slot, 2)) return LBFGS_HIP_ERR_ARG;
     OpConstrainDir op{};
     op.in[0] = d->p; op.in[1] = pg->p; op.out[0] = d->p;
     op.start = start; op.end = end;
-    double* outs[1] = {d->ctx->board + out_slot};
+    double* outs[2] = {d->ctx->board + out_slot, d->ctx->board + out_slot + 1};
     return launch(d->ctx, LBFGS_HIP_K_OWLQN, op, outs);
 }
 

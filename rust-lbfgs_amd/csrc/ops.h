@@ -163,7 +163,8 @@ struct OpTwoLoopFirst {
 // One fused step:   q = [ -src | src ] + c*u ;  [ q *= gamma ] ;  dst = q ;  sum += w*q
 //   VMODE 0: w is a third stream v        (3r 1w)  -- the dominant kernel
 //   VMODE 1: w = u  (gamma transition)    (2r 1w)
-//   VMODE 2: w = q  (last step, ||d||^2)  (2r 1w)
+//   VMODE 2: w = q  (last step): sums ||d||^2 AND g.d, the next line search's dginit
+//            (core.rs:78-92), reading g as the third stream                      (3r 1w)
 // The coefficient is formed on the device from the previous reduction (no host round trip):
 //   mode A (first loop, lbfgs.rs:587-589):  alpha_j = dot/ys_j ; c = -alpha_j   (alpha_j is stored)
 //   mode B (second loop, lbfgs.rs:597-599): beta = dot/ys_j ;    c = alpha_j - beta
@@ -172,10 +173,10 @@ struct TwoLoopCoef {
 };
 template <bool NEG_SRC, bool SCALE, int VMODE>
 struct OpTwoLoopStep {
-    static constexpr int NIN = (VMODE == 0) ? 3 : 2, NOUT = 1, NRED = 1;
+    static constexpr int NIN = (VMODE == 1) ? 2 : 3, NOUT = 1, NRED = (VMODE == 2) ? 2 : 1;
     // measured best for the 3r+1w shape on MI355X: fine grid-stride, 2 chunks in flight per stream
     static constexpr int TUNE_MAP = (VMODE == 0) ? 1 : DEFAULT_MAP, TUNE_UNROLL = (VMODE == 0) ? 2 : UNROLL;
-    const double* in[3];  // src, u, v
+    const double* in[3];  // src, u, v (VMODE 2: g)
     double* out[1];       // dst (= d)
     const double* dot_in; // previous reduction (global sum)
     const double* ys_j;   // ys of the slot whose coefficient this step applies
@@ -203,6 +204,7 @@ struct OpTwoLoopStep {
         w[0] = q;
         const double wv = (VMODE == 0) ? v[2] : (VMODE == 1 ? v[1] : q);
         acc[0] += wv * q;                      // math.rs:41
+        if constexpr (VMODE == 2) acc[1] += v[2] * q;  // g.d
     }
 };
 
@@ -249,9 +251,10 @@ struct OpOrthantSelect {
     }
 };
 
-// orthantwise.rs:140-161: d_i = 0 where signum(d_i) != signum(-pg_i) on [start,end); ||d||^2
+// orthantwise.rs:140-161: d_i = 0 where signum(d_i) != signum(-pg_i) on [start,end); ||d||^2 and pg.d
+// (the next line search's dginit under OWL-QN, core.rs:90)
 struct OpConstrainDir {
-    static constexpr int NIN = 2, NOUT = 1, NRED = 1;
+    static constexpr int NIN = 2, NOUT = 1, NRED = 2;
     const double* in[2];  // d, pg
     double* out[1];       // d
     uint64_t start, end;
@@ -262,6 +265,7 @@ struct OpConstrainDir {
         if (gi >= start && gi < end && signum0(d) != signum0(-v[1])) d = 0.0;
         w[0] = d;
         acc[0] += d * d;
+        acc[1] += v[1] * d;
     }
 };
 
@@ -405,16 +409,17 @@ struct OpFill {  // vec![c; n]
     __device__ void elem(const Coef&, const double*, double* w, double*, uint64_t) const { w[0] = c; }
 };
 
-struct OpScaleDevNorm {  // d *= gamma (gamma = board ratio) and ||d||^2: two-loop with no corrections stored
-    static constexpr int NIN = 1, NOUT = 1, NRED = 1;
-    const double* in[1];
-    double* out[1];
+struct OpScaleDevNorm {  // d = (-g)*gamma, ||d||^2 and g.d: two-loop with no corrections stored
+    static constexpr int NIN = 1, NOUT = 1, NRED = 2;
+    const double* in[1];  // g
+    double* out[1];       // d
     const double *gn, *gd;
     typedef double Coef;
     __device__ Coef setup() const { return *gn / *gd; }
     __device__ void elem(const Coef& c, const double* v, double* w, double* acc, uint64_t) const {
-        w[0] = v[0] * c;
+        w[0] = (-v[0]) * c;
         acc[0] += w[0] * w[0];
+        acc[1] += v[0] * w[0];
     }
 };
 

@@ -83,8 +83,10 @@ def sharded_context(n, device=0, kind="rccl", process_group=None, stream=None):
     rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
     lo, hi = shard_range(n, rank, world)
     shard = _ffi.Shard(rank, world, n, lo, hi - lo)
-    if world == 1:
-        comm = None
+    import os
+
+    if world == 1 and not (kind == "rccl" and os.environ.get("LBFGS_FORCE_RCCL") == "1"):
+        comm = None  # (LBFGS_FORCE_RCCL=1 exercises the RCCL code path with a 1-rank communicator)
     elif kind == "rccl":
         comm = rccl_comm(process_group)
     elif kind == "callback":

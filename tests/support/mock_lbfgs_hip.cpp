@@ -256,7 +256,9 @@ int lbfgs_hip_two_loop(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
     oracle_vecncpy(d->p->data(), g->p->data(), nl(h->ctx));
     int rc = lbfgs_hip_two_loop_unfused(h, d, k, end, gn, gd, new_end);
     if (rc != 0) return rc;
-    return gdot(h->ctx, d->p->data(), d->p->data(), h->ctx->board + dn);
+    rc = gdot(h->ctx, d->p->data(), d->p->data(), h->ctx->board + dn);
+    if (rc != 0) return rc;
+    return gdot(h->ctx, g->p->data(), d->p->data(), h->ctx->board + dn + 1);
 }
 
 int lbfgs_hip_owlqn_post_eval(const lbfgs_hip_vec* x, const lbfgs_hip_vec* g, lbfgs_hip_vec* pg, double cc,
@@ -279,7 +281,9 @@ int lbfgs_hip_constrain_direction(lbfgs_hip_vec* d, const lbfgs_hip_vec* pg, uin
     size_t ls, le;
     local_range(d->ctx, start, end, &ls, &le);
     oracle_project(d->p->data(), pg->p->data(), ls, le, 1);
-    return gdot(d->ctx, d->p->data(), d->p->data(), d->ctx->board + o);
+    int rc = gdot(d->ctx, d->p->data(), d->p->data(), d->ctx->board + o);
+    if (rc != 0) return rc;
+    return gdot(d->ctx, pg->p->data(), d->p->data(), d->ctx->board + o + 1);
 }
 
 static int eval_obj(const lbfgs_hip_objective* obj, lbfgs_hip_ctx* c, const double* x, double* g, double* f) {

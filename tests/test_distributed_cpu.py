@@ -1,0 +1,148 @@
+"""N > 1 path on the CPU: two gloo ranks, contiguous shards, scalar all-reduce through the callback
+communicator, on the CPU test double of the C-ABI (tests/support).  Checks that the SHARDED run
+reproduces the single-rank oracle trajectory (to summation-order noise: each rank sums its shard
+sequentially, then the two partials are added), for L-BFGS and for OWL-QN with an [start, end)
+range that straddles the shard boundary, and that a sharded host closure's partial f is reduced."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["LBFGS_ROOT"])
+import torch.distributed as dist
+import rust_lbfgs_amd as R
+from rust_lbfgs_amd import _ffi, objectives
+from rust_lbfgs_amd import dist as D
+if os.environ.get("LBFGS_WORKER_PRODUCT") != "1":   # CPU suite: the test double; GPU suite: the HIP library
+    from tests.support import mock
+    _ffi.use_library_for_tests(mock.load())
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+case = json.loads(os.environ["LBFGS_CASE"])
+n = case["n"]
+ctx = D.sharded_context(n, kind="callback")
+lo, hi = D.shard_range(n, rank, world)
+assert ctx.n_local == hi - lo and ctx.shard.offset == lo
+b = R.lbfgs().with_m(case["m"]).with_max_iterations(case["iters"]).with_epsilon(0.0)
+if case.get("owl"):
+    b = b.with_orthantwise(*case["owl"])
+if case["objective"] == "quadratic":
+    ev = objectives.Quadratic()
+elif case["objective"] == "logistic":
+    ev = objectives.Logistic()
+else:
+    # a separable HOST closure evaluated on this rank's shard only: returns the shard's partial f
+    def ev(x, g):
+        idx = np.arange(lo, hi, dtype=np.float64)
+        a = 1.0 + (idx % 7.0)
+        g[:] = a * (x - 0.5)
+        return float(np.sum(0.5 * a * (x - 0.5) ** 2))
+rows = []
+x = np.zeros(ctx.n_local)
+st = b.build(x, ev, ctx=ctx)
+while not st.is_converged():
+    p = st.propagate()
+    rows.append([p.niter, p.neval, p.ncall, p.fx, p.xnorm, p.gnorm, p.step])
+xs = st.download("x")
+st.close()
+nred, _ = ctx.prof_read(_ffi.K_COMM)   # the test double counts its all-reduces here
+if os.environ.get("LBFGS_WORKER_PRODUCT") == "1":
+    nred = 1
+ctx.close()
+out = dict(rank=rank, lo=lo, hi=hi, rows=rows, x=xs.tolist(), allreduces=nred)
+json.dump(out, open(os.path.join(os.environ["LBFGS_OUT"], f"rank{rank}.json"), "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_world(case, world, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, LBFGS_ROOT=ROOT, LBFGS_CASE=json.dumps(case), LBFGS_OUT=str(tmp_path),
+               OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return [json.load(open(tmp_path / f"rank{k}.json")) for k in range(world)]
+
+
+def oracle_rows(case):
+    from oracle import oracle as O
+
+    b = O.lbfgs().with_m(case["m"]).with_max_iterations(case["iters"]).with_epsilon(0.0)
+    if case.get("owl"):
+        b = b.with_orthantwise(*case["owl"])
+    n = case["n"]
+    if case["objective"] == "quadratic":
+        ev = O.quadratic()
+    elif case["objective"] == "logistic":
+        ev = O.logistic()
+    else:
+        def ev(x, g):
+            idx = np.arange(0, n, dtype=np.float64)
+            a = 1.0 + (idx % 7.0)
+            g[:] = a * (x - 0.5)
+            return float(np.sum(0.5 * a * (x - 0.5) ** 2))
+    rows = []
+    x = np.zeros(n)
+    b.minimize(x, ev, lambda p: rows.append([p["niter"], p["neval"], p["ncall"], p["fx"], p["xnorm"], p["gnorm"],
+                                            p["step"]]) and False)
+    return rows, x
+
+
+@pytest.mark.parametrize("case", [
+    dict(name="quadratic", n=5000, m=5, iters=25, objective="quadratic"),
+    dict(name="owlqn_straddle", n=3001, m=6, iters=20, objective="logistic", owl=[0.5, 700, 2900]),
+    dict(name="host_closure", n=1000, m=4, iters=12, objective="closure"),
+], ids=lambda c: c["name"])
+def test_two_ranks_match_single_rank_oracle(case, tmp_path):
+    outs = run_world(case, 2, tmp_path)
+    ref_rows, ref_x = oracle_rows(case)
+    # shards tile [0, n) contiguously
+    assert outs[0]["lo"] == 0 and outs[0]["hi"] == outs[1]["lo"] and outs[1]["hi"] == case["n"]
+    # every rank saw the same (global) scalars
+    assert outs[0]["rows"] == outs[1]["rows"]
+    assert outs[0]["allreduces"] == outs[1]["allreduces"] > 0
+    rows = outs[0]["rows"]
+    assert len(rows) == len(ref_rows)
+    for got, ref in zip(rows, ref_rows):
+        assert got[:3] == ref[:3]
+        for a, b in zip(got[3:], ref[3:]):
+            assert abs(a - b) <= 1e-9 * max(abs(b), 1e-6), (got, ref)
+    x = np.concatenate([np.array(o["x"]) for o in outs])
+    assert np.max(np.abs(x - ref_x)) <= 1e-9 * max(np.max(np.abs(ref_x)), 1e-12)
+
+
+def test_shard_range_properties():
+    import rust_lbfgs_amd as R  # noqa: F401
+    from rust_lbfgs_amd.dist import shard_range
+
+    for n in (0, 1, 255, 256, 257, 1000, 10**8, 10**8 + 1):
+        for world in (1, 2, 3, 4, 8):
+            pieces = [shard_range(n, r, world) for r in range(world)]
+            assert pieces[0][0] == 0 and pieces[-1][1] == n
+            for (a, b), (c, d) in zip(pieces, pieces[1:]):
+                assert b == c and a <= b
+            for lo, hi in pieces:
+                if hi > lo:  # non-empty shards start on a 256-element (2 KiB) boundary
+                    assert lo % 256 == 0 and (hi % 256 == 0 or hi == n)
+    assert shard_range(10**8, 7, 8) == (87501568, 100000000)

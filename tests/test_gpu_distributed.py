@@ -1,0 +1,57 @@
+"""N > 1 on the real HIP library with ONE GPU: two processes share GPU 0, each holds a contiguous
+shard, scalars are closed through the callback communicator (gloo).  Plus the RCCL code path with a
+1-rank communicator (dlopen, ncclCommInitRank, in-place ncclAllReduce on the compute stream)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import rust_lbfgs_amd as R
+from rust_lbfgs_amd import _ffi
+from rust_lbfgs_amd.math import DeviceVec
+from tests.test_distributed_cpu import oracle_rows, run_world
+from tests.test_gpu_parity import product_library  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", [
+    dict(name="quadratic", n=200_003, m=7, iters=25, objective="quadratic"),
+    dict(name="owlqn_straddle", n=30_001, m=6, iters=20, objective="logistic", owl=[0.5, 7000, 29000]),
+    dict(name="host_closure", n=1000, m=4, iters=12, objective="closure"),
+], ids=lambda c: c["name"])
+def test_two_processes_one_gpu(case, tmp_path, monkeypatch):
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("covered by tests/test_distributed_cpu.py")
+    monkeypatch.setenv("LBFGS_WORKER_PRODUCT", "1")
+    outs = run_world(case, 2, tmp_path)
+    ref_rows, ref_x = oracle_rows(case)
+    assert outs[0]["rows"] == outs[1]["rows"]
+    assert len(outs[0]["rows"]) == len(ref_rows)
+    for got, ref in zip(outs[0]["rows"], ref_rows):
+        assert got[:3] == ref[:3]
+        for a, b in zip(got[3:], ref[3:]):
+            assert abs(a - b) <= 1e-9 * max(abs(b), 1e-6), (got, ref)
+    x = np.concatenate([np.array(o["x"]) for o in outs])
+    assert np.max(np.abs(x - ref_x)) <= 1e-9 * max(np.max(np.abs(ref_x)), 1e-12)
+
+
+def test_rccl_single_rank_communicator():
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs RCCL")
+    from rust_lbfgs_amd.dist import CommSpec
+
+    L = _ffi.load()
+    buf = (C.c_char * 128)()
+    assert L.lbfgs_hip_rccl_unique_id(buf) == 0, L.lbfgs_hip_last_error(None)
+    n = 100_001
+    shard = _ffi.Shard(0, 1, n, 0, n)
+    with R.Context(n, shard=shard, comm=CommSpec(_ffi.COMM_RCCL, unique_id=buf)) as ctx:
+        x, y = DeviceVec(ctx), DeviceVec(ctx)
+        x.fill(2.0); y.fill(0.5)
+        assert x.vecdot(y) == float(n)            # 1-rank all-reduce is the identity
+        assert x.vec2norm() == np.sqrt(4.0 * n)
+        nred, ms = ctx.prof_read(_ffi.K_COMM)
+        x.free(); y.free()
