@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- L-BFGS iterations/sec and two-loop HBM GB/s on MI355X (BASELINE.json's metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 100000000] [--m 10]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dim 100000000] [--hist 10]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is ONE L-BFGS iteration (LbfgsState::propagate, reference src/lbfgs.rs:503-560) of the
-synthetic diagonal quadratic of BASELINE.json config 4: n = 1e8, m = 10, More-Thuente, f64,
-everything resident in HBM (device objective, no PCIe in the timed region).  It contains one
-fused line-step+evaluate+g.d trial (normally exactly one), the history update, the fused
-two-loop recursion and the step clamp.  With N > 1 the n-vector is sharded contiguously over
-the ranks (total work fixed => "strong" scaling) and every reduction is closed by an RCCL
-all-reduce of its f64 scalars.
+synthetic diagonal quadratic of BASELINE.json config 4: n = 1e8, m = 10, More-Thuente, f64, the
+crate's default parameters, everything resident in HBM (device objective, no PCIe in the timed
+region).  One step = the line search (fused line-step + evaluate + g.d per trial), the history
+update and the fused two-loop recursion.  With N > 1 the n-vector is sharded contiguously over the
+ranks (total work fixed => "strong" scaling) and every reduction is closed by an all-reduce of its
+f64 scalars: RCCL ncclAllReduce on the compute stream, or the direct xGMI mailbox exchange ("p2p").
+With --comm auto (default) both are measured -- RCCL first, then p2p if its start-up self-test
+passes on every rank -- and the faster one is reported as `value`; both are listed in `config`.
 
 The JSON line carries, besides the contract fields:
   roofline      the dominant kernel (two-loop step  q += c*u ; out = v.q,  3 reads + 1 write of
@@ -37,12 +39,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--n", type=int, default=100_000_000)
-    ap.add_argument("--m", type=int, default=10)
+    ap.add_argument("--dim", dest="n", type=int, default=100_000_000, help="n, the number of variables")
+    ap.add_argument("--hist", dest="m", type=int, default=10, help="m, the number of L-BFGS corrections")
     ap.add_argument("--no-prof", action="store_true", help="do not time kernels with HIP events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=4_000_000, help="sample size of the CPU baseline")
     ap.add_argument("--grid", type=int, default=0, help="workgroups per launch (0 = library default)")
+    ap.add_argument("--comm", default="auto", choices=["auto", "rccl", "p2p", "callback"],
+                    help="N>1: how scalars are all-reduced (auto = measure RCCL, then p2p if its self-test passes)")
+    ap.add_argument("--pg-backend", default="nccl", help="torch.distributed backend used for rendezvous/barriers")
+    ap.add_argument("--device", type=int, default=-1, help="force a device index (testing: several ranks on one GPU)")
     return ap.parse_args()
 
 
@@ -74,88 +80,145 @@ def cpu_baseline(n_sample, m, n_full):
     }
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        a.gpus = world
+class Env:
+    """rank / world / torch.distributed plumbing (only rendezvous, barriers and a max over ranks)."""
+
+    def __init__(self, a):
+        self.a = a
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dev = self.local_rank if a.device < 0 else a.device
+        self.dist = self.torch = None
+        if self.world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU
+            import torch
+            import torch.distributed as dist
+
+            self.torch, self.dist = torch, dist
+            torch.cuda.set_device(self.dev)
+            if a.pg_backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.dev))
+            else:
+                dist.init_process_group(a.pg_backend)
+
+    def _tensor(self, v):
+        return self.torch.tensor([v], dtype=self.torch.float64, device="cuda" if self.a.pg_backend == "nccl" else "cpu")
+
+    def barrier(self, ctx=None):
+        if ctx is not None:
+            try:
+                ctx.sync()
+            except Exception:  # noqa: BLE001
+                pass
+        if self.dist is not None:
+            self.torch.cuda.synchronize()
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def reduce(self, v, op):
+        if self.dist is None:
+            return v
+        t = self._tensor(v)
+        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
+        return float(t.item())
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def make_context(env, kind):
+    """-> (ctx or None, label).  Every rank returns the same decision."""
+    import rust_lbfgs_amd as R
+    from rust_lbfgs_amd.dist import sharded_context
+
+    a = env.a
+    if env.world == 1:
+        if env.dist is not None and os.environ.get("LBFGS_FORCE_RCCL") == "1":
+            return sharded_context(a.n, device=env.dev, kind="rccl"), "rccl"
+        return R.Context(a.n, device=env.dev), "none"
+    ok, ctx = 1.0, None
+    try:
+        ctx = sharded_context(a.n, device=env.dev, kind=kind)
+        if kind == "p2p":  # known-answer reductions through the real code path before trusting it
+            tri = env.world * (env.world + 1) / 2.0
+            for it in range(16):
+                ctx.set_scalars(200, [float((env.rank + 1) * (it + 1)), float(env.rank == it % env.world),
+                                      -0.5 * (env.rank + 1)])
+                ctx.check(ctx._L.lbfgs_hip_scalars_allreduce(ctx._h, 200, 3))
+                if list(ctx.scalars(200, 3)) != [tri * (it + 1), 1.0, -0.5 * tri]:
+                    ok = 0.0
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] rank {env.rank}: {kind} communicator unavailable: {e}", file=sys.stderr)
+        ok = 0.0
+    if env.reduce(ok, "MIN") != 1.0:
+        if ctx is not None:
+            ctx.close()
+        return None, kind
+    return ctx, kind
+
+
+def measure(env, ctx, label):
+    """W warm-up steps, then exactly K timed steps between barriers; max over ranks.  Every rank executes the
+    same barriers even if its own run failed, so a failure can never leave a peer waiting."""
+    import numpy as np
 
     import rust_lbfgs_amd as R
     from rust_lbfgs_amd import _ffi, objectives
 
-    dist = None
-    torch = None
-    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU
-        import torch
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        from rust_lbfgs_amd.dist import sharded_context
-
-        ctx = sharded_context(a.n, device=local_rank, kind="rccl")
-    else:
-        ctx = R.Context(a.n, device=local_rank)
+    a = env.a
     if a.grid:
         ctx.set_grid(a.grid)
-
-    def barrier():
-        ctx.sync()
-        if dist is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    import numpy as np
-
     builder = R.lbfgs().with_m(a.m).with_epsilon(0.0)
     x0 = np.zeros(ctx.n_local)
-    state = builder.build(x0, objectives.Quadratic(), ctx=ctx)
-    restarts = 0
+    hold = {"state": None, "restarts": 0}
+    ok = 1.0
+    ncalls = 0
+    prefill = max(0, a.m + 2 - a.warmup)  # history must be full (bound = m) before anything is timed
 
     def step():
-        nonlocal state, restarts
         try:
-            return state.propagate()
-        except R.LbfgsError:
+            return hold["state"].propagate()
+        except R.LbfgsError as e:
+            if e.code <= -100:
+                raise  # backend / communicator failure
             # converged to rounding error (the line search cannot make progress): start over
-            state.close()
-            state = builder.build(x0, objectives.Quadratic(), ctx=ctx)
-            restarts += 1
-            return state.propagate()
+            hold["state"].close()
+            hold["state"] = builder.build(x0, objectives.Quadratic(), ctx=ctx)
+            hold["restarts"] += 1
+            return hold["state"].propagate()
 
-    prefill = max(0, a.m + 2 - a.warmup)  # history must be full (bound = m) before anything is timed
-    for _ in range(prefill + a.warmup):
-        step()
-
-    ncalls = 0
-    if not a.no_prof:
-        ctx.prof_enable(True)
-        ctx.prof_reset()
-    barrier()
+    try:
+        hold["state"] = builder.build(x0, objectives.Quadratic(), ctx=ctx)
+        for _ in range(prefill + a.warmup):
+            step()
+        if not a.no_prof:
+            ctx.prof_enable(True)
+            ctx.prof_reset()
+    except R.LbfgsError as e:
+        print(f"[bench] rank {env.rank}: {label} failed in warm-up: {e}", file=sys.stderr)
+        ok = 0.0
+    env.barrier(ctx)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        ncalls += step().ncall
-    barrier()
+    try:
+        if ok:
+            for _ in range(a.steps):
+                ncalls += step().ncall
+    except R.LbfgsError as e:
+        print(f"[bench] rank {env.rank}: {label} failed in the timed region: {e}", file=sys.stderr)
+        ok = 0.0
+    env.barrier(ctx)
     dt = time.perf_counter() - t0
-    ctx.prof_enable(False)
-
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    out = None
-    if rank == 0:
+    dt = env.reduce(dt, "MAX")
+    ok = env.reduce(ok, "MIN")
+    res = None
+    if ok == 1.0:
+        ctx.prof_enable(False)
         n_local = ctx.n_local
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None}
         if not a.no_prof:
             ns, ms_step = ctx.prof_read(_ffi.K_TWOLOOP_STEP)
-            ne, ms_edge = ctx.prof_read(_ffi.K_TWOLOOP_EDGE)
             nt, ms_all = ctx.prof_read(_ffi.K_TWOLOOP_ALL)
             nu, ms_upd = ctx.prof_read(_ffi.K_UPDATE)
             nv, ms_eval = ctx.prof_read(_ffi.K_EVAL)
@@ -171,46 +234,86 @@ def main():
                     if pm["n_local"] == n_local:
                         roof["traffic"] = pm["traffic_bytes_per_launch"] / 1e9
                         roof["traffic_unit"] = "GB per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_bench_n1e8_m10.md)"
-                except Exception:
+                except Exception:  # noqa: BLE001
                     pass
             if nt:
                 t_tl = ms_all / nt
                 # 8*b passes of 8 bytes: the fused minimum that respects the dot->axpy dependency
                 gbps = 64.0 * a.m * n_local / (t_tl * 1e-3) / 1e9
                 roof.update(two_loop={"ms": t_tl, "algorithmic_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS,
-                                      "bytes": 64 * a.m * n_local, "calls": nt})
+                                      "bytes": 64 * a.m * n_local, "calls": nt,
+                                      "note": "per GPU: this rank's shard, incl. the all-reduces inside the recursion"})
             roof["per_iteration_ms"] = {
                 "two_loop": ms_all / max(nt, 1), "history_update": ms_upd / max(a.steps, 1),
-                "line_eval": ms_eval / max(a.steps, 1), "allreduce": ms_comm / max(a.steps, 1)}
+                "line_eval": ms_eval / max(a.steps, 1), "allreduce": ms_comm / max(a.steps, 1),
+                "allreduce_launches": nc / max(a.steps, 1)}
+        res = dict(label=label, value=a.steps / dt, ms_per_step=dt / a.steps * 1e3, roofline=roof, n_local=n_local,
+                   prefill=prefill, trials=ncalls / max(a.steps, 1), restarts=hold["restarts"])
+    if hold["state"] is not None:
+        try:
+            hold["state"].close()
+        except Exception:  # noqa: BLE001
+            pass
+    return res
+
+
+def main():
+    a = parse()
+    # stdout carries exactly ONE JSON line: RCCL, gloo and friends print banners to fd 1, so park it on stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    env = Env(a)
+    if env.world != a.gpus:
+        if env.world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = env.world
+
+    import rust_lbfgs_amd  # noqa: F401  (fails loudly if the HIP extension is not built)
+
+    kinds = ["rccl", "p2p"] if (env.world > 1 and a.comm == "auto") else [a.comm if env.world > 1 else "none"]
+    results = []
+    for kind in kinds:
+        ctx, label = make_context(env, kind)
+        if ctx is None:
+            continue
+        r = measure(env, ctx, label)
+        ctx.close()
+        if r is not None:
+            results.append(r)
+
+    out = None
+    if env.rank == 0:
+        if not results:
+            sys.exit("bench.py: no communicator produced a result")
+        best = max(results, key=lambda r: r["value"])
         out = {
             "metric": "L-BFGS iters/sec (two-loop HBM GB/s in roofline) at n=1e8, m=10",
-            "value": a.steps / dt,
+            "value": best["value"],
             "unit": "iters/sec",
-            "n_gpus": world,
+            "n_gpus": env.world,
             "steps": a.steps,
             "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3,
+            "ms_per_step": best["ms_per_step"],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"hashed diagonal quadratic (cond 1e3), n={a.n}, m={a.m}, MoreThuente, "
-                                   f"x/g/s/y sharded contiguously over {world} GPU(s)",
-                       "n": a.n, "m": a.m, "n_local_rank0": n_local, "prefill_iters": prefill,
-                       "line_search_trials_per_step": ncalls / max(a.steps, 1), "restarts": restarts,
-                       "allreduce": "rccl" if (world > 1 or os.environ.get("LBFGS_FORCE_RCCL") == "1") else "none"},
-            "roofline": roof,
+            "config": {"workload": f"hashed diagonal quadratic (cond 1e3), n={a.n}, m={a.m}, MoreThuente, crate defaults, "
+                                   f"x/g/s/y sharded contiguously over {env.world} GPU(s)",
+                       "n": a.n, "m": a.m, "n_local_rank0": best["n_local"], "prefill_iters": best["prefill"],
+                       "line_search_trials_per_step": best["trials"], "restarts": best["restarts"],
+                       "allreduce": best["label"],
+                       "allreduce_measured_iters_per_sec": {r["label"]: round(r["value"], 3) for r in results}},
+            "roofline": best["roofline"],
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if env.world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.m, a.n)
-    state.close()
-    ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    env.finish()
     if out is not None:
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -68,7 +68,10 @@ typedef struct lbfgs_hip_shard {
 enum {
     LBFGS_HIP_COMM_NONE = 0,     /* world == 1 */
     LBFGS_HIP_COMM_RCCL = 1,     /* ncclAllReduce(ncclDouble, ncclSum) on the context's stream */
-    LBFGS_HIP_COMM_CALLBACK = 2  /* host callback (e.g. torch.distributed/gloo); stages through pinned memory */
+    LBFGS_HIP_COMM_CALLBACK = 2, /* host callback (e.g. torch.distributed/gloo); stages through pinned memory */
+    LBFGS_HIP_COMM_P2P = 3       /* direct xGMI exchange: every rank stores its partial, as tagged 8-byte granules,
+                                    into each peer's IPC-mapped mailbox and sums the P values in rank order --
+                                    one tiny kernel per reduction, bitwise identical on every rank */
 };
 /* in-place sum all-reduce of `count` doubles in host memory; return 0 on success */
 typedef int (*lbfgs_hip_allreduce_cb)(void* user, double* buf, int32_t count);
@@ -79,6 +82,9 @@ typedef struct lbfgs_hip_comm {
     const void* rccl_unique_id;  /* 128 bytes from lbfgs_hip_rccl_unique_id() on rank 0, shared out of band */
     lbfgs_hip_allreduce_cb callback;
     void* callback_user;
+    void* p2p_mailbox;           /* P2P: this rank's mailbox from lbfgs_hip_p2p_mailbox_create (owned by the ctx afterwards) */
+    const void* p2p_handles;     /* P2P: world x 64-byte IPC handles in rank order, gathered out of band */
+    double p2p_timeout_s;        /* P2P: bound on every spin (0 = 5 s); a timeout fails the next scalars_read */
 } lbfgs_hip_comm;
 
 /* ------------------------------------------------------------------------- */
@@ -88,6 +94,10 @@ int lbfgs_hip_abi_version(void);
 int lbfgs_hip_device_count(int* count);
 /* rank 0: produce the 128-byte RCCL unique id to broadcast to the other ranks */
 int lbfgs_hip_rccl_unique_id(void* out128);
+/* P2P step 1 (before ctx_create): allocate this rank's mailbox in uncached device memory and export
+ * its 64-byte IPC handle; the host framework all-gathers the handles into lbfgs_hip_comm.p2p_handles. */
+int lbfgs_hip_p2p_mailbox_create(int device, void** mailbox_out, void* ipc_handle64_out);
+void lbfgs_hip_p2p_mailbox_destroy(int device, void* mailbox); /* only if ctx_create was never given it */
 /* shard == NULL => single rank holding n elements.  comm == NULL => NONE.
  * stream == NULL => the context creates its own non-blocking stream. */
 int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfgs_hip_shard* shard,

@@ -22,7 +22,7 @@ HIP_ERR_ARG, HIP_ERR_HIP, HIP_ERR_COMM, HIP_ERR_NOMEM, HIP_ERR_NO_DEVICE = -101,
 
 LS_MORETHUENTE, LS_BT_ARMIJO, LS_BT_STRONGWOLFE, LS_BT_WOLFE = 0, 1, 2, 3
 EVAL_HOST, EVAL_DEVICE, EVAL_BUILTIN = 0, 1, 2
-COMM_NONE, COMM_RCCL, COMM_CALLBACK = 0, 1, 2
+COMM_NONE, COMM_RCCL, COMM_CALLBACK, COMM_P2P = 0, 1, 2, 3
 OBJ_QUADRATIC, OBJ_LOGISTIC, OBJ_ROSENBROCK = 1, 2, 3
 (K_TWOLOOP_STEP, K_TWOLOOP_EDGE, K_UPDATE, K_LINE, K_EVAL, K_OWLQN, K_BLAS1, K_COMM, K_TWOLOOP_ALL) = range(9)
 VEC_X, VEC_GX, VEC_XP, VEC_GP, VEC_PG, VEC_WP, VEC_D = range(7)
@@ -39,7 +39,8 @@ ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32
 
 class Comm(C.Structure):
     _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("rccl_unique_id", C.c_void_p),
-                ("callback", ALLREDUCE_CB), ("callback_user", C.c_void_p)]
+                ("callback", ALLREDUCE_CB), ("callback_user", C.c_void_p),
+                ("p2p_mailbox", C.c_void_p), ("p2p_handles", C.c_void_p), ("p2p_timeout_s", C.c_double)]
 
 
 class Objective(C.Structure):
@@ -85,7 +86,8 @@ class CReport(C.Structure):
 
 # every symbol include/lbfgs_hip.h declares
 HIP_SYMBOLS = """
-lbfgs_hip_abi_version lbfgs_hip_device_count lbfgs_hip_rccl_unique_id lbfgs_hip_ctx_create lbfgs_hip_ctx_destroy
+lbfgs_hip_abi_version lbfgs_hip_device_count lbfgs_hip_rccl_unique_id lbfgs_hip_p2p_mailbox_create
+lbfgs_hip_p2p_mailbox_destroy lbfgs_hip_ctx_create lbfgs_hip_ctx_destroy
 lbfgs_hip_last_error lbfgs_hip_sync lbfgs_hip_stream lbfgs_hip_get_shard lbfgs_hip_set_grid
 lbfgs_hip_vec_alloc lbfgs_hip_vec_free lbfgs_hip_vec_upload lbfgs_hip_vec_download lbfgs_hip_vec_fill
 lbfgs_hip_vec_ptr lbfgs_hip_vec_swap
@@ -115,6 +117,8 @@ def declare(L):
         "lbfgs_hip_abi_version": (i, []),
         "lbfgs_hip_device_count": (i, [C.POINTER(i)]),
         "lbfgs_hip_rccl_unique_id": (i, [vp]),
+        "lbfgs_hip_p2p_mailbox_create": (i, [i, C.POINTER(vp), vp]),
+        "lbfgs_hip_p2p_mailbox_destroy": (None, [i, vp]),
         "lbfgs_hip_ctx_create": (i, [C.POINTER(vp), i, u64, C.POINTER(Shard), C.POINTER(Comm), vp]),
         "lbfgs_hip_ctx_destroy": (None, [vp]),
         "lbfgs_hip_last_error": (C.c_char_p, [vp]),

@@ -72,6 +72,73 @@ bool rccl_load(std::string* err) {
 std::string g_create_error;  // last error of a failed ctx_create (no ctx to hold it)
 }  // namespace
 
+// ------------------------------------------------------------------------------------ P2P all-reduce
+// xGMI is point-to-point and fully connected, and the messages here are 8-48 bytes: instead of a collective
+// launch per reduction, ONE wave stores this rank's partials directly into every peer's mailbox and sums what
+// the peers stored into its own.  A double travels as two 8-byte granules {tag = epoch, 32 data bits} (the
+// LL-protocol idea: an 8-byte store is atomic, so data and flag arrive together, no fence between them).
+// Mailboxes are uncached device memory shared by IPC; all accesses are system-scope atomics.  The sum runs in
+// rank order on every rank, so all ranks hold bitwise identical results.  Every spin is bounded.
+constexpr int P2P_MAX_WORLD = 8;
+constexpr int P2P_RING = 4;  // a rank can be at most one reduction ahead of a peer; 4 slots is ample
+constexpr size_t P2P_MBOX_WORDS = (size_t)P2P_RING * P2P_MAX_WORLD * MAX_RED * 2;
+
+struct P2PArgs {
+    unsigned long long* mbox[P2P_MAX_WORLD];
+    double* val[MAX_RED];
+    int world, rank, count;
+    unsigned int epoch;
+    unsigned int* err;
+    unsigned long long timeout_ticks;  // wall_clock64 ticks (100 MHz)
+};
+
+__device__ __forceinline__ size_t p2p_word(unsigned epoch, int src_rank, int k, int half) {
+    return (((size_t)(epoch % P2P_RING) * P2P_MAX_WORLD + src_rank) * MAX_RED + k) * 2 + half;
+}
+
+__global__ __launch_bounds__(64) void p2p_allreduce_kernel(const P2PArgs a) {
+    __shared__ unsigned int bits[P2P_MAX_WORLD][MAX_RED][2];
+    const int lane = threadIdx.x;
+    const int per_rank = a.count * 2;
+    const int total = a.world * per_rank;
+    // 1. publish: my partial k, half h -> peer p's mailbox [epoch][my rank][k][h]
+    for (int i = lane; i < total; i += 64) {
+        const int p = i / per_rank, k = (i % per_rank) >> 1, h = i & 1;
+        const unsigned long long b = (unsigned long long)__double_as_longlong(*a.val[k]);
+        const unsigned int data = h ? (unsigned int)(b >> 32) : (unsigned int)b;
+        const unsigned long long granule = ((unsigned long long)a.epoch << 32) | data;
+        __hip_atomic_store(a.mbox[p] + p2p_word(a.epoch, a.rank, k, h), granule, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // 2. collect: what rank r stored for me, until its tag is this epoch (bounded)
+    const long long t0 = wall_clock64();
+    for (int i = lane; i < total; i += 64) {
+        const int r = i / per_rank, k = (i % per_rank) >> 1, h = i & 1;
+        const unsigned long long* src = a.mbox[a.rank] + p2p_word(a.epoch, r, k, h);
+        unsigned long long g;
+        for (;;) {
+            g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((unsigned int)(g >> 32) == a.epoch) break;
+            if ((unsigned long long)(wall_clock64() - t0) > a.timeout_ticks) {
+                atomicExch(a.err, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        bits[r][k][h] = (unsigned int)g;
+    }
+    __syncthreads();
+    // 3. fixed-order sum over ranks
+    if (lane < a.count) {
+        double s = 0.0;
+        for (int r = 0; r < a.world; ++r) {
+            const unsigned long long b = ((unsigned long long)bits[r][lane][1] << 32) | bits[r][lane][0];
+            s += __longlong_as_double((long long)b);
+        }
+        *a.val[lane] = s;
+    }
+}
+
 // ------------------------------------------------------------------------------------ objects
 struct ProfPair {
     hipEvent_t a, b;
@@ -91,6 +158,12 @@ struct lbfgs_hip_ctx {
     nccl_comm_t nccl = nullptr;
     lbfgs_hip_allreduce_cb cb = nullptr;
     void* cb_user = nullptr;
+    // P2P communicator
+    unsigned long long* p2p_mbox[P2P_MAX_WORLD] = {nullptr};  // [rank] -> that rank's mailbox (own entry = local)
+    bool p2p_opened[P2P_MAX_WORLD] = {false};
+    unsigned int p2p_epoch = 0;
+    unsigned int* p2p_err = nullptr;      // device flag: a spin timed out
+    unsigned long long p2p_timeout_ticks = 0;
     double* board = nullptr;         // LBFGS_HIP_BOARD_SLOTS doubles + 2 ping-pong dots
     double* partials = nullptr;      // MAX_RED * MAX_GRID
     unsigned int* ticket = nullptr;
@@ -192,6 +265,20 @@ int allreduce(lbfgs_hip_ctx* ctx, double* const* ptrs, int count) {
         }
         rc = g_rccl.GroupEnd();
         if (rc != 0) return fail(ctx, LBFGS_HIP_ERR_COMM, "ncclGroupEnd: %s", g_rccl.GetErrorString(rc));
+        return LBFGS_HIP_OK;
+    }
+    if (ctx->comm_kind == LBFGS_HIP_COMM_P2P) {
+        P2PArgs a{};
+        for (int r = 0; r < ctx->shard.world; ++r) a.mbox[r] = ctx->p2p_mbox[r];
+        for (int i = 0; i < count; ++i) a.val[i] = ptrs[i];
+        a.world = ctx->shard.world;
+        a.rank = ctx->shard.rank;
+        a.count = count;
+        a.epoch = ++ctx->p2p_epoch;
+        a.err = ctx->p2p_err;
+        a.timeout_ticks = ctx->p2p_timeout_ticks;
+        hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(1), dim3(64), 0, ctx->stream, a);
+        HIP_TRY(ctx, hipGetLastError());
         return LBFGS_HIP_OK;
     }
     // host callback: stage through pinned memory (synchronises the stream)
@@ -309,6 +396,32 @@ int lbfgs_hip_rccl_unique_id(void* out128) {
     return LBFGS_HIP_OK;
 }
 
+int lbfgs_hip_p2p_mailbox_create(int device, void** mailbox_out, void* ipc_handle64_out) {
+    if (!mailbox_out || !ipc_handle64_out) return fail(nullptr, LBFGS_HIP_ERR_ARG, "null argument");
+    *mailbox_out = nullptr;
+    hipError_t e = hipSetDevice(device);
+    void* p = nullptr;
+    const size_t bytes = P2P_MBOX_WORDS * sizeof(unsigned long long);
+    if (e == hipSuccess) e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    if (e == hipSuccess) e = hipMemset(p, 0, bytes);  // tag 0 is never a valid epoch
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    hipIpcMemHandle_t hdl;
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&hdl, p);
+    if (e != hipSuccess) {
+        if (p) (void)hipFree(p);
+        return fail(nullptr, LBFGS_HIP_ERR_COMM, "P2P mailbox: %s", hipGetErrorString(e));
+    }
+    memcpy(ipc_handle64_out, &hdl, HIP_IPC_HANDLE_SIZE);
+    *mailbox_out = p;
+    return LBFGS_HIP_OK;
+}
+
+void lbfgs_hip_p2p_mailbox_destroy(int device, void* mailbox) {
+    if (!mailbox) return;
+    (void)hipSetDevice(device);
+    (void)hipFree(mailbox);
+}
+
 int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfgs_hip_shard* shard,
                          const lbfgs_hip_comm* comm, void* stream) {
     if (!out) return fail(nullptr, LBFGS_HIP_ERR_ARG, "null out");
@@ -363,7 +476,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     CTX_TRY(hipMalloc(&ctx->partials, (size_t)MAX_RED * MAX_GRID * sizeof(double)));
     CTX_TRY(hipMalloc(&ctx->ticket, 64));
     CTX_TRY(hipMemsetAsync(ctx->ticket, 0, 64, ctx->stream));
-    CTX_TRY(hipHostMalloc(&ctx->pinned, LBFGS_HIP_BOARD_SLOTS * sizeof(double), hipHostMallocDefault));
+    CTX_TRY(hipHostMalloc(&ctx->pinned, (LBFGS_HIP_BOARD_SLOTS + 1) * sizeof(double), hipHostMallocDefault));
     CTX_TRY(hipStreamSynchronize(ctx->stream));
 #undef CTX_TRY
 
@@ -388,6 +501,38 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
             return r;
         }
         ctx->comm_kind = LBFGS_HIP_COMM_RCCL;
+    } else if (kind == LBFGS_HIP_COMM_P2P) {
+        const int W = ctx->shard.world, me = ctx->shard.rank;
+        if (W > P2P_MAX_WORLD || !comm->p2p_mailbox || !comm->p2p_handles) {
+            lbfgs_hip_ctx_destroy(ctx);
+            return fail(nullptr, LBFGS_HIP_ERR_ARG, "P2P communicator needs a mailbox, %d handles and world <= %d", W,
+                        P2P_MAX_WORLD);
+        }
+        ctx->p2p_mbox[me] = (unsigned long long*)comm->p2p_mailbox;
+        for (int r = 0; r < W; ++r) {
+            if (r == me) continue;
+            hipIpcMemHandle_t hdl;
+            memcpy(&hdl, (const char*)comm->p2p_handles + (size_t)r * HIP_IPC_HANDLE_SIZE, sizeof(hdl));
+            void* p = nullptr;
+            hipError_t e = hipIpcOpenMemHandle(&p, hdl, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) {
+                int rc = fail(nullptr, LBFGS_HIP_ERR_COMM, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
+                lbfgs_hip_ctx_destroy(ctx);
+                return rc;
+            }
+            ctx->p2p_mbox[r] = (unsigned long long*)p;
+            ctx->p2p_opened[r] = true;
+        }
+        hipError_t e = hipMalloc(&ctx->p2p_err, 64);
+        if (e == hipSuccess) e = hipMemset(ctx->p2p_err, 0, 64);
+        if (e != hipSuccess) {
+            int rc = fail(nullptr, LBFGS_HIP_ERR_HIP, "P2P error flag: %s", hipGetErrorString(e));
+            lbfgs_hip_ctx_destroy(ctx);
+            return rc;
+        }
+        const double tmo = comm->p2p_timeout_s > 0 ? comm->p2p_timeout_s : 5.0;
+        ctx->p2p_timeout_ticks = (unsigned long long)(tmo * 1e8);  // wall_clock64 runs at 100 MHz
+        ctx->comm_kind = LBFGS_HIP_COMM_P2P;
     } else if (kind == LBFGS_HIP_COMM_CALLBACK) {
         if (!comm->callback) {
             lbfgs_hip_ctx_destroy(ctx);
@@ -406,6 +551,12 @@ void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->nccl && g_rccl.ok) g_rccl.CommDestroy(ctx->nccl);
+    for (int r = 0; r < P2P_MAX_WORLD; ++r) {
+        if (!ctx->p2p_mbox[r]) continue;
+        if (ctx->p2p_opened[r]) (void)hipIpcCloseMemHandle(ctx->p2p_mbox[r]);
+        else (void)hipFree(ctx->p2p_mbox[r]);
+    }
+    if (ctx->p2p_err) (void)hipFree(ctx->p2p_err);
     for (auto& pc : ctx->prof)
         for (auto& pr : pc.pending) { (void)hipEventDestroy(pr.a); (void)hipEventDestroy(pr.b); }
     for (auto& pr : ctx->prof_pool) { (void)hipEventDestroy(pr.a); (void)hipEventDestroy(pr.b); }
@@ -509,8 +660,16 @@ int lbfgs_hip_scalars_read(lbfgs_hip_ctx* ctx, int first, int count, double* hos
     if (count == 0) return lbfgs_hip_sync(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, ctx->board + first, count * sizeof(double), hipMemcpyDeviceToHost,
                                 ctx->stream));
+    if (ctx->p2p_err)  // pinned[BOARD_SLOTS] is reserved for the P2P timeout flag
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + LBFGS_HIP_BOARD_SLOTS, ctx->p2p_err, sizeof(unsigned int),
+                                    hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(host, ctx->pinned, count * sizeof(double));
+    if (ctx->p2p_err) {
+        unsigned int flag;
+        memcpy(&flag, ctx->pinned + LBFGS_HIP_BOARD_SLOTS, sizeof(flag));
+        if (flag) return fail(ctx, LBFGS_HIP_ERR_COMM, "P2P all-reduce timed out waiting for a peer");
+    }
     return LBFGS_HIP_OK;
 }
 

@@ -58,6 +58,33 @@ def rccl_comm(process_group=None):
     return CommSpec(_ffi.COMM_RCCL, unique_id=buf)
 
 
+def p2p_comm(device, process_group=None, timeout_s=5.0):
+    """Direct xGMI exchange: every rank exports its mailbox by IPC handle, torch.distributed gathers them."""
+    import torch.distributed as dist
+
+    L = _ffi.load()
+    world = dist.get_world_size(process_group)
+    mbox = C.c_void_p()
+    hdl = (C.c_char * 64)()
+    rc = L.lbfgs_hip_p2p_mailbox_create(device, C.byref(mbox), hdl)
+    ok = [None] * world
+    dist.all_gather_object(ok, (rc, bytes(hdl.raw)), group=process_group)
+    if any(r != 0 for r, _ in ok):
+        if rc == 0:
+            L.lbfgs_hip_p2p_mailbox_destroy(device, mbox)
+        raise LbfgsError(_ffi.HIP_ERR_COMM, "P2P mailbox creation failed on some rank: " +
+                         L.lbfgs_hip_last_error(None).decode())
+    handles = (C.c_char * (64 * world))()
+    for r, (_, h) in enumerate(ok):
+        C.memmove(C.addressof(handles) + 64 * r, h, 64)
+    spec = CommSpec(_ffi.COMM_P2P)
+    spec._handles = handles
+    spec.c.p2p_mailbox = mbox
+    spec.c.p2p_handles = C.cast(handles, C.c_void_p)
+    spec.c.p2p_timeout_s = timeout_s
+    return spec
+
+
 def callback_comm(process_group=None):
     """Host all-reduce through torch.distributed (gloo or nccl group): slow, for tests."""
     import torch
@@ -91,6 +118,8 @@ def sharded_context(n, device=0, kind="rccl", process_group=None, stream=None):
         comm = rccl_comm(process_group)
     elif kind == "callback":
         comm = callback_comm(process_group)
+    elif kind == "p2p":
+        comm = p2p_comm(device, process_group)
     else:
         raise ValueError(kind)
     return Context(n, device=device, shard=shard, comm=comm, stream=stream)

@@ -75,6 +75,8 @@ extern "C" {
 int lbfgs_hip_abi_version(void) { return LBFGS_HIP_ABI_VERSION; }
 int lbfgs_hip_device_count(int* count) { *count = 0; return LBFGS_HIP_OK; }
 int lbfgs_hip_rccl_unique_id(void*) { return fail(nullptr, LBFGS_HIP_ERR_COMM, "mock: no RCCL"); }
+int lbfgs_hip_p2p_mailbox_create(int, void**, void*) { return fail(nullptr, LBFGS_HIP_ERR_COMM, "mock: no P2P"); }
+void lbfgs_hip_p2p_mailbox_destroy(int, void*) {}
 
 int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int, uint64_t n, const lbfgs_hip_shard* shard, const lbfgs_hip_comm* comm,
                          void*) {

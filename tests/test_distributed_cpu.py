@@ -29,7 +29,7 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 case = json.loads(os.environ["LBFGS_CASE"])
 n = case["n"]
-ctx = D.sharded_context(n, kind="callback")
+ctx = D.sharded_context(n, kind=os.environ.get("LBFGS_COMM_KIND", "callback"))
 lo, hi = D.shard_range(n, rank, world)
 assert ctx.n_local == hi - lo and ctx.shard.offset == lo
 b = R.lbfgs().with_m(case["m"]).with_max_iterations(case["iters"]).with_epsilon(0.0)

@@ -22,10 +22,14 @@ pytestmark = pytest.mark.gpu
     dict(name="owlqn_straddle", n=30_001, m=6, iters=20, objective="logistic", owl=[0.5, 7000, 29000]),
     dict(name="host_closure", n=1000, m=4, iters=12, objective="closure"),
 ], ids=lambda c: c["name"])
-def test_two_processes_one_gpu(case, tmp_path, monkeypatch):
+@pytest.mark.parametrize("kind", ["callback", "p2p"])
+def test_two_processes_one_gpu(case, kind, tmp_path, monkeypatch):
+    """kind = "p2p": the direct-exchange communicator (IPC mailboxes, tagged granules) between two
+    processes whose "peer" is the same GPU -- the protocol is identical to the 8-GPU xGMI case."""
     if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
         pytest.skip("covered by tests/test_distributed_cpu.py")
     monkeypatch.setenv("LBFGS_WORKER_PRODUCT", "1")
+    monkeypatch.setenv("LBFGS_COMM_KIND", kind)
     outs = run_world(case, 2, tmp_path)
     ref_rows, ref_x = oracle_rows(case)
     assert outs[0]["rows"] == outs[1]["rows"]
