@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--comm", default="auto", choices=["auto", "rccl", "p2p", "callback"],
                     help="N>1: how scalars are all-reduced (auto = measure RCCL, then p2p if its self-test passes)")
     ap.add_argument("--pg-backend", default="nccl", help="torch.distributed backend used for rendezvous/barriers")
+    ap.add_argument("--no-vector-free", action="store_true",
+                    help="skip the extra measurement of the vector-free (Gram) two-loop extension")
     ap.add_argument("--device", type=int, default=-1, help="force a device index (testing: several ranks on one GPU)")
     return ap.parse_args()
 
@@ -159,7 +161,7 @@ def make_context(env, kind):
     return ctx, kind
 
 
-def measure(env, ctx, label):
+def measure(env, ctx, label, vector_free=False):
     """W warm-up steps, then exactly K timed steps between barriers; max over ranks.  Every rank executes the
     same barriers even if its own run failed, so a failure can never leave a peer waiting."""
     import numpy as np
@@ -171,6 +173,8 @@ def measure(env, ctx, label):
     if a.grid:
         ctx.set_grid(a.grid)
     builder = R.lbfgs().with_m(a.m).with_epsilon(0.0)
+    if vector_free:
+        builder = builder.with_vector_free(True)
     x0 = np.zeros(ctx.n_local)
     hold = {"state": None, "restarts": 0}
     ok = 1.0
@@ -273,15 +277,23 @@ def main():
     import rust_lbfgs_amd  # noqa: F401  (fails loudly if the HIP extension is not built)
 
     kinds = ["rccl", "p2p"] if (env.world > 1 and a.comm == "auto") else [a.comm if env.world > 1 else "none"]
-    results = []
+    results, ext = [], {}
     for kind in kinds:
         ctx, label = make_context(env, kind)
         if ctx is None:
             continue
         r = measure(env, ctx, label)
-        ctx.close()
         if r is not None:
             results.append(r)
+            if not a.no_vector_free and a.m <= 10:
+                # EXTENSION, reported beside the headline, never as `value`: the same iteration with the
+                # two-loop carried out in Gram-coefficient space (4m+3 passes, 2 all-reduces)
+                rv = measure(env, ctx, label + "+vector_free", vector_free=True)
+                if rv is not None:
+                    tl = rv["roofline"].get("two_loop", {})
+                    ext[label] = {"iters_per_sec": round(rv["value"], 3), "two_loop_ms": tl.get("ms"),
+                                  "two_loop_passes": 4 * a.m + 3}
+        ctx.close()
 
     out = None
     if env.rank == 0:
@@ -306,7 +318,8 @@ def main():
                        "n": a.n, "m": a.m, "n_local_rank0": best["n_local"], "prefill_iters": best["prefill"],
                        "line_search_trials_per_step": best["trials"], "restarts": best["restarts"],
                        "allreduce": best["label"],
-                       "allreduce_measured_iters_per_sec": {r["label"]: round(r["value"], 3) for r in results}},
+                       "allreduce_measured_iters_per_sec": {r["label"]: round(r["value"], 3) for r in results},
+                       "extension_vector_free_two_loop": ext},
             "roofline": best["roofline"],
         }
         if env.world == 1 and not a.no_cpu_baseline:

@@ -192,6 +192,14 @@ int lbfgs_hip_history_damp(lbfgs_hip_history* h, int slot, const lbfgs_hip_vec* 
  * `g` is gx, or pg under OWL-QN (core.rs:96-97). */
 int lbfgs_hip_two_loop(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
                        int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int* new_end);
+/* EXTENSION: the same recursion in the coefficient space of the basis [s_j.., y_j.., g]
+ * ("vector-free" L-BFGS): one pass refreshes the three changed rows of the Gram matrix B^T B, a scalar
+ * kernel runs lbfgs.rs:582-601 on 2m+1 coefficients, one pass forms d.  4m+3 passes and 2 all-reduces
+ * instead of 8m+1 and 2m+1.  Mathematically identical; rounding differs (tests bound it by 1e-10 against
+ * the exact recursion).  Requires that it is called after EVERY history update (the Gram matrix is
+ * maintained incrementally) and m <= 10.  Same arguments and outputs as lbfgs_hip_two_loop. */
+int lbfgs_hip_two_loop_gram(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
+                            int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int* new_end);
 /* the same recursion as the reference's UNFUSED sequence of primitives (10*bound+2 passes);
  * d must already hold -g.  Kept as the on-device cross-check of the fused kernels. */
 int lbfgs_hip_two_loop_unfused(lbfgs_hip_history* h, lbfgs_hip_vec* d, uint64_t k, int end,

@@ -58,7 +58,8 @@ typedef struct lbfgs_param {
     double min_step, max_step;  /* 1e-20, 1e20 */
     uint64_t max_linesearch;    /* 20 */
     int32_t orthantwise;        /* 0 = None */
-    int32_t _pad;
+    int32_t vector_free;        /* EXTENSION, default 0: 1 = run the two-loop in Gram-coefficient space
+                                   (lbfgs_hip_two_loop_gram): 4m+3 passes, 2 all-reduces; same results to rounding */
     double owl_c;               /* 1.0 */
     uint64_t owl_start;         /* 0 */
     int64_t owl_end;            /* -1 = None */

@@ -416,6 +416,14 @@ class Lbfgs:
         self.param.m = m
         return self
 
+    def with_vector_free(self, on=True):
+        """EXTENSION: run the two-loop recursion in Gram-coefficient space -- 4m+3 vector passes
+        and 2 all-reduces per iteration instead of 8m+1 and 2m+1.  Same direction up to rounding (<= 1e-10
+        relative in the parity tests); the exact recursion stays the default."""
+        _assert(not on or self.param.m <= 10, "vector-free two-loop supports m <= 10")
+        self.param.vector_free = int(bool(on))
+        return self
+
     def build(self, x, evaluate, *, ctx=None, device=0):
         """lbfgs.rs:443-481"""
         return LbfgsState(self.param, x, evaluate, ctx=ctx, device=device)

@@ -664,8 +664,12 @@ int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
         }
     }
     int new_end = st->end;
-    TRYB(st, lbfgs_hip_two_loop(st->hist, st->d, st->grad_for_direction(), st->k - 1, st->end, S_UPD + 1, S_UPD + 2,
-                                S_DNORM2, &new_end));
+    if (st->vars.vector_free)
+        TRYB(st, lbfgs_hip_two_loop_gram(st->hist, st->d, st->grad_for_direction(), st->k - 1, st->end, S_UPD + 1,
+                                         S_UPD + 2, S_DNORM2, &new_end));
+    else
+        TRYB(st, lbfgs_hip_two_loop(st->hist, st->d, st->grad_for_direction(), st->k - 1, st->end, S_UPD + 1, S_UPD + 2,
+                                    S_DNORM2, &new_end));
     if (st->owlqn())  // :554, orthantwise.rs:140-161 (after dnorm, as in the reference)
         TRYB(st, lbfgs_hip_constrain_direction(st->d, st->pg, st->owl_start, st->owl_end, S_DNORM2C));
     TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_UPD, S_END_BLOCK - S_UPD, u));

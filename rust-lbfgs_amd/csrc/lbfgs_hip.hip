@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "ops.h"
+#include "gram.h"
 
 using namespace lh;
 
@@ -170,6 +171,7 @@ struct lbfgs_hip_ctx {
     double* pinned = nullptr;        // host staging, LBFGS_HIP_BOARD_SLOTS doubles
     int grid_default = 0;
     int grid_override = 0;
+    int gram_grid = 0;  // workgroups of the Gram rows kernel (0 = same as the others)
     size_t nt_threshold_bytes = (size_t)256 << 20;
     bool prof_on = false;
     ProfClass prof[LBFGS_HIP_K_CLASSES];
@@ -188,6 +190,10 @@ struct lbfgs_hip_history {
     std::vector<lbfgs_hip_vec*> s, y;
     double* ys;     // device, m
     double* alpha;  // device, m
+    // vector-free (Gram) two-loop: G = B^T B over the basis [s.., y.., g], refreshed rows, coefficients
+    double* gram = nullptr;        // (2m+1)^2
+    double* gram_rows = nullptr;   // 3*(2m+1), contiguous (one all-reduce message)
+    double* gram_delta = nullptr;  // 2m+1
 };
 
 namespace {
@@ -297,10 +303,15 @@ int allreduce(lbfgs_hip_ctx* ctx, double* const* ptrs, int count) {
 // ---- launch one operator ---------------------------------------------------------------------
 template <class Op>
 int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out) {
+    static_assert(Op::NRED <= MAX_RED, "the partials buffer holds MAX_RED sums per workgroup");
     RedCtl red{};
     red.partials = ctx->partials;
     red.ticket = ctx->ticket;
-    for (int k = 0; k < Op::NRED; ++k) red.out[k] = red_out[k];
+    if constexpr (Op::NRED <= RED_PTRS) {
+        for (int k = 0; k < Op::NRED; ++k) red.out[k] = red_out[k];
+    } else {
+        red.out_contig = red_out[0];  // caller guarantees red_out[k] == red_out[0] + k
+    }
     const uint64_t n = ctx->shard.n_local;
     constexpr int MAP = tuning<Op>::MAP, UNR = tuning<Op>::UNR;
     // streaming (`nt`) hints once a vector cannot stay in the 256 MiB Infinity Cache anyway
@@ -322,6 +333,63 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out)
 inline bool same_ctx(const lbfgs_hip_vec* a, const lbfgs_hip_vec* b) { return a && b && a->ctx == b->ctx; }
 
 }  // namespace
+
+// ---- vector-free (Gram) two-loop: scalar recursion on the coefficients --------------------------------
+constexpr int GRAM_MAX_M = 10;  // 3*(2m+1) sums must fit MAX_RED
+constexpr int GRAM_MAX_NB = 2 * GRAM_MAX_M + 1;
+struct GramArgs {
+    double* G;             // nb x nb, basis order [s_0..s_{m-1}, y_0..y_{m-1}, g]
+    const double* rows;    // 3 x nb in POSITION order of the rows kernel
+    double* delta;         // nb coefficients out (basis order)
+    double* alpha;         // history alpha[m] (kept for API parity, lbfgs.rs:587)
+    const double *gnum, *gden;
+    int m, bound;
+    int row_basis[3];                 // basis index of the three refreshed rows
+    int pos_to_basis[GRAM_MAX_NB];    // position p of the rows kernel -> basis index
+    int order[GRAM_MAX_M];            // slots, newest first (lbfgs.rs:583)
+};
+
+__global__ __launch_bounds__(64) void gram_coef_kernel(const GramArgs a) {
+    __shared__ double G[GRAM_MAX_NB * GRAM_MAX_NB];
+    __shared__ double delta[GRAM_MAX_NB];
+    __shared__ double alpha[GRAM_MAX_M];
+    const int nb = 2 * a.m + 1, lane = threadIdx.x;
+    // 1. refresh the three rows/columns that changed, then stage G in LDS
+    for (int i = lane; i < 3 * nb; i += 64) {
+        const int r = i / nb, p = i % nb;
+        const int bi = a.row_basis[r], bj = a.pos_to_basis[p];
+        const double v = a.rows[i];
+        a.G[bi * nb + bj] = v;
+        a.G[bj * nb + bi] = v;
+    }
+    __syncthreads();
+    for (int i = lane; i < nb * nb; i += 64) G[i] = a.G[i];
+    __syncthreads();
+    if (lane == 0) {
+        const int m = a.m;
+        for (int j = 0; j < nb; ++j) delta[j] = 0.0;
+        delta[2 * m] = -1.0;  // q = -g
+        for (int it = 0; it < a.bound; ++it) {  // lbfgs.rs:582-590
+            const int j = a.order[it];
+            double dot = 0.0;
+            for (int t = 0; t < nb; ++t) dot += G[j * nb + t] * delta[t];        // s_j . q
+            const double al = dot / G[j * nb + (m + j)];                          // / ys_j
+            alpha[j] = al;
+            delta[m + j] = delta[m + j] + (-al);                                  // q -= alpha*y_j
+        }
+        const double gamma = *a.gnum / *a.gden;                                   // lbfgs.rs:591
+        for (int t = 0; t < nb; ++t) delta[t] = delta[t] * gamma;
+        for (int it = a.bound - 1; it >= 0; --it) {  // lbfgs.rs:594-601
+            const int j = a.order[it];
+            double dot = 0.0;
+            for (int t = 0; t < nb; ++t) dot += G[(m + j) * nb + t] * delta[t];  // y_j . q
+            const double beta = dot / G[j * nb + (m + j)];
+            delta[j] = delta[j] + (alpha[j] - beta);                              // q += (alpha-beta)*s_j
+        }
+        for (int t = 0; t < nb; ++t) a.delta[t] = delta[t];
+        for (int it = 0; it < a.bound; ++it) a.alpha[a.order[it]] = alpha[a.order[it]];
+    }
+}
 
 // ---- helpers of the C-ABI functions below (templates need C++ linkage) -----------------------
 namespace {
@@ -366,6 +434,65 @@ int prof_drain(lbfgs_hip_ctx* ctx) {
         pc.pending.clear();
     }
     return LBFGS_HIP_OK;
+}
+}  // namespace
+
+namespace {
+template <int M>
+int two_loop_gram_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, int bound, int end, int e1,
+                       const double* gnum, const double* gden, double* dn) {
+    lbfgs_hip_ctx* ctx = h->ctx;
+    constexpr int NB = 2 * M + 1;
+    GramArgs ga{};
+    // rows kernel: position 0 = new s, 1 = new y, 2 = g, then every other basis vector in ascending order
+    GramRowsArgs<M> rows{};
+    rows.in[0] = h->s[end]->p; rows.in[1] = h->y[end]->p; rows.in[2] = g->p;
+    ga.pos_to_basis[0] = end; ga.pos_to_basis[1] = M + end; ga.pos_to_basis[2] = 2 * M;
+    int p = 3;
+    for (int b = 0; b < 2 * M; ++b) {
+        if (b == end || b == M + end) continue;
+        rows.in[p] = (b < M) ? h->s[b]->p : h->y[b - M]->p;
+        ga.pos_to_basis[p] = b;
+        ++p;
+    }
+    {
+        RedCtl red{};
+        red.partials = ctx->partials;
+        red.ticket = ctx->ticket;
+        red.out_contig = h->gram_rows;
+        const uint64_t n = ctx->shard.n_local;
+        const int grid = ctx->gram_grid > 0 ? ctx->gram_grid : grid_for(ctx);
+        ProfScope ps(ctx, LBFGS_HIP_K_TWOLOOP_STEP);
+        if (n * sizeof(double) >= ctx->nt_threshold_bytes)
+            hipLaunchKernelGGL((gram_rows_kernel<M, true, GRAM_ROWS_UNROLL>), dim3(grid), dim3(BLOCK), 0, ctx->stream, rows, n, red);
+        else
+            hipLaunchKernelGGL((gram_rows_kernel<M, false, GRAM_ROWS_UNROLL>), dim3(grid), dim3(BLOCK), 0, ctx->stream, rows, n, red);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    {
+        std::vector<double*> ptrs(3 * NB);
+        for (int i = 0; i < 3 * NB; ++i) ptrs[i] = h->gram_rows + i;
+        int rc = allreduce(ctx, ptrs.data(), 3 * NB);
+        if (rc != LBFGS_HIP_OK) return rc;
+    }
+    // scalar recursion on the coefficients
+    ga.G = h->gram; ga.rows = h->gram_rows; ga.delta = h->gram_delta; ga.alpha = h->alpha;
+    ga.gnum = gnum; ga.gden = gden; ga.m = M; ga.bound = bound;
+    ga.row_basis[0] = end; ga.row_basis[1] = M + end; ga.row_basis[2] = 2 * M;
+    for (int i = 0; i < bound; ++i) ga.order[i] = ((e1 - 1 - i) % M + M) % M;
+    {
+        ProfScope ps(ctx, LBFGS_HIP_K_TWOLOOP_EDGE);
+        hipLaunchKernelGGL(gram_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, ga);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    // d = sum_j delta_j b_j, ||d||^2, g.d
+    OpGramCombine<M> cmb{};
+    for (int b = 0; b < M; ++b) { cmb.in[b] = h->s[b]->p; cmb.in[M + b] = h->y[b]->p; }
+    cmb.in[2 * M] = g->p;
+    cmb.out[0] = d->p;
+    cmb.delta = h->gram_delta;
+    double* outs2[2] = {dn, dn + 1};
+    return launch(ctx, LBFGS_HIP_K_TWOLOOP_STEP, cmb, outs2);
 }
 }  // namespace
 
@@ -469,7 +596,9 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     // ~0.85 workgroups per CU: measured optimum of the windowed streaming map on MI355X (216 of 256 CUs);
     // more workgroups only add concurrent DRAM pages (tools/tune_stream.hip)
     ctx->grid_default = std::max(1, prop.multiProcessorCount * 27 / 32);
+    ctx->gram_grid = prop.multiProcessorCount;  // the 21-stream Gram rows pass peaks at one workgroup per CU
     if (const char* e = getenv("LBFGS_HIP_NT_THRESHOLD_MB")) ctx->nt_threshold_bytes = (size_t)atoll(e) << 20;
+    if (const char* e = getenv("LBFGS_HIP_GRAM_GRID")) ctx->gram_grid = std::min(MAX_GRID, std::max(0, atoi(e)));
     if (const char* e = getenv("LBFGS_HIP_GRID")) ctx->grid_override = std::min(MAX_GRID, std::max(0, atoi(e)));
     CTX_TRY(hipMalloc(&ctx->board, (LBFGS_HIP_BOARD_SLOTS + 2) * sizeof(double)));
     CTX_TRY(hipMemsetAsync(ctx->board, 0, (LBFGS_HIP_BOARD_SLOTS + 2) * sizeof(double), ctx->stream));
@@ -829,6 +958,7 @@ void lbfgs_hip_history_destroy(lbfgs_hip_history* h) {
         (void)hipStreamSynchronize(h->ctx->stream);
         (void)hipFree(h->ys);
     }
+    if (h->gram) (void)hipFree(h->gram);
     delete h;
 }
 
@@ -1010,6 +1140,38 @@ int lbfgs_hip_two_loop_unfused(lbfgs_hip_history* h, lbfgs_hip_vec* d, uint64_t 
         j = (j + 1) % m;
     }
     return LBFGS_HIP_OK;
+}
+
+// vector-free (Gram) variant of lbfgs_hip_two_loop: same arguments, same results up to rounding
+int lbfgs_hip_two_loop_gram(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
+                            int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int* new_end) {
+    if (!h || !d || !g || d->ctx != h->ctx || g->ctx != h->ctx || end < 0 || end >= h->m || !new_end)
+        return LBFGS_HIP_ERR_ARG;
+    if (!slot_ok(gamma_num_slot, 1) || !slot_ok(gamma_den_slot, 1) || !slot_ok(dnorm_slot, 2)) return LBFGS_HIP_ERR_ARG;
+    lbfgs_hip_ctx* ctx = h->ctx;
+    const int m = h->m;
+    if (m > GRAM_MAX_M) return fail(ctx, LBFGS_HIP_ERR_ARG, "vector-free two-loop supports m <= %d", GRAM_MAX_M);
+    if (!h->gram) {
+        const size_t nb = 2 * (size_t)m + 1, words = nb * nb + 3 * nb + nb;
+        HIP_TRY(ctx, hipMalloc(&h->gram, words * sizeof(double)));
+        HIP_TRY(ctx, hipMemsetAsync(h->gram, 0, words * sizeof(double), ctx->stream));
+        h->gram_rows = h->gram + nb * nb;
+        h->gram_delta = h->gram_rows + 3 * nb;
+    }
+    ProfScope whole(ctx, LBFGS_HIP_K_TWOLOOP_ALL);
+    const int e1 = (end + 1) % m;
+    const int bound = (int)((uint64_t)m < k ? (uint64_t)m : k);
+    *new_end = e1;
+    const double* gnum = ctx->board + gamma_num_slot;
+    const double* gden = ctx->board + gamma_den_slot;
+    double* dn = ctx->board + dnorm_slot;
+    switch (m) {
+#define LH_CASE(MM) case MM: return two_loop_gram_impl<MM>(h, d, g, bound, end, e1, gnum, gden, dn);
+        LH_CASE(1) LH_CASE(2) LH_CASE(3) LH_CASE(4) LH_CASE(5) LH_CASE(6)
+        LH_CASE(7) LH_CASE(8) LH_CASE(9) LH_CASE(10)
+#undef LH_CASE
+        default: return LBFGS_HIP_ERR_ARG;
+    }
 }
 
 // ==================================================================================== OWL-QN

@@ -34,15 +34,17 @@ constexpr int BLOCK = 256;          // 4 wave64 per workgroup
 constexpr int WAVES = BLOCK / 64;
 constexpr int UNROLL = 4;           // default: independent 16-B loads per stream per thread
 constexpr int DEFAULT_MAP = 2;      // default address map (see stream_kernel)
-constexpr int MAX_RED = 6;          // sums a kernel may produce
+constexpr int MAX_RED = 64;         // sums a kernel may produce (the Gram rows need 3*(2m+1))
 constexpr int MAX_GRID = 4096;      // upper bound on workgroups per launch
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+constexpr int RED_PTRS = 6;         // sums that may go to individually addressed slots
 struct RedCtl {
     double* partials;        // [MAX_RED][MAX_GRID] workgroup partial sums
     unsigned int* ticket;    // arrival counter, self-resetting
-    double* out[MAX_RED];    // where the last workgroup puts the totals
+    double* out[RED_PTRS];   // where the last workgroup puts the totals (NRED <= RED_PTRS) ...
+    double* out_contig;      // ... or one contiguous array of NRED doubles (NRED > RED_PTRS)
 };
 
 // ---- agent-scope accesses for the cross-workgroup hand-off -------------------------------
@@ -114,7 +116,10 @@ __device__ __forceinline__ void grid_reduce(double (&acc)[NRED], const RedCtl& r
     block_sum<NRED>(tot, lds);
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < NRED; ++k) *red.out[k] = tot[k];
+        for (int k = 0; k < NRED; ++k) {
+            if constexpr (NRED <= RED_PTRS) *red.out[k] = tot[k];
+            else red.out_contig[k] = tot[k];
+        }
         __hip_atomic_store(red.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -205,6 +210,7 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const Op op, const uint64
                                                         const RedCtl red) {
     constexpr int UNROLL = UNR;
     constexpr int NIN = Op::NIN, NOUT = Op::NOUT, NRED = Op::NRED;
+    static_assert(NRED <= MAX_RED, "partials buffer overflow");
     const typename Op::Coef cf = op.setup();
     double acc[NRED ? NRED : 1];
 #pragma unroll

@@ -263,6 +263,11 @@ int lbfgs_hip_two_loop(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
     return gdot(h->ctx, g->p->data(), d->p->data(), h->ctx->board + dn + 1);
 }
 
+int lbfgs_hip_two_loop_gram(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end, int gn,
+                            int gd, int dn, int* new_end) {
+    return lbfgs_hip_two_loop(h, d, g, k, end, gn, gd, dn, new_end);  // the test double has one recursion
+}
+
 int lbfgs_hip_owlqn_post_eval(const lbfgs_hip_vec* x, const lbfgs_hip_vec* g, lbfgs_hip_vec* pg, double cc,
                               uint64_t start, uint64_t end, int o) {
     lbfgs_hip_ctx* c = x->ctx;

@@ -395,3 +395,136 @@ def test_trajectory_matches_oracle_trace(case):
             assert np.max(np.abs(dgot - dref)) <= rt * max(row["dnorm_inf"], tr["g_floor"]), (case, row["niter"])
         if tr["converged_after"] is not None:
             assert st.is_converged() == tr["converged_after"]
+
+
+# ---------------------------------------------------------------------------------------------
+# EXTENSION: vector-free (Gram) two-loop -- same direction as the exact recursion and as the oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,m", [(4097, 7), (70001, 10), (513, 3), (100, 6), (262145, 9)])
+def test_two_loop_gram_vs_oracle_over_a_run(n, m):
+    """Feed the ORACLE's history, slot by slot as a run produces it (the Gram matrix is incremental), and
+    compare every direction with the oracle's at 1e-10."""
+    x = np.zeros(n)
+    st = O.lbfgs().with_m(m).with_epsilon(0.0).build(x, O.quadratic())
+    with R.Context(n) as ctx:
+        hist = H.History(ctx, m)
+        gv, d = DeviceVec(ctx), DeviceVec(ctx)
+        worst = 0.0
+        for it in range(3 * m + 4):
+            end_before = st.end
+            p = st.propagate()
+            if p["niter"] == 1:
+                continue
+            hist.s(end_before).upload(st.hist(end_before, "s"))
+            hist.y(end_before).upload(st.hist(end_before, "y"))
+            hist.set_scalars(ys=np.array([st.ys(j) for j in range(m)]))  # (only the exact recursion reads these)
+            ctx.set_scalars(7, [st.gamma, 1.0])
+            gv.upload(st.vec("gx"))
+            ne = hist.two_loop_gram(d, gv, st.k - 1, end_before, 7, 8, 12)
+            assert ne == st.end
+            dref = st.vec("d")
+            worst = max(worst, rel(d.to_numpy(), dref))
+            dn2, dg = ctx.scalars(12, 2)
+            assert abs(dn2 - O.vecdot(dref, dref)) <= 1e-9 * O.vecdot(dref, dref)
+            assert abs(dg - O.vecdot(st.vec("gx"), dref)) <= 1e-9 * abs(O.vecdot(st.vec("gx"), dref))
+        st.close()
+        hist.free(); gv.free(); d.free()
+    print("gram worst", n, m, worst)
+    assert worst <= RTOL
+
+
+@pytest.mark.parametrize("case", ["quadratic_m7", "rosen_m10", "logistic_owlqn"])
+def test_vector_free_runs_match_exact_runs(case):
+    """Whole runs with with_vector_free(True) against the exact recursion on the same device."""
+    cfg = {
+        "quadratic_m7": (lambda b: b.with_m(7).with_epsilon(0.0).with_max_iterations(40), objectives.Quadratic, np.zeros(4096)),
+        "rosen_m10": (lambda b: b.with_m(10).with_max_iterations(30), objectives.Rosenbrock, P.rosenbrock_x0(1000)),
+        "logistic_owlqn": (lambda b: b.with_orthantwise(0.5, 0, None).with_max_iterations(25), objectives.Logistic,
+                           np.zeros(4096)),
+    }[case]
+    rows = {}
+    for vf in (False, True):
+        x = cfg[2].copy()
+        out = []
+        cfg[0](R.lbfgs()).with_vector_free(vf).minimize(x, cfg[1](), lambda p: out.append((p.niter, p.neval, p.fx, p.gnorm,
+                                                                                         p.step)) and False)
+        rows[vf] = (out, x)
+    assert len(rows[False][0]) == len(rows[True][0])
+    for a, b in zip(rows[False][0], rows[True][0]):
+        assert a[:2] == b[:2]
+        for u, v in zip(a[2:], b[2:]):
+            assert abs(u - v) <= 1e-8 * max(abs(u), 1e-6), (case, a, b)
+    assert np.max(np.abs(rows[False][1] - rows[True][1])) <= 1e-8 * max(np.max(np.abs(rows[False][1])), 1e-12)
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases: empty, single element, more than 2^31 elements
+# ---------------------------------------------------------------------------------------------
+def test_empty_and_single_element_vectors():
+    """n = 0: every kernel is a no-op and every sum is 0 (the reference's loops over empty slices);
+    n = 1: the scalar tail path alone."""
+    with R.Context(0) as ctx:
+        x, y = DeviceVec(ctx), DeviceVec(ctx)
+        y.vecadd(x, 2.0); y.vecscale(3.0); y.vecncpy(x)
+        assert x.vecdot(y) == 0.0 and x.vec2norm() == 0.0
+        assert x.to_numpy().shape == (0,)
+        x.free(); y.free()
+    with R.Context(1) as ctx:
+        x, y = DeviceVec(ctx, [3.0]), DeviceVec(ctx, [-0.5])
+        y.vecadd(x, 2.0)
+        assert y.to_numpy().tolist() == [5.5] and x.vecdot(y) == 16.5 and x.vec2norm() == 3.0
+        x.free(); y.free()
+    # a 1-variable minimisation through the whole stack: f = (x-2)^2
+    x = np.array([10.0])
+
+    def ev(xx, g):
+        g[0] = 2.0 * (xx[0] - 2.0)
+        return (xx[0] - 2.0) ** 2
+
+    xo = x.copy()
+    ro = O.lbfgs().minimize(xo, ev)
+    rp = R.lbfgs().minimize(x, ev)
+    assert abs(x[0] - 2.0) <= 1e-6 and abs(x[0] - xo[0]) <= 1e-12 and rp.neval == ro["neval"]
+
+
+def test_more_than_2_pow_31_elements():
+    """64-bit indexing: 2^31 + 1027 elements (17 GB per vector); integer-valued data keeps every sum exact."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs 52 GB")
+    n = (1 << 31) + 1027
+    with R.Context(n) as ctx:
+        x, y, z = DeviceVec(ctx), DeviceVec(ctx), DeviceVec(ctx)
+        x.fill(1.0); y.fill(2.0)
+        assert x.vecdot(y) == 2.0 * n
+        z.vecdiff(y, x)            # 1
+        z.vecadd(y, 0.5)           # 2
+        H.norms_sq(z, y, 14)
+        assert ctx.scalars(14, 2).tolist() == [4.0 * n, 4.0 * n]
+        H.line_step(z, x, y, 3.0)  # 1 + 3*2 = 7
+        assert z.vecdot(x) == 7.0 * n
+        x.free(); y.free(); z.free()
+
+
+def test_lj38_damped_closure_matches_oracle():
+    """BASELINE config 5 at parity size: examples/lj.rs (LJ38, all-pairs) with with_damping(true), through the
+    drop-in host closure.  Powell damping is parity-unpinned by the reference's tests; the oracle follows the
+    source text (lbfgs.rs:664-689, incl. the dropped case 2)."""
+    rng = np.random.default_rng(7)
+    x0 = rng.random(38 * 3) * 3.2 + 48.4
+
+    def lj(x, g):
+        f, gg = O.eval_builtin(O.lj(), np.ascontiguousarray(x))
+        g[:] = gg
+        return f
+
+    rows_o, rows_p = [], []
+    xo, xp = x0.copy(), x0.copy()
+    cfg = lambda b: b.with_damping(True).with_max_iterations(40)
+    cfg(O.lbfgs()).minimize(xo, O.lj(), lambda p: rows_o.append((p["niter"], p["neval"], p["fx"], p["gnorm"], p["step"])) and False)
+    cfg(R.lbfgs()).minimize(xp, lj, lambda p: rows_p.append((p.niter, p.neval, p.fx, p.gnorm, p.step)) and False)
+    assert len(rows_o) == len(rows_p) >= 10
+    for a, b in zip(rows_o, rows_p):
+        assert a[:2] == b[:2]
+        for u, v in zip(a[2:], b[2:]):
+            assert abs(u - v) <= 1e-9 * max(abs(u), 1e-3), (a, b)
+    assert np.max(np.abs(xo - xp)) <= 1e-9 * np.max(np.abs(xo))

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../rust-lbfgs_amd/csrc/ops.h"
+#include "../rust-lbfgs_amd/csrc/gram.h"
 
 using namespace lh;
 
@@ -108,6 +109,44 @@ void sweep_lineeval(const Bufs& b, const std::vector<int>& grids, double* extra[
     }
 }
 
+template <int UNR, unsigned NTL, unsigned NTS, int MAP, int SPAN = 1>
+void sweep_combine(const Bufs& b, const std::vector<int>& grids, double** vecs) {
+    OpGramCombine<10> op{};
+    for (int j = 0; j < 21; ++j) op.in[j] = vecs[j];
+    op.out[0] = vecs[21];
+    op.delta = b.board + 20;
+    for (int g : grids) {
+        int occ = 0;
+        float ms = run<decltype(op), UNR, NTL, NTS, MAP, SPAN>(op, b, g, 7, &occ);
+        printf("comb21r1w_s%d map=%d unroll=%d ntl=%d nts=%d grid=%5d (%.2f/CU, occ=%d) : %8.3f ms  %7.1f GB/s\n", SPAN, MAP, UNR,
+               (int)(NTL & 15u), (int)(NTS & 15u), g, g / 256.0, occ, ms, 22.0 * 8 * b.n / ms / 1e6);
+    }
+}
+template <int UNR>
+void sweep_rows(const Bufs& b, const std::vector<int>& grids, double** vecs) {
+    GramRowsArgs<10> a{};
+    for (int j = 0; j < 21; ++j) a.in[j] = vecs[j];
+    RedCtl red{};
+    red.partials = b.partials; red.ticket = b.ticket; red.out_contig = b.board + 64;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int g : grids) {
+        std::vector<float> ts;
+        for (int r = 0; r < 8; ++r) {
+            CK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL((gram_rows_kernel<10, true, UNR>), dim3(g), dim3(BLOCK), 0, 0, a, b.n, red);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0) ts.push_back(ms);
+        }
+        std::sort(ts.begin(), ts.end());
+        float ms = ts[ts.size() / 2];
+        printf("rows21r_s1 map=1 unroll=%d ntl=15 nts=0 grid=%5d (%.2f/CU, occ=0) : %8.3f ms  %7.1f GB/s\n", UNR, g, g / 256.0, ms,
+               21.0 * 8 * b.n / ms / 1e6);
+    }
+}
+
 int main(int argc, char** argv) {
     Bufs b{};
     b.n = argc > 1 ? strtoull(argv[1], nullptr, 10) : 100000000ULL;
@@ -129,21 +168,21 @@ int main(int argc, char** argv) {
     bd[0] = 1e-12;  // tiny coefficient so q stays bounded across repetitions
     CK(hipMemcpy(b.board, bd, sizeof(bd), hipMemcpyHostToDevice));
 
-    double* extra[4];
-    for (int i = 0; i < 3; ++i) { CK(hipMalloc(&extra[i], bytes)); CK(hipMemcpy(extra[i], h.data(), bytes, hipMemcpyHostToDevice)); }
-    std::vector<int> grids = {176, 192, 208, 216, 224, 232, 240, 256, 512, 1024, 2048};
+    // 22 vectors for the Gram kernels
+    double* vecs[22];
+    CK(hipMalloc(&b.board, 256 * sizeof(double)));
+    { double bd2[256]; for (int i = 0; i < 256; ++i) bd2[i] = 1e-3; CK(hipMemcpy(b.board, bd2, sizeof(bd2), hipMemcpyHostToDevice)); }
+    for (int i = 0; i < 22; ++i) { CK(hipMalloc(&vecs[i], bytes)); CK(hipMemcpy(vecs[i], h.data(), bytes, hipMemcpyHostToDevice)); }
+    std::vector<int> grids = {128, 160, 192, 216, 240, 256, 432, 512, 864};
     if (argc > 2) { grids.clear(); for (int i = 2; i < argc; ++i) grids.push_back(atoi(argv[i])); }
     constexpr unsigned ALL = ~0u;
-    sweep_step<2, ALL, ALL, 1, 1>(b, grids);
-    sweep_step<4, ALL, ALL, 2, 1>(b, grids);
-    sweep_step<2, 6u, 0u, 1, 1>(b, grids);   // q cached, u and v streamed
-    sweep_step<4, 6u, 0u, 2, 1>(b, grids);
-    sweep_step<2, 0u, 0u, 1, 1>(b, grids);
-    sweep_hist<2, ALL, ALL, 1, 1>(b, grids, extra);
-    sweep_hist<4, ALL, ALL, 2, 1>(b, grids, extra);
-    sweep_lineeval<2, ALL, ALL, 1, 1>(b, grids, extra);
-    sweep_lineeval<4, ALL, ALL, 2, 1>(b, grids, extra);
-    sweep_dot<2, ALL, 1>(b, grids);
-    sweep_dot<4, ALL, 2>(b, grids);
+    sweep_rows<1>(b, grids, vecs);
+    sweep_rows<2>(b, grids, vecs);
+    sweep_rows<3>(b, grids, vecs);
+    sweep_combine<1, ALL, ALL, 1, 1>(b, grids, vecs);
+    sweep_combine<1, ALL, ALL, 2, 2>(b, grids, vecs);
+    sweep_combine<1, ALL, ALL, 2, 4>(b, grids, vecs);
+    sweep_combine<2, ALL, ALL, 1, 1>(b, grids, vecs);
+    sweep_combine<2, ALL, ALL, 2, 1>(b, grids, vecs);
     return 0;
 }
