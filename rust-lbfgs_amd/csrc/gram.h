@@ -98,12 +98,19 @@ __global__ __launch_bounds__(BLOCK) void gram_rows_kernel(const GramRowsArgs<M> 
     __syncthreads();
     if (s_last == 0u) return;
     // last workgroup: wave w finishes sums w, w+4, ... in a fixed order (lane-strided partials, then the wave tree)
+    __shared__ double s_vals[NK];
     for (int k = wave; k < NK; k += WAVES) {
         double s = 0.0;
         for (unsigned int b = lane; b < G; b += 64) s += load_agent(red.partials + (size_t)k * MAX_GRID + b);
         s = wave_sum(s);
-        if (lane == 0) red.out_contig[k] = s;
+        if (lane == 0) s_vals[k] = s;
     }
+    __syncthreads();
+    if (red.p2p.world > 1) {  // close the NK sums across ranks before the kernel ends
+        __shared__ unsigned int s_bits[P2P_MAX_WORLD][MAX_RED][2];
+        p2p_exchange(red.p2p, s_vals, NK, s_bits);
+    }
+    for (int k = threadIdx.x; k < NK; k += BLOCK) red.out_contig[k] = s_vals[k];
     if (threadIdx.x == 0) __hip_atomic_store(red.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -74,70 +74,21 @@ std::string g_create_error;  // last error of a failed ctx_create (no ctx to hol
 }  // namespace
 
 // ------------------------------------------------------------------------------------ P2P all-reduce
-// xGMI is point-to-point and fully connected, and the messages here are 8-48 bytes: instead of a collective
-// launch per reduction, ONE wave stores this rank's partials directly into every peer's mailbox and sums what
-// the peers stored into its own.  A double travels as two 8-byte granules {tag = epoch, 32 data bits} (the
-// LL-protocol idea: an 8-byte store is atomic, so data and flag arrive together, no fence between them).
-// Mailboxes are uncached device memory shared by IPC; all accesses are system-scope atomics.  The sum runs in
-// rank order on every rank, so all ranks hold bitwise identical results.  Every spin is bounded.
-constexpr int P2P_MAX_WORLD = 8;
-constexpr int P2P_RING = 4;  // a rank can be at most one reduction ahead of a peer; 4 slots is ample
-constexpr size_t P2P_MBOX_WORDS = (size_t)P2P_RING * P2P_MAX_WORLD * MAX_RED * 2;
-
+// Stand-alone form of lh::p2p_exchange (stream.h) for sums the HOST produced (lbfgs_hip_scalars_allreduce);
+// sums produced by a kernel are exchanged by that kernel's last workgroup and never come here.
 struct P2PArgs {
-    unsigned long long* mbox[P2P_MAX_WORLD];
+    P2PCtl ctl;
     double* val[MAX_RED];
-    int world, rank, count;
-    unsigned int epoch;
-    unsigned int* err;
-    unsigned long long timeout_ticks;  // wall_clock64 ticks (100 MHz)
+    int count;
 };
 
-__device__ __forceinline__ size_t p2p_word(unsigned epoch, int src_rank, int k, int half) {
-    return (((size_t)(epoch % P2P_RING) * P2P_MAX_WORLD + src_rank) * MAX_RED + k) * 2 + half;
-}
-
 __global__ __launch_bounds__(64) void p2p_allreduce_kernel(const P2PArgs a) {
+    __shared__ double vals[MAX_RED];
     __shared__ unsigned int bits[P2P_MAX_WORLD][MAX_RED][2];
-    const int lane = threadIdx.x;
-    const int per_rank = a.count * 2;
-    const int total = a.world * per_rank;
-    // 1. publish: my partial k, half h -> peer p's mailbox [epoch][my rank][k][h]
-    for (int i = lane; i < total; i += 64) {
-        const int p = i / per_rank, k = (i % per_rank) >> 1, h = i & 1;
-        const unsigned long long b = (unsigned long long)__double_as_longlong(*a.val[k]);
-        const unsigned int data = h ? (unsigned int)(b >> 32) : (unsigned int)b;
-        const unsigned long long granule = ((unsigned long long)a.epoch << 32) | data;
-        __hip_atomic_store(a.mbox[p] + p2p_word(a.epoch, a.rank, k, h), granule, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    // 2. collect: what rank r stored for me, until its tag is this epoch (bounded)
-    const long long t0 = wall_clock64();
-    for (int i = lane; i < total; i += 64) {
-        const int r = i / per_rank, k = (i % per_rank) >> 1, h = i & 1;
-        const unsigned long long* src = a.mbox[a.rank] + p2p_word(a.epoch, r, k, h);
-        unsigned long long g;
-        for (;;) {
-            g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if ((unsigned int)(g >> 32) == a.epoch) break;
-            if ((unsigned long long)(wall_clock64() - t0) > a.timeout_ticks) {
-                atomicExch(a.err, 1u);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        bits[r][k][h] = (unsigned int)g;
-    }
+    if ((int)threadIdx.x < a.count) vals[threadIdx.x] = *a.val[threadIdx.x];
     __syncthreads();
-    // 3. fixed-order sum over ranks
-    if (lane < a.count) {
-        double s = 0.0;
-        for (int r = 0; r < a.world; ++r) {
-            const unsigned long long b = ((unsigned long long)bits[r][lane][1] << 32) | bits[r][lane][0];
-            s += __longlong_as_double((long long)b);
-        }
-        *a.val[lane] = s;
-    }
+    p2p_exchange(a.ctl, vals, a.count, bits);
+    if ((int)threadIdx.x < a.count) *a.val[threadIdx.x] = vals[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------ objects
@@ -249,6 +200,18 @@ struct ProfScope {
     }
 };
 
+// the P2P control block of the NEXT reduction (epochs advance identically on every rank)
+P2PCtl next_p2p(lbfgs_hip_ctx* ctx) {
+    P2PCtl c{};
+    for (int r = 0; r < ctx->shard.world && r < P2P_MAX_WORLD; ++r) c.mbox[r] = ctx->p2p_mbox[r];
+    c.world = ctx->shard.world;
+    c.rank = ctx->shard.rank;
+    c.epoch = ++ctx->p2p_epoch;
+    c.err = ctx->p2p_err;
+    c.timeout_ticks = ctx->p2p_timeout_ticks;
+    return c;
+}
+
 // ---- closing a reduction across ranks --------------------------------------------------------
 // `ptrs` are device addresses (board or history scalars) just written by the last workgroup.
 int allreduce(lbfgs_hip_ctx* ctx, double* const* ptrs, int count) {
@@ -275,14 +238,9 @@ int allreduce(lbfgs_hip_ctx* ctx, double* const* ptrs, int count) {
     }
     if (ctx->comm_kind == LBFGS_HIP_COMM_P2P) {
         P2PArgs a{};
-        for (int r = 0; r < ctx->shard.world; ++r) a.mbox[r] = ctx->p2p_mbox[r];
+        a.ctl = next_p2p(ctx);
         for (int i = 0; i < count; ++i) a.val[i] = ptrs[i];
-        a.world = ctx->shard.world;
-        a.rank = ctx->shard.rank;
         a.count = count;
-        a.epoch = ++ctx->p2p_epoch;
-        a.err = ctx->p2p_err;
-        a.timeout_ticks = ctx->p2p_timeout_ticks;
         hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(1), dim3(64), 0, ctx->stream, a);
         HIP_TRY(ctx, hipGetLastError());
         return LBFGS_HIP_OK;
@@ -313,6 +271,8 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out)
         red.out_contig = red_out[0];  // caller guarantees red_out[k] == red_out[0] + k
     }
     const uint64_t n = ctx->shard.n_local;
+    const bool in_kernel_exchange = Op::NRED > 0 && ctx->comm_kind == LBFGS_HIP_COMM_P2P;
+    if (in_kernel_exchange) red.p2p = next_p2p(ctx);  // the last workgroup closes the reduction itself
     constexpr int MAP = tuning<Op>::MAP, UNR = tuning<Op>::UNR;
     // streaming (`nt`) hints once a vector cannot stay in the 256 MiB Infinity Cache anyway
     const bool streaming = n * sizeof(double) >= ctx->nt_threshold_bytes;
@@ -326,7 +286,7 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out)
                                op, n, ctx->shard.offset, red);
     }
     HIP_TRY(ctx, hipGetLastError());
-    if (Op::NRED > 0) return allreduce(ctx, red_out, Op::NRED);
+    if (Op::NRED > 0 && !in_kernel_exchange) return allreduce(ctx, red_out, Op::NRED);
     return LBFGS_HIP_OK;
 }
 
@@ -460,6 +420,7 @@ int two_loop_gram_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
         red.partials = ctx->partials;
         red.ticket = ctx->ticket;
         red.out_contig = h->gram_rows;
+        if (ctx->comm_kind == LBFGS_HIP_COMM_P2P) red.p2p = next_p2p(ctx);
         const uint64_t n = ctx->shard.n_local;
         const int grid = ctx->gram_grid > 0 ? ctx->gram_grid : grid_for(ctx);
         ProfScope ps(ctx, LBFGS_HIP_K_TWOLOOP_STEP);
@@ -469,7 +430,7 @@ int two_loop_gram_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
             hipLaunchKernelGGL((gram_rows_kernel<M, false, GRAM_ROWS_UNROLL>), dim3(grid), dim3(BLOCK), 0, ctx->stream, rows, n, red);
     }
     HIP_TRY(ctx, hipGetLastError());
-    {
+    if (ctx->comm_kind != LBFGS_HIP_COMM_P2P) {
         std::vector<double*> ptrs(3 * NB);
         for (int i = 0; i < 3 * NB; ++i) ptrs[i] = h->gram_rows + i;
         int rc = allreduce(ctx, ptrs.data(), 3 * NB);

@@ -40,12 +40,80 @@ constexpr int MAX_GRID = 4096;      // upper bound on workgroups per launch
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int RED_PTRS = 6;         // sums that may go to individually addressed slots
+
+// ---- direct xGMI exchange of reduction results (communicator kind "p2p") ---------------------------
+// xGMI is point-to-point and fully connected and the messages are 8-48 bytes, so instead of a collective
+// launch per reduction the LAST workgroup of the producing kernel stores this rank's sums straight into
+// every peer's mailbox and adds up what the peers stored into its own.  A double travels as two 8-byte
+// granules {tag = epoch, 32 data bits} (an 8-byte store is atomic, so data and flag arrive together: the
+// LL-protocol idea).  Mailboxes are uncached device memory mapped through IPC handles; all accesses are
+// system-scope atomics.  The sum runs in rank order on every rank => bitwise identical results everywhere.
+// Every spin is bounded by a wall-clock timeout that raises *err.
+constexpr int P2P_MAX_WORLD = 8;
+constexpr int P2P_RING = 4;  // a rank can be at most one reduction ahead of a peer; 4 slots is ample
+constexpr size_t P2P_MBOX_WORDS = (size_t)P2P_RING * P2P_MAX_WORLD * MAX_RED * 2;
+struct P2PCtl {
+    unsigned long long* mbox[P2P_MAX_WORLD];  // [rank] -> that rank's mailbox (own entry = local)
+    int world, rank;                          // world <= 1: no exchange
+    unsigned int epoch;                       // reduction sequence number, identical on all ranks, never 0
+    unsigned int* err;
+    unsigned long long timeout_ticks;         // wall_clock64 ticks (100 MHz)
+};
+
 struct RedCtl {
     double* partials;        // [MAX_RED][MAX_GRID] workgroup partial sums
     unsigned int* ticket;    // arrival counter, self-resetting
     double* out[RED_PTRS];   // where the last workgroup puts the totals (NRED <= RED_PTRS) ...
     double* out_contig;      // ... or one contiguous array of NRED doubles (NRED > RED_PTRS)
+    P2PCtl p2p;
 };
+
+__device__ __forceinline__ size_t p2p_word(unsigned epoch, int src_rank, int k, int half) {
+    return (((size_t)(epoch % P2P_RING) * P2P_MAX_WORLD + src_rank) * MAX_RED + k) * 2 + half;
+}
+
+// Called by ALL threads of one workgroup (>= 64 threads).  vals[0..count) in LDS: in = this rank's sums,
+// out = the global sums.  bits: LDS scratch [P2P_MAX_WORLD][MAX_RED][2].
+__device__ __forceinline__ void p2p_exchange(const P2PCtl& c, double* vals, int count,
+                                             unsigned int (*bits)[MAX_RED][2]) {
+    const int per_rank = count * 2, total = c.world * per_rank;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        for (int i = lane; i < total; i += 64) {  // publish to every peer (own mailbox included)
+            const int p = i / per_rank, k = (i % per_rank) >> 1, h = i & 1;
+            const unsigned long long b = (unsigned long long)__double_as_longlong(vals[k]);
+            const unsigned int data = h ? (unsigned int)(b >> 32) : (unsigned int)b;
+            __hip_atomic_store(c.mbox[p] + p2p_word(c.epoch, c.rank, k, h), ((unsigned long long)c.epoch << 32) | data,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        const long long t0 = wall_clock64();
+        for (int i = lane; i < total; i += 64) {  // collect what rank r stored for me
+            const int r = i / per_rank, k = (i % per_rank) >> 1, h = i & 1;
+            const unsigned long long* src = c.mbox[c.rank] + p2p_word(c.epoch, r, k, h);
+            unsigned long long g;
+            for (;;) {
+                g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((unsigned int)(g >> 32) == c.epoch) break;
+                if ((unsigned long long)(wall_clock64() - t0) > c.timeout_ticks) {
+                    atomicExch(c.err, 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            bits[r][k][h] = (unsigned int)g;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < count) {  // fixed-order sum over ranks
+        double sum = 0.0;
+        for (int r = 0; r < c.world; ++r) {
+            const unsigned long long b = ((unsigned long long)bits[r][threadIdx.x][1] << 32) | bits[r][threadIdx.x][0];
+            sum += __longlong_as_double((long long)b);
+        }
+        vals[threadIdx.x] = sum;
+    }
+    __syncthreads();
+}
 
 // ---- agent-scope accesses for the cross-workgroup hand-off -------------------------------
 // Partials are stored write-through (sc1) and read back with sc1 loads, the ticket is an
@@ -114,6 +182,20 @@ __device__ __forceinline__ void grid_reduce(double (&acc)[NRED], const RedCtl& r
     }
     __syncthreads();  // lds reuse
     block_sum<NRED>(tot, lds);
+    if (red.p2p.world > 1) {  // close the reduction across ranks before the kernel ends (uniform branch)
+        __shared__ double s_vals[NRED];
+        __shared__ unsigned int s_bits[P2P_MAX_WORLD][MAX_RED][2];
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < NRED; ++k) s_vals[k] = tot[k];
+        }
+        __syncthreads();
+        p2p_exchange(red.p2p, s_vals, NRED, s_bits);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < NRED; ++k) tot[k] = s_vals[k];
+        }
+    }
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < NRED; ++k) {
