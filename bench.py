@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--hist", dest="m", type=int, default=10, help="m, the number of L-BFGS corrections")
     ap.add_argument("--no-prof", action="store_true", help="do not time kernels with HIP events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=4_000_000, help="sample size of the CPU baseline")
+    ap.add_argument("--cpu-n", type=int, default=20_000_000, help="sample size of the CPU baseline (~10 s on one core)")
     ap.add_argument("--grid", type=int, default=0, help="workgroups per launch (0 = library default)")
     ap.add_argument("--comm", default="auto", choices=["auto", "rccl", "p2p", "callback"],
                     help="N>1: how scalars are all-reduced (auto = measure RCCL, then p2p if its self-test passes)")

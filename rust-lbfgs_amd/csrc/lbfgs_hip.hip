@@ -123,7 +123,7 @@ struct lbfgs_hip_ctx {
     int grid_default = 0;
     int grid_override = 0;
     int gram_grid = 0;  // workgroups of the Gram rows kernel (0 = same as the others)
-    size_t nt_threshold_bytes = (size_t)256 << 20;
+    size_t nt_threshold_bytes = (size_t)128 << 20;  // measured crossover: 95 MiB vectors prefer plain, 190 MiB prefer nt
     bool prof_on = false;
     ProfClass prof[LBFGS_HIP_K_CLASSES];
     std::vector<ProfPair> prof_pool;
@@ -274,7 +274,7 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out)
     const bool in_kernel_exchange = Op::NRED > 0 && ctx->comm_kind == LBFGS_HIP_COMM_P2P;
     if (in_kernel_exchange) red.p2p = next_p2p(ctx);  // the last workgroup closes the reduction itself
     constexpr int MAP = tuning<Op>::MAP, UNR = tuning<Op>::UNR;
-    // streaming (`nt`) hints once a vector cannot stay in the 256 MiB Infinity Cache anyway
+    // streaming (`nt`) hints once the running vector cannot stay in the 256 MiB Infinity Cache next to the others
     const bool streaming = n * sizeof(double) >= ctx->nt_threshold_bytes;
     {
         ProfScope ps(ctx, kclass);

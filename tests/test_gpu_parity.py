@@ -542,3 +542,43 @@ def test_lj38_damped_closure_matches_oracle():
         assert a[:2] == b[:2]
         for u, v in zip(a[2:], b[2:]):
             assert abs(u - v) <= max(1e-10, 20.0 * floor) * max(abs(u), 1e-3), (a, b, floor)
+
+
+def test_owlqn_ops_special_values_bitwise():
+    """signum(NaN) = signum(+-0) = 0 (orthantwise.rs:174-180), f64::signum of non-zero x, the x == 0
+    pseudo-gradient branches (orthantwise.rs:94-106) and the projections, on NaN / +-0 / +-inf / denormals:
+    every output must carry the oracle's bits (NaNs compared as NaNs)."""
+    specials = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 5e-324, -5e-324, 1.0, -1.0, 1e308, -1e308, 2.5])
+    n = len(specials) ** 2
+    xs = np.repeat(specials, len(specials))
+    gs = np.tile(specials, len(specials))
+    c, start, end = 0.75, 3, n - 5
+
+    def same(a, b):
+        a, b = np.asarray(a), np.asarray(b)
+        nan = np.isnan(a) & np.isnan(b)
+        return bool(np.all(nan | (a.view(np.uint64) == b.view(np.uint64))))
+
+    with R.Context(n) as ctx:
+        x, g, pg, wp, d = (DeviceVec(ctx) for _ in range(5))
+        x.upload(xs); g.upload(gs); d.upload(gs[::-1].copy())
+        H.owlqn_post_eval(x, g, pg, c, start, end, 2)
+        pgo = np.zeros(n)
+        O.lib().oracle_pseudo_gradient(c, start, end, O._dp(pgo), O._dp(xs), O._dp(gs), n)
+        assert same(pg.to_numpy(), pgo)
+        H.orthant_select(wp, x, pg)
+        wpo = np.zeros(n)
+        O.lib().oracle_orthant_select(O._dp(wpo), O._dp(xs), O._dp(pgo), n)
+        assert same(wp.to_numpy(), wpo)
+        # line step with projection: x' = xp + t*d projected on wp
+        xt = DeviceVec(ctx)
+        H.line_step(xt, x, d, 0.5, wp, start, end)
+        xo = xs.copy(); O.vecadd(xo, gs[::-1].copy(), 0.5)
+        O.lib().oracle_project(O._dp(xo), O._dp(wpo), start, end, 0)
+        assert same(xt.to_numpy(), xo)
+        H.constrain_direction(d, pg, start, end, 13)
+        do = gs[::-1].copy()
+        O.lib().oracle_project(O._dp(do), O._dp(pgo), start, end, 1)
+        assert same(d.to_numpy(), do)
+        for v in (x, g, pg, wp, d, xt):
+            v.free()
