@@ -115,11 +115,33 @@ const char* lbfgs_state_ls_error(const lbfgs_state* st);
 /* LineSearch::find on the state's Problem (line.rs:193-223) */
 int lbfgs_line_search(lbfgs_state* st, double* step, uint64_t* ncall);
 
+/* ---- Problem (core.rs:10-218) used stand-alone, as the reference's public API allows (line.rs:8-32) ----
+ * lbfgs_problem_new = Problem::new: allocates the vectors, uploads x, evaluates NOTHING; the state has no
+ * L-BFGS history (propagate is refused).  `param` supplies the Orthantwise and LineSearch settings. */
+int lbfgs_problem_new(lbfgs_state** out, lbfgs_hip_ctx* ctx, const lbfgs_param* param, const double* x0,
+                      const lbfgs_evaluator* eval);
+int lbfgs_problem_evaluate(lbfgs_state* st);                        /* core.rs:119-132 */
+int lbfgs_problem_update_search_direction(lbfgs_state* st);         /* core.rs:95-101  */
+int lbfgs_problem_dginit(lbfgs_state* st, double* out);             /* core.rs:78-92   */
+int lbfgs_problem_dg_unchecked(lbfgs_state* st, double* out);       /* core.rs:114-116 */
+int lbfgs_problem_save_state(lbfgs_state* st);                      /* core.rs:207-210 */
+int lbfgs_problem_revert(lbfgs_state* st);                          /* core.rs:201-204 */
+int lbfgs_problem_take_line_step(lbfgs_state* st, double step);     /* core.rs:155-164 */
+int lbfgs_problem_update_orthant_new_point(lbfgs_state* st);        /* core.rs:167-180 */
+int lbfgs_problem_constrain_search_direction(lbfgs_state* st);      /* core.rs:213-217 */
+int lbfgs_problem_norms(lbfgs_state* st, double* xnorm, double* gnorm); /* core.rs:183-194 */
+int lbfgs_problem_status(lbfgs_state* st, double* fx, uint64_t* neval, int* evaluated, int* orthantwise);
+/* LineSearch is a value independent of the Problem in the reference (`ls.find(&mut prb, &mut step)`, line.rs:193):
+ * copy the LineSearch fields of `ls` (algorithm, ftol, gtol, xtol, min/max_step, max_linesearch, gradient_only)
+ * into the state before lbfgs_line_search. */
+int lbfgs_problem_set_linesearch(lbfgs_state* st, const lbfgs_param* ls);
+
 /* vectors of the Problem / history, for Progress.x / Progress.gx and for parity tests */
 enum { LBFGS_VEC_X = 0, LBFGS_VEC_GX, LBFGS_VEC_XP, LBFGS_VEC_GP, LBFGS_VEC_PG, LBFGS_VEC_WP, LBFGS_VEC_D,
        LBFGS_VEC_S0 = 100, LBFGS_VEC_Y0 = 200 };
 int lbfgs_state_download(lbfgs_state* st, int which, double* host);
 void* lbfgs_state_devptr(lbfgs_state* st, int which);
+lbfgs_hip_vec* lbfgs_state_vec(lbfgs_state* st, int which); /* borrowed handle (e.g. Problem::search_direction) */
 int lbfgs_state_info(lbfgs_state* st, uint64_t* k, uint64_t* end, double* step, double* gamma);
 lbfgs_hip_history* lbfgs_state_history(lbfgs_state* st);
 

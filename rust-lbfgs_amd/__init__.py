@@ -19,7 +19,7 @@ def build(force=False):
 
 
 def __getattr__(name):  # lazy submodules (dist imports torch)
-    if name in ("math", "objectives", "dist", "hotpath"):
+    if name in ("math", "objectives", "dist", "hotpath", "problem"):
         import importlib
 
         return importlib.import_module(f"{__name__}.{name}")

@@ -106,7 +106,11 @@ lbfgs_hip_prof_enable lbfgs_hip_prof_reset lbfgs_hip_prof_read
 SOLVER_SYMBOLS = """
 lbfgs_param_default lbfgs_build lbfgs_is_converged lbfgs_propagate lbfgs_get_report lbfgs_state_free
 lbfgs_state_error lbfgs_state_ls_error lbfgs_line_search lbfgs_state_download lbfgs_state_devptr lbfgs_state_info
-lbfgs_state_history lbfgs_minimize
+lbfgs_state_history lbfgs_state_vec lbfgs_minimize
+lbfgs_problem_new lbfgs_problem_evaluate lbfgs_problem_update_search_direction lbfgs_problem_dginit
+lbfgs_problem_dg_unchecked lbfgs_problem_save_state lbfgs_problem_revert lbfgs_problem_take_line_step
+lbfgs_problem_update_orthant_new_point lbfgs_problem_constrain_search_direction lbfgs_problem_norms
+lbfgs_problem_status lbfgs_problem_set_linesearch
 """.split()
 
 
@@ -180,6 +184,20 @@ def declare(L):
         "lbfgs_state_devptr": (vp, [vp, i]),
         "lbfgs_state_info": (i, [vp, C.POINTER(u64), C.POINTER(u64), dp, dp]),
         "lbfgs_state_history": (vp, [vp]),
+        "lbfgs_state_vec": (vp, [vp, i]),
+        "lbfgs_problem_new": (i, [C.POINTER(vp), vp, C.POINTER(Param), dp, C.POINTER(Evaluator)]),
+        "lbfgs_problem_evaluate": (i, [vp]),
+        "lbfgs_problem_update_search_direction": (i, [vp]),
+        "lbfgs_problem_dginit": (i, [vp, dp]),
+        "lbfgs_problem_dg_unchecked": (i, [vp, dp]),
+        "lbfgs_problem_save_state": (i, [vp]),
+        "lbfgs_problem_revert": (i, [vp]),
+        "lbfgs_problem_take_line_step": (i, [vp, dbl]),
+        "lbfgs_problem_update_orthant_new_point": (i, [vp]),
+        "lbfgs_problem_constrain_search_direction": (i, [vp]),
+        "lbfgs_problem_norms": (i, [vp, dp, dp]),
+        "lbfgs_problem_status": (i, [vp, dp, C.POINTER(u64), C.POINTER(i), C.POINTER(i)]),
+        "lbfgs_problem_set_linesearch": (i, [vp, C.POINTER(Param)]),
         "lbfgs_minimize": (i, [vp, C.POINTER(Param), dp, C.POINTER(Evaluator), PROGRESS_CB, vp, C.POINTER(CReport),
                                C.c_char_p, C.c_size_t]),
     }

@@ -173,6 +173,7 @@ struct lbfgs_state {
     bool owl_range_known = false;
     double xnorm2 = 0.0, gnorm2 = 0.0;  // squared norms at the current point
     bool norms_valid = false;
+    bool evaluated = false;              // core.rs:48
     std::vector<double> host_x, host_g;  // staging for the host closure
     // LbfgsState (lbfgs.rs:425-439)
     lbfgs_hip_history* hist = nullptr;
@@ -280,6 +281,7 @@ int evaluate_here(lbfgs_state* st, bool want_dg, double* dg_out) {
     }
     if (dg_out) *dg_out = b[S_DG];
     st->neval += 1;
+    st->evaluated = true;
     return LBFGS_OK;
 }
 
@@ -540,6 +542,8 @@ void lbfgs_param_default(lbfgs_param* p) {  // lbfgs.rs:161-176, line.rs:151-162
     p->owl_end = -1;
 }
 
+static std::string g_build_error;
+
 void lbfgs_state_free(lbfgs_state* st) {
     if (!st) return;
     lbfgs_hip_history_destroy(st->hist);
@@ -548,11 +552,10 @@ void lbfgs_state_free(lbfgs_state* st) {
     delete st;
 }
 
-static std::string g_build_error;
-
-int lbfgs_build(lbfgs_state** out, lbfgs_hip_ctx* ctx, const lbfgs_param* param, const double* x0,
-                const lbfgs_evaluator* eval) {
-    if (!out || !ctx || !param || !eval || param->m < 1) return LBFGS_ERR_PARAM;
+// Problem::new (core.rs:59-75): zeroed vectors (pg/wp only under OWL-QN), x uploaded, nothing evaluated.
+static int problem_new(lbfgs_state** out, lbfgs_hip_ctx* ctx, const lbfgs_param* param, const double* x0,
+                       const lbfgs_evaluator* eval, bool with_history) {
+    if (!out || !ctx || !param || !eval || (with_history && param->m < 1)) return LBFGS_ERR_PARAM;
     *out = nullptr;
     lbfgs_state* st = new (std::nothrow) lbfgs_state();
     if (!st) return LBFGS_HIP_ERR_NOMEM;
@@ -566,7 +569,6 @@ int lbfgs_build(lbfgs_state** out, lbfgs_hip_ctx* ctx, const lbfgs_param* param,
     };
     int rc = backend(st, lbfgs_hip_get_shard(ctx, &st->shard));
     if (rc != LBFGS_OK) return bail_out(rc);
-    // Problem::new (core.rs:59-75): zeroed vectors.  pg/wp only exist under OWL-QN.
     lbfgs_hip_vec** need[] = {&st->x, &st->gx, &st->xp, &st->gp, &st->d};
     for (auto** v : need)
         if ((rc = backend(st, lbfgs_hip_vec_alloc(ctx, v))) != LBFGS_OK) return bail_out(rc);
@@ -575,9 +577,24 @@ int lbfgs_build(lbfgs_state** out, lbfgs_hip_ctx* ctx, const lbfgs_param* param,
         if ((rc = backend(st, lbfgs_hip_vec_alloc(ctx, &st->wp))) != LBFGS_OK) return bail_out(rc);
     }
     // lbfgs.rs:449: m zeroed (s, y) pairs
-    if ((rc = backend(st, lbfgs_hip_history_create(ctx, (int)param->m, &st->hist))) != LBFGS_OK) return bail_out(rc);
+    if (with_history && (rc = backend(st, lbfgs_hip_history_create(ctx, (int)param->m, &st->hist))) != LBFGS_OK)
+        return bail_out(rc);
     if ((rc = backend(st, lbfgs_hip_vec_upload(st->x, x0, st->shard.n_local))) != LBFGS_OK) return bail_out(rc);
+    *out = st;
+    return LBFGS_OK;
+}
 
+int lbfgs_build(lbfgs_state** out, lbfgs_hip_ctx* ctx, const lbfgs_param* param, const double* x0,
+                const lbfgs_evaluator* eval) {
+    lbfgs_state* st = nullptr;
+    int rc = problem_new(&st, ctx, param, x0, eval, true);
+    if (rc != LBFGS_OK) return rc;
+    *out = nullptr;
+    auto bail_out = [&](int rc_) {
+        g_build_error = st->err;
+        lbfgs_state_free(st);
+        return rc_;
+    };
     if ((rc = evaluate_here(st, false, nullptr)) != LBFGS_OK) return bail_out(rc);  // lbfgs.rs:454
     // lbfgs.rs:457: d = -g (or -pg)
     if ((rc = backend(st, lbfgs_hip_vecncpy(st->d, st->grad_for_direction()))) != LBFGS_OK) return bail_out(rc);
@@ -591,6 +608,84 @@ int lbfgs_build(lbfgs_state** out, lbfgs_hip_ctx* ctx, const lbfgs_param* param,
     st->k = 0;
     st->ncall = 0;
     *out = st;
+    return LBFGS_OK;
+}
+
+// ---- Problem, stand-alone (core.rs:59-217) ----------------------------------------------------------
+int lbfgs_problem_new(lbfgs_state** out, lbfgs_hip_ctx* ctx, const lbfgs_param* param, const double* x0,
+                      const lbfgs_evaluator* eval) {
+    return problem_new(out, ctx, param, x0, eval, false);
+}
+int lbfgs_problem_evaluate(lbfgs_state* st) {
+    if (!st) return LBFGS_ERR_PARAM;
+    st->dginit_valid = false;
+    return evaluate_here(st, false, nullptr);
+}
+int lbfgs_problem_update_search_direction(lbfgs_state* st) {
+    if (!st) return LBFGS_ERR_PARAM;
+    st->dginit_valid = false;
+    return backend(st, lbfgs_hip_vecncpy(st->d, st->grad_for_direction()));
+}
+int lbfgs_problem_dginit(lbfgs_state* st, double* out) {  // on the CURRENT point (gx / pg), as core.rs:78-92
+    if (!st || !out) return LBFGS_ERR_PARAM;
+    TRYB(st, lbfgs_hip_vecdot(st->owlqn() ? st->pg : st->gx, st->d, S_DGINIT));
+    return backend(st, lbfgs_hip_scalars_read(st->ctx, S_DGINIT, 1, out));
+}
+int lbfgs_problem_dg_unchecked(lbfgs_state* st, double* out) {
+    if (!st || !out) return LBFGS_ERR_PARAM;
+    TRYB(st, lbfgs_hip_vecdot(st->gx, st->d, S_DG));
+    return backend(st, lbfgs_hip_scalars_read(st->ctx, S_DG, 1, out));
+}
+int lbfgs_problem_save_state(lbfgs_state* st) {  // copies here: x and gx stay valid for the caller
+    if (!st) return LBFGS_ERR_PARAM;
+    TRYB(st, lbfgs_hip_veccpy(st->xp, st->x));
+    return backend(st, lbfgs_hip_veccpy(st->gp, st->gx));
+}
+int lbfgs_problem_revert(lbfgs_state* st) { return st ? revert(st) : LBFGS_ERR_PARAM; }
+int lbfgs_problem_take_line_step(lbfgs_state* st, double step) {
+    if (!st) return LBFGS_ERR_PARAM;
+    if (st->owlqn()) TRY(owl_range(st));
+    st->norms_valid = false;
+    return backend(st, lbfgs_hip_line_step(st->x, st->xp, st->d, step, st->owlqn() ? st->wp : nullptr, st->owl_start,
+                                           st->owl_end));
+}
+int lbfgs_problem_update_orthant_new_point(lbfgs_state* st) {
+    if (!st || !st->owlqn()) return LBFGS_ERR_PARAM;
+    return backend(st, lbfgs_hip_orthant_select(st->wp, st->xp, st->pg));
+}
+int lbfgs_problem_constrain_search_direction(lbfgs_state* st) {  // no-op without OWL-QN (core.rs:213-217)
+    if (!st) return LBFGS_ERR_PARAM;
+    if (!st->owlqn()) return LBFGS_OK;
+    TRY(owl_range(st));
+    st->dginit_valid = false;
+    TRYB(st, lbfgs_hip_constrain_direction(st->d, st->pg, st->owl_start, st->owl_end, S_DNORM2C));
+    double c2;
+    TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_DNORM2C, 1, &c2));
+    if (std::sqrt(c2) == 0.0) return fail(st, LBFGS_PANIC_ZERO_DIRECTION, "invalid direction vector after constraints");
+    return LBFGS_OK;
+}
+int lbfgs_problem_norms(lbfgs_state* st, double* xnorm, double* gnorm) {
+    if (!st) return LBFGS_ERR_PARAM;
+    TRY(ensure_norms(st));
+    if (xnorm) *xnorm = std::sqrt(st->xnorm2);
+    if (gnorm) *gnorm = std::sqrt(st->gnorm2);
+    return LBFGS_OK;
+}
+int lbfgs_problem_set_linesearch(lbfgs_state* st, const lbfgs_param* ls) {
+    if (!st || !ls) return LBFGS_ERR_PARAM;
+    st->vars.ls_algorithm = ls->ls_algorithm;
+    st->vars.gradient_only = ls->gradient_only;
+    st->vars.ftol = ls->ftol; st->vars.gtol = ls->gtol; st->vars.xtol = ls->xtol;
+    st->vars.min_step = ls->min_step; st->vars.max_step = ls->max_step;
+    st->vars.max_linesearch = ls->max_linesearch;
+    return LBFGS_OK;
+}
+int lbfgs_problem_status(lbfgs_state* st, double* fx, uint64_t* neval, int* evaluated, int* orthantwise) {
+    if (!st) return LBFGS_ERR_PARAM;
+    if (fx) *fx = st->fx;
+    if (neval) *neval = st->neval;
+    if (evaluated) *evaluated = st->evaluated ? 1 : 0;
+    if (orthantwise) *orthantwise = st->owlqn() ? 1 : 0;
     return LBFGS_OK;
 }
 
@@ -617,6 +712,7 @@ int lbfgs_line_search(lbfgs_state* st, double* step, uint64_t* ncall) {
 
 int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
     if (!st) return LBFGS_ERR_PARAM;
+    if (!st->hist) return fail(st, LBFGS_ERR_PARAM, "this state is a stand-alone Problem (no L-BFGS history)");
     st->k += 1;
     if (st->k == 1) return out ? get_progress(st, out) : LBFGS_OK;  // :507-510
 
@@ -724,7 +820,7 @@ static lbfgs_hip_vec* pick(lbfgs_state* st, int which) {
         case LBFGS_VEC_D: return st->d;
         default: break;
     }
-    const int m = (int)st->vars.m;
+    const int m = st->hist ? (int)st->vars.m : 0;
     if (which >= LBFGS_VEC_S0 && which < LBFGS_VEC_S0 + m) return lbfgs_hip_history_s(st->hist, which - LBFGS_VEC_S0);
     if (which >= LBFGS_VEC_Y0 && which < LBFGS_VEC_Y0 + m) return lbfgs_hip_history_y(st->hist, which - LBFGS_VEC_Y0);
     return nullptr;
@@ -736,6 +832,8 @@ int lbfgs_state_download(lbfgs_state* st, int which, double* host) {
     if (!v) return fail(st, LBFGS_ERR_PARAM, "no such vector");
     return backend(st, lbfgs_hip_vec_download(v, host, st->shard.n_local));
 }
+
+lbfgs_hip_vec* lbfgs_state_vec(lbfgs_state* st, int which) { return st ? pick(st, which) : nullptr; }
 
 void* lbfgs_state_devptr(lbfgs_state* st, int which) {
     lbfgs_hip_vec* v = st ? pick(st, which) : nullptr;

@@ -582,3 +582,23 @@ def test_owlqn_ops_special_values_bitwise():
         assert same(d.to_numpy(), do)
         for v in (x, g, pg, wp, d, xt):
             v.free()
+
+
+def test_line_rs_doctest_problem_and_linesearch():
+    """src/line.rs:8-32: Problem::new, evaluate, update_search_direction, LineSearch::default().find on the device."""
+    from rust_lbfgs_amd.problem import LineSearch, Problem
+
+    x = P.rosenbrock_x0()
+    with Problem(x, R.default_evaluate(), None) as prb:
+        prb.evaluate()
+        prb.update_search_direction()
+        step = 1.0 / prb.search_direction().vec2norm()
+        ncall, step = LineSearch().find(prb, step)
+        so = O.lbfgs().build(P.rosenbrock_x0(), O.rosenbrock())
+        so.propagate()
+        po = so.propagate()
+        assert ncall == po["ncall"]
+        assert abs(step - po["step"]) <= RTOL * po["step"] and abs(prb.fx - po["fx"]) <= RTOL * abs(po["fx"])
+        assert rel(prb.x, so.vec("x")) <= RTOL and rel(prb.gx, so.vec("gx")) <= RTOL
+        assert abs(prb.gnorm() - po["gnorm"]) <= RTOL * po["gnorm"]
+        so.close()

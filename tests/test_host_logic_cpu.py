@@ -230,3 +230,49 @@ def test_c_minimize_entry_point():
     rep2 = R.lbfgs().minimize(x2, R.default_evaluate())
     assert np.array_equal(x, x2) and rep.fx == rep2.fx and niters[-1] == 35
     ctx.close()
+
+
+def test_problem_and_linesearch_public_api():
+    """src/line.rs:8-32 doctest: Problem::new + evaluate + update_search_direction + LineSearch::default().find,
+    and the other public Problem methods (core.rs:59-217), against the oracle's first line search."""
+    from rust_lbfgs_amd.problem import LineSearch, LineSearchAlgorithm, Orthantwise, Problem, signum
+
+    assert [signum(v) for v in (0.0, -0.0, float("nan"), 2.0, -3.0)] == [0.0, 0.0, 0.0, 1.0, -1.0]
+    x = P.rosenbrock_x0()
+    with Problem(x, R.default_evaluate(), None) as prb:
+        assert not prb.evaluated() and prb.number_of_evaluation() == 0 and not prb.orthantwise()
+        prb.evaluate()
+        assert prb.evaluated() and prb.number_of_evaluation() == 1
+        prb.update_search_direction()
+        d = prb.search_direction()
+        assert np.array_equal(d.to_numpy(), -prb.gx)
+        step = 1.0 / d.vec2norm()
+        ncall, step = LineSearch().find(prb, step)
+        # the oracle's iteration 2 is exactly this line search
+        so = O.lbfgs().build(P.rosenbrock_x0(), O.rosenbrock())
+        so.propagate()
+        po = so.propagate()
+        assert (ncall, step, prb.fx) == (po["ncall"], po["step"], po["fx"])
+        assert np.array_equal(prb.x, so.vec("x")) and np.array_equal(prb.gx, so.vec("gx"))
+        assert prb.gnorm() == po["gnorm"] and prb.xnorm() == po["xnorm"]
+        assert prb.dg_unchecked() == O.vecdot(so.vec("gx"), -so.vec("gp"))  # d is still -g(x0)
+        so.close()
+        # save_state / take_line_step / revert
+        prb.save_state()
+        x_saved = prb.x
+        prb.take_line_step(0.25)
+        assert not np.array_equal(prb.x, x_saved)
+        prb.revert()
+        assert np.array_equal(prb.x, x_saved)
+    # backtracking with OWL-QN through the same API
+    x = P.rosenbrock_x0()
+    with Problem(x, R.default_evaluate(), Orthantwise(c=1.0, start=0, end=99)) as prb:
+        prb.evaluate()
+        prb.update_search_direction()
+        assert prb.orthantwise()
+        ncall, step = LineSearch(algorithm=LineSearchAlgorithm.BacktrackingWolfe).find(prb, 1.0 / prb.search_direction().vec2norm())
+        so = O.lbfgs().with_orthantwise(1.0, 0, 99).build(P.rosenbrock_x0(), O.rosenbrock())
+        so.propagate()
+        po = so.propagate()
+        assert (ncall, step, prb.fx) == (po["ncall"], po["step"], po["fx"])
+        so.close()
