@@ -18,7 +18,7 @@ from collections import defaultdict
 PASSES = [
     (r"OpTwoLoopStep<(true|false), false, 0>", (3, 1), "two-loop step  q+=c*u; out=v.q"),
     (r"OpTwoLoopStep<(true|false), true, 1>", (2, 1), "two-loop gamma transition"),
-    (r"OpTwoLoopStep<false, false, 2>", (2, 1), "two-loop last step + ||d||^2"),
+    (r"OpTwoLoopStep<false, false, 2>", (3, 1), "two-loop last step + ||d||^2 + g.d (g re-read for the next dginit)"),
     (r"OpTwoLoopFirst", (2, 0), "two-loop first dot s.(-g)"),
     (r"OpHistUpdate<", (4, 2), "history update s,y + 5 sums"),
     (r"OpObjLineEval<", (2, 2), "line step + quadratic eval + g.d"),

@@ -26,7 +26,7 @@ float run(const Op& op, const Bufs& b, int grid, int reps, int* occ) {
     RedCtl red{};
     red.partials = b.partials;
     red.ticket = b.ticket;
-    for (int k = 0; k < MAX_RED; ++k) red.out[k] = b.board + 2 + k;
+    for (int k = 0; k < RED_PTRS; ++k) red.out[k] = b.board + 2 + k;
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, stream_kernel<Op, UNR, NTL, NTS, MAP, SPAN>, BLOCK, 0));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -168,6 +168,33 @@ int main(int argc, char** argv) {
     bd[0] = 1e-12;  // tiny coefficient so q stays bounded across repetitions
     CK(hipMemcpy(b.board, bd, sizeof(bd), hipMemcpyHostToDevice));
 
+    if (argc > 2 && atoi(argv[2]) == -1) {  // fixed-overhead probe: tiny vectors, back-to-back launches
+        std::vector<int> g1 = {216};
+        constexpr unsigned NO = 0u;
+        sweep_copy<4, NO, NO, 2>(b, g1);
+        sweep_dot<4, NO, 2>(b, g1);
+        sweep_step<2, NO, NO, 1, 1>(b, g1);
+        // 20 dependent step kernels back to back, one event pair around all of them
+        OpTwoLoopStep<false, false, 0> op{};
+        op.in[0] = b.q; op.in[1] = b.u; op.in[2] = b.v; op.out[0] = b.q;
+        op.dot_in = b.board; op.ys_j = b.board + 1; op.alpha_j = b.board + 10; op.gamma_num = b.board; op.gamma_den = b.board + 1;
+        op.mode_b = 1;
+        RedCtl red{};
+        red.partials = b.partials; red.ticket = b.ticket;
+        for (int k = 0; k < RED_PTRS; ++k) red.out[k] = b.board + 2 + k;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < 20; ++i)
+                hipLaunchKernelGGL((stream_kernel<decltype(op), 2, 0u, 0u, 1, 1>), dim3(216), dim3(BLOCK), 0, 0, op, b.n, 0, red);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("20 dependent step kernels at n=%llu: %.1f us each\n", (unsigned long long)b.n, ms * 1000 / 20);
+        }
+        return 0;
+    }
     // 22 vectors for the Gram kernels
     double* vecs[22];
     CK(hipMalloc(&b.board, 256 * sizeof(double)));
