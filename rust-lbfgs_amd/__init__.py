@@ -9,7 +9,7 @@ C-ABI of include/lbfgs_hip.h.  There is no CPU fallback: without the built exten
 the package raises.
 """
 from . import _build, _ffi
-from .api import (BuiltinObjective, Context, DeviceEvaluate, Lbfgs, LbfgsError, LbfgsPanic, LbfgsState, Progress,
+from .api import (BuiltinObjective, Context, DeviceEvaluate, TorchEvaluate, Lbfgs, LbfgsError, LbfgsPanic, LbfgsState, Progress,
                   Report, default_evaluate, default_progress, lbfgs)
 
 
@@ -27,4 +27,4 @@ def __getattr__(name):  # lazy submodules (dist imports torch)
 
 
 __all__ = ["lbfgs", "Lbfgs", "LbfgsState", "Progress", "Report", "LbfgsError", "LbfgsPanic", "Context",
-           "DeviceEvaluate", "BuiltinObjective", "default_evaluate", "default_progress", "build"]
+           "DeviceEvaluate", "TorchEvaluate", "BuiltinObjective", "default_evaluate", "default_progress", "build"]

@@ -211,6 +211,47 @@ def declare(L):
 _LIB = None
 
 
+def _one_hip_runtime():
+    """PyTorch-ROCm bundles its own libamdhip64.so.7; if this library pulled in /opt/rocm's copy first and torch
+    were imported later, the process would hold two HIP runtimes and the second sees no device.  So when torch
+    is installed (and not yet imported) pre-load ITS runtime by path -- cheap, torch itself is not imported --
+    and let liblbfgs_hip.so bind to it by SONAME.  LBFGS_HIP_RUNTIME=system keeps /opt/rocm's runtime."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules or os.environ.get("LBFGS_HIP_RUNTIME") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    rt = os.path.join(libdir, "libamdhip64.so")
+    if os.path.exists(rt):
+        try:
+            C.CDLL(rt, mode=C.RTLD_GLOBAL)
+        except OSError:
+            return
+        # ... and if RCCL is needed later (world > 1) it must be the build that belongs to this runtime
+        rccl = os.path.join(libdir, "librccl.so")
+        if os.path.exists(rccl):
+            os.environ.setdefault("LBFGS_HIP_RCCL", rccl)
+
+
+def torch_before_rccl():
+    """RCCL and PyTorch-ROCm share a stack of bundled libraries; dlopen'ing librccl before torch has initialised
+    ends in a double free at interpreter exit (observed on ROCm 7.2 + torch 2.10+rocm7.0), while torch first is
+    clean.  Every RCCL user of this package goes through torch.distributed for the rendezvous anyway, so make
+    the order explicit."""
+    import importlib.util
+    import sys
+
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
+
+
 def load():
     """Load the product libraries.  Raises if they are not built (run rust_lbfgs_amd.build())."""
     global _LIB
@@ -223,6 +264,7 @@ def load():
             raise ImportError(
                 f"{p} is missing: the HIP extension is not built (python -c 'import rust_lbfgs_amd as r; r.build()'); "
                 "this package has no CPU fallback")
+    _one_hip_runtime()
     # liblbfgs_solver.so names liblbfgs_hip.so as a dependency (rpath $ORIGIN); RTLD_LOCAL keeps the
     # lbfgs_hip_* symbols out of the global namespace
     _LIB = declare(C.CDLL(solver, mode=C.RTLD_LOCAL))

@@ -56,6 +56,8 @@ class Context:
         self._L = L
         self._h = C.c_void_p()
         self._keep = comm  # keeps the callback / id buffer alive
+        if comm is not None and comm.c.kind == _ffi.COMM_RCCL:
+            _ffi.torch_before_rccl()
         shard_p = C.byref(shard) if shard is not None else None
         comm_p = C.byref(comm.c) if comm is not None else None
         rc = L.lbfgs_hip_ctx_create(C.byref(self._h), device, n, shard_p, comm_p, stream)
@@ -124,6 +126,40 @@ class DeviceEvaluate:
 
     def __init__(self, fn):
         self.fn = fn
+
+
+class _DevArray:
+    """Minimal __cuda_array_interface__ carrier so torch can view device memory it does not own."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+class TorchEvaluate(DeviceEvaluate):
+    """`evaluate` written in PyTorch on the device-resident vectors (no PCIe traffic):
+
+        def fn(x: torch.Tensor, g: torch.Tensor) -> float | torch.Tensor:   # x read-only, write g in place
+            ...
+    x and g are float64 CUDA(HIP) tensors that VIEW the optimiser's buffers of this rank's shard."""
+
+    def __init__(self, fn, device=0):
+        import torch
+
+        self._torch = torch
+        self._dev = torch.device("cuda", device)
+
+        def raw(xptr, gptr, n, stream):
+            if n == 0:
+                return float(fn(torch.empty(0, dtype=torch.float64, device=self._dev),
+                                torch.empty(0, dtype=torch.float64, device=self._dev)))
+            xt = torch.as_tensor(_DevArray(xptr, n), device=self._dev)
+            gt = torch.as_tensor(_DevArray(gptr, n), device=self._dev)
+            f = fn(xt, gt)
+            f = float(f)  # .item() synchronises torch's stream: g is complete before the optimiser reads it
+            torch.cuda.synchronize(self._dev)
+            return f
+
+        super().__init__(raw)
 
 
 @dataclass

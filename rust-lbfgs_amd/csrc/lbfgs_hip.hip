@@ -47,8 +47,11 @@ const int kNcclDouble = 8, kNcclSum = 0;
 
 bool rccl_load(std::string* err) {
     if (g_rccl.ok) return true;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // LBFGS_HIP_RCCL: the RCCL build that belongs to the HIP runtime in use (set by the Python loader when it
+    // pre-loaded PyTorch's bundled runtime); otherwise whatever librccl.so.1 the process already has / finds
+    const char* names[] = {getenv("LBFGS_HIP_RCCL"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* nm : names) {
+        if (!nm || !*nm) continue;
         g_rccl.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
         if (g_rccl.handle) break;
     }

@@ -175,7 +175,7 @@ template <bool NEG_SRC, bool SCALE, int VMODE>
 struct OpTwoLoopStep {
     static constexpr int NIN = (VMODE == 1) ? 2 : 3, NOUT = 1, NRED = (VMODE == 2) ? 2 : 1;
     // measured best for the 3r+1w shape on MI355X: fine grid-stride, 2 chunks in flight per stream
-    static constexpr int TUNE_MAP = (VMODE == 0) ? 1 : DEFAULT_MAP, TUNE_UNROLL = (VMODE == 0) ? 2 : UNROLL;
+    static constexpr int TUNE_MAP = (VMODE == 1) ? DEFAULT_MAP : 1, TUNE_UNROLL = (VMODE == 1) ? UNROLL : 2;
     const double* in[3];  // src, u, v (VMODE 2: g)
     double* out[1];       // dst (= d)
     const double* dot_in; // previous reduction (global sum)

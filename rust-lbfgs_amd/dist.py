@@ -44,7 +44,7 @@ class CommSpec:
 
 def rccl_comm(process_group=None):
     """RCCL communicator: rank 0 makes the unique id, torch.distributed broadcasts it."""
-    import torch.distributed as dist
+    import torch.distributed as dist  # (torch is imported before librccl is touched: _ffi.torch_before_rccl)
 
     L = _ffi.load()
     buf = (C.c_char * 128)()

@@ -48,6 +48,7 @@ def test_rccl_single_rank_communicator():
     from rust_lbfgs_amd.dist import CommSpec
 
     L = _ffi.load()
+    _ffi.torch_before_rccl()  # as dist.rccl_comm() does: torch initialises before librccl is opened
     buf = (C.c_char * 128)()
     assert L.lbfgs_hip_rccl_unique_id(buf) == 0, L.lbfgs_hip_last_error(None)
     n = 100_001

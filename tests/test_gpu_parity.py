@@ -602,3 +602,36 @@ def test_line_rs_doctest_problem_and_linesearch():
         assert rel(prb.x, so.vec("x")) <= RTOL and rel(prb.gx, so.vec("gx")) <= RTOL
         assert abs(prb.gnorm() - po["gnorm"]) <= RTOL * po["gnorm"]
         so.close()
+
+
+def test_device_closure_bridge_with_torch():
+    """the evaluate closure on DEVICE pointers (x and g never leave HBM), written in PyTorch with
+    autograd, against the same objective through the drop-in host closure."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("device pointers")
+    import torch
+
+    n = 20_000
+    w = np.linspace(0.5, 3.0, n)
+    wt = torch.tensor(w, dtype=torch.float64, device="cuda:0")
+
+    def host(x, g):  # f = sum w*(x-1)^2 + 0.25*sum x^4
+        g[:] = 2.0 * w * (x - 1.0) + x ** 3
+        return float(np.sum(w * (x - 1.0) ** 2) + 0.25 * np.sum(x ** 4))
+
+    def dev(x, g):
+        xr = x.detach().clone().requires_grad_(True)
+        f = torch.sum(wt * (xr - 1.0) ** 2) + 0.25 * torch.sum(xr ** 4)
+        f.backward()
+        g.copy_(xr.grad)
+        return f
+
+    xh, xd = np.zeros(n), np.zeros(n)
+    rh, rd = [], []
+    R.lbfgs().with_max_iterations(25).minimize(xh, host, lambda p: rh.append((p.niter, p.neval, p.fx, p.gnorm)) and False)
+    R.lbfgs().with_max_iterations(25).minimize(xd, R.TorchEvaluate(dev), lambda p: rd.append((p.niter, p.neval, p.fx, p.gnorm)) and False)
+    assert len(rh) == len(rd) >= 5
+    for a, b in zip(rh, rd):
+        assert a[:2] == b[:2]
+        assert abs(a[2] - b[2]) <= 1e-9 * abs(a[2]) and abs(a[3] - b[3]) <= 1e-7 * max(a[3], 1e-9)
+    assert np.max(np.abs(xh - xd)) <= 1e-8
