@@ -269,13 +269,3 @@ def load():
     # lbfgs_hip_* symbols out of the global namespace
     _LIB = declare(C.CDLL(solver, mode=C.RTLD_LOCAL))
     return _LIB
-
-
-def use_library_for_tests(lib):
-    """TESTS ONLY: substitute the loaded library (the CPU test double of tests/support/).
-
-    The product never calls this; it exists so the host orchestration can be tested in
-    the GPU-less suite.  Returns the previous library so a fixture can restore it."""
-    global _LIB
-    prev, _LIB = _LIB, lib
-    return prev

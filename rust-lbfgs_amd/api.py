@@ -155,7 +155,7 @@ class TorchEvaluate(DeviceEvaluate):
             xt = torch.as_tensor(_DevArray(xptr, n), device=self._dev)
             gt = torch.as_tensor(_DevArray(gptr, n), device=self._dev)
             f = fn(xt, gt)
-            f = float(f)  # .item() synchronises torch's stream: g is complete before the optimiser reads it
+            f = float(f.detach()) if hasattr(f, "detach") else float(f)  # .item() synchronises torch's stream: g is complete before the optimiser reads it
             torch.cuda.synchronize(self._dev)
             return f
 

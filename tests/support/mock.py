@@ -44,3 +44,20 @@ def load():
     from rust_lbfgs_amd import _ffi
 
     return _ffi.declare(C.CDLL(build()))
+
+
+def install():
+    """Point the Python binding at the test double (tests only; the product has no hook for this: we patch the
+    module attribute).  Returns the previous library for `restore`."""
+    import rust_lbfgs_amd  # noqa: F401
+    from rust_lbfgs_amd import _ffi
+
+    prev = _ffi._LIB
+    _ffi._LIB = load()
+    return prev
+
+
+def restore(prev):
+    from rust_lbfgs_amd import _ffi
+
+    _ffi._LIB = prev

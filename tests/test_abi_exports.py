@@ -43,13 +43,13 @@ def test_no_cpu_fallback_without_gpu(libs):
     """Without a GPU the product fails loudly instead of computing on the host."""
     if os.path.exists("/dev/kfd"):
         pytest.skip("GPU present")
-    prev = _ffi.use_library_for_tests(None)
+    prev, _ffi._LIB = _ffi._LIB, None
     try:
         with pytest.raises(R.LbfgsError) as e:
             R.Context(16)
         assert e.value.code == _ffi.HIP_ERR_NO_DEVICE
     finally:
-        _ffi.use_library_for_tests(prev)
+        _ffi._LIB = prev
 
 
 def test_product_libraries_do_not_link_the_oracle(libs):

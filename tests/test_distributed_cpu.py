@@ -24,7 +24,7 @@ from rust_lbfgs_amd import _ffi, objectives
 from rust_lbfgs_amd import dist as D
 if os.environ.get("LBFGS_WORKER_PRODUCT") != "1":   # CPU suite: the test double; GPU suite: the HIP library
     from tests.support import mock
-    _ffi.use_library_for_tests(mock.load())
+    mock.install()
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 case = json.loads(os.environ["LBFGS_CASE"])

@@ -33,11 +33,11 @@ def product_library():
     if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
         from tests.support import mock
 
-        prev = _ffi.use_library_for_tests(mock.load())
+        prev = mock.install()
         yield
-        _ffi.use_library_for_tests(prev)
+        mock.restore(prev)
     else:
-        _ffi.use_library_for_tests(None)
+        _ffi._LIB = None
         _ffi.load()  # raises if the HIP extension is not built
         yield
 

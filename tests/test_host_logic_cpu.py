@@ -22,9 +22,9 @@ KA = json.load(open(os.path.join(P.GOLDEN, "reference_known_answers.json")))
 
 @pytest.fixture(autouse=True)
 def on_mock():
-    prev = _ffi.use_library_for_tests(mock.load())
+    prev = mock.install()
     yield
-    _ffi.use_library_for_tests(prev)
+    mock.restore(prev)
 
 
 def run_pair(configure, x0, oracle_eval, product_eval, max_rows=10_000):
