@@ -242,10 +242,13 @@ def measure(env, ctx, label, vector_free=False):
                     pass
             if nt:
                 t_tl = ms_all / nt
-                # 8*b passes of 8 bytes: the fused minimum that respects the dot->axpy dependency
-                gbps = 64.0 * a.m * n_local / (t_tl * 1e-3) / 1e9
+                # 8*b passes of 8 bytes is the fused minimum that respects the dot->axpy dependency;
+                # the first numerator s.(-g) now comes out of the history-update kernel, so the exact recursion
+                # is charged 8*b - 2 passes (it actually moves 8*b - 1: the last step re-reads g for the next g.d)
+                passes = (4 * a.m + 3) if vector_free else (8 * a.m - 2)
+                gbps = 8.0 * passes * n_local / (t_tl * 1e-3) / 1e9
                 roof.update(two_loop={"ms": t_tl, "algorithmic_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS,
-                                      "bytes": 64 * a.m * n_local, "calls": nt,
+                                      "bytes": 8 * passes * n_local, "passes": passes, "calls": nt,
                                       "note": "per GPU: this rank's shard, incl. the all-reduces inside the recursion"})
             roof["per_iteration_ms"] = {
                 "two_loop": ms_all / max(nt, 1), "history_update": ms_upd / max(a.steps, 1),

@@ -173,7 +173,10 @@ int lbfgs_hip_history_scalars_write(lbfgs_hip_history* h, const double* ys, cons
  *   board[out_slot+1] = y.s          (:653)  also stored as ys[slot] (:656)
  *   board[out_slot+2] = y.y          (:654)
  *   board[out_slot+3] = ||x||^2, board[out_slot+4] = ||g||^2   (free: x and g are read anyway)
- *   board[out_slot+5] = s.bs with bs = gp*(-step)               (:670-673; only when damping != 0)
+ *   board[out_slot+5] = s.bs with bs = gp*(-step)               (:670-673; 0 unless damping != 0)
+ *   board[out_slot+6] = s.(-g): the numerator of the two-loop's first alpha (lbfgs.rs:587 with d = -g), free
+ *                       here; pass the slot to lbfgs_hip_two_loop_from to skip that pass (not under OWL-QN,
+ *                       where the direction starts from -pg)
  * The caller does the scalar tests (:646, :655) and gamma = ys/yy (:691).  */
 int lbfgs_hip_history_update(lbfgs_hip_history* h, int slot, const lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
                              const lbfgs_hip_vec* g, const lbfgs_hip_vec* gp, double step, int damping,
@@ -192,6 +195,10 @@ int lbfgs_hip_history_damp(lbfgs_hip_history* h, int slot, const lbfgs_hip_vec* 
  * `g` is gx, or pg under OWL-QN (core.rs:96-97). */
 int lbfgs_hip_two_loop(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
                        int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int* new_end);
+/* the same, starting from an alpha_0 numerator that is already on the board (first_dot_slot >= 0: the value
+ * lbfgs_hip_history_update left at out_slot+6 for the slot `end` and this `g`): 8*bound - 1 passes */
+int lbfgs_hip_two_loop_from(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
+                            int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end);
 /* EXTENSION: the same recursion in the coefficient space of the basis [s_j.., y_j.., g]
  * ("vector-free" L-BFGS): one pass refreshes the three changed rows of the Gram matrix B^T B, a scalar
  * kernel runs lbfgs.rs:582-601 on 2m+1 coefficients, one pass forms d.  4m+3 passes and 2 all-reduces

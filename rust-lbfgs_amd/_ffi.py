@@ -97,7 +97,7 @@ lbfgs_hip_vecdiff lbfgs_hip_vec2norm_sq
 lbfgs_hip_line_step lbfgs_hip_norms_sq
 lbfgs_hip_history_create lbfgs_hip_history_destroy lbfgs_hip_history_s lbfgs_hip_history_y
 lbfgs_hip_history_scalars_read lbfgs_hip_history_scalars_write lbfgs_hip_history_update lbfgs_hip_history_damp
-lbfgs_hip_two_loop lbfgs_hip_two_loop_gram lbfgs_hip_two_loop_unfused
+lbfgs_hip_two_loop lbfgs_hip_two_loop_from lbfgs_hip_two_loop_gram lbfgs_hip_two_loop_unfused
 lbfgs_hip_owlqn_post_eval lbfgs_hip_orthant_select lbfgs_hip_constrain_direction
 lbfgs_hip_objective_eval lbfgs_hip_objective_line_eval
 lbfgs_hip_prof_enable lbfgs_hip_prof_reset lbfgs_hip_prof_read
@@ -160,6 +160,7 @@ def declare(L):
         "lbfgs_hip_history_update": (i, [vp, i, vp, vp, vp, vp, dbl, i, i]),
         "lbfgs_hip_history_damp": (i, [vp, i, vp, dbl, dbl]),
         "lbfgs_hip_two_loop": (i, [vp, vp, vp, u64, i, i, i, i, C.POINTER(i)]),
+        "lbfgs_hip_two_loop_from": (i, [vp, vp, vp, u64, i, i, i, i, i, C.POINTER(i)]),
         "lbfgs_hip_two_loop_gram": (i, [vp, vp, vp, u64, i, i, i, i, C.POINTER(i)]),
         "lbfgs_hip_two_loop_unfused": (i, [vp, vp, u64, i, i, i, C.POINTER(i)]),
         "lbfgs_hip_owlqn_post_eval": (i, [vp, vp, vp, dbl, u64, u64, i]),

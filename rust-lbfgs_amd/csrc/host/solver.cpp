@@ -31,12 +31,12 @@ enum Slot {
     S_XN2_OWL = 4,  // ||x||^2            (OWL-QN)
     S_DGINIT = 5,
     // one contiguous block read with ONE synchronisation at the end of an iteration:
-    S_UPD = 6,      // ||s||^2, ys, yy, ||x||^2, ||g||^2, s.bs          (history update)
-    S_DNORM2 = 12,  // ||d||^2, g.d                                      (two-loop, last step)
-    S_DNORM2C = 14, // ||d||^2, pg.d after the orthant projection        (OWL-QN)
-    S_END_BLOCK = 16,
-    S_NORMS = 16,   // ||x||^2, ||g||^2
-    S_FAILED = 18   // closure failure count (world > 1)
+    S_UPD = 6,      // ||s||^2, ys, yy, ||x||^2, ||g||^2, s.bs, s.(-g)  (history update)
+    S_DNORM2 = 13,  // ||d||^2, g.d                                      (two-loop, last step)
+    S_DNORM2C = 15, // ||d||^2, pg.d after the orthant projection        (OWL-QN)
+    S_END_BLOCK = 17,
+    S_NORMS = 17,   // ||x||^2, ||g||^2
+    S_FAILED = 19   // closure failure count (world > 1)
 };
 
 inline bool sign_positive(double v) { return !std::signbit(v); }  // f64::is_sign_positive
@@ -763,9 +763,9 @@ int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
     if (st->vars.vector_free)
         TRYB(st, lbfgs_hip_two_loop_gram(st->hist, st->d, st->grad_for_direction(), st->k - 1, st->end, S_UPD + 1,
                                          S_UPD + 2, S_DNORM2, &new_end));
-    else
-        TRYB(st, lbfgs_hip_two_loop(st->hist, st->d, st->grad_for_direction(), st->k - 1, st->end, S_UPD + 1, S_UPD + 2,
-                                    S_DNORM2, &new_end));
+    else  // without OWL-QN and damping the update kernel already summed s_new.(-g): start from it
+        TRYB(st, lbfgs_hip_two_loop_from(st->hist, st->d, st->grad_for_direction(), st->k - 1, st->end, S_UPD + 1,
+                                         S_UPD + 2, S_DNORM2, st->owlqn() ? -1 : S_UPD + 6, &new_end));
     if (st->owlqn())  // :554, orthantwise.rs:140-161 (after dnorm, as in the reference)
         TRYB(st, lbfgs_hip_constrain_direction(st->d, st->pg, st->owl_start, st->owl_end, S_DNORM2C));
     TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_UPD, S_END_BLOCK - S_UPD, u));

@@ -959,22 +959,21 @@ int lbfgs_hip_history_update(lbfgs_hip_history* h, int slot, const lbfgs_hip_vec
     if (!h || slot < 0 || slot >= h->m || !x || !xp || !g || !gp) return LBFGS_HIP_ERR_ARG;
     lbfgs_hip_ctx* ctx = h->ctx;
     if (x->ctx != ctx || xp->ctx != ctx || g->ctx != ctx || gp->ctx != ctx) return LBFGS_HIP_ERR_ARG;
-    if (!slot_ok(out_slot, damping ? 6 : 5)) return LBFGS_HIP_ERR_ARG;
+    if (!slot_ok(out_slot, 7)) return LBFGS_HIP_ERR_ARG;
     double* b = ctx->board + out_slot;
+    double* outs[7] = {b, b + 1, b + 2, b + 3, b + 4, b + 5, b + 6};
     int rc;
     if (damping) {
         OpHistUpdate<true> op{};
         op.in[0] = x->p; op.in[1] = xp->p; op.in[2] = g->p; op.in[3] = gp->p;
         op.out[0] = h->s[slot]->p; op.out[1] = h->y[slot]->p;
         op.neg_step = -step;
-        double* outs[6] = {b, b + 1, b + 2, b + 3, b + 4, b + 5};
         rc = launch(ctx, LBFGS_HIP_K_UPDATE, op, outs);
     } else {
         OpHistUpdate<false> op{};
         op.in[0] = x->p; op.in[1] = xp->p; op.in[2] = g->p; op.in[3] = gp->p;
         op.out[0] = h->s[slot]->p; op.out[1] = h->y[slot]->p;
         op.neg_step = 0.0;
-        double* outs[5] = {b, b + 1, b + 2, b + 3, b + 4};
         rc = launch(ctx, LBFGS_HIP_K_UPDATE, op, outs);
     }
     if (rc != LBFGS_HIP_OK) return rc;
@@ -997,6 +996,12 @@ int lbfgs_hip_history_damp(lbfgs_hip_history* h, int slot, const lbfgs_hip_vec* 
 
 int lbfgs_hip_two_loop(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
                        int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int* new_end) {
+    return lbfgs_hip_two_loop_from(h, d, g, k, end, gamma_num_slot, gamma_den_slot, dnorm_slot, -1, new_end);
+}
+
+int lbfgs_hip_two_loop_from(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
+                            int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end) {
+    if (first_dot_slot >= 0 && !slot_ok(first_dot_slot, 1)) return LBFGS_HIP_ERR_ARG;
     if (!h || !d || !g || d->ctx != h->ctx || g->ctx != h->ctx || end < 0 || end >= h->m || !new_end)
         return LBFGS_HIP_ERR_ARG;
     if (!slot_ok(gamma_num_slot, 1) || !slot_ok(gamma_den_slot, 1) || !slot_ok(dnorm_slot, 2)) return LBFGS_HIP_ERR_ARG;
@@ -1021,7 +1026,11 @@ int lbfgs_hip_two_loop(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
     auto jat = [&](int i) { return ((e1 - 1 - i) % m + m) % m; };
     int pp = 0;
     int rc;
-    {   // alpha_0 numerator: s_{j0} . (-g)                                         2r
+    const double* cur = dots + pp;  // where the pending numerator lives
+    if (first_dot_slot >= 0) {
+        // alpha_0 numerator already on the board (the history-update kernel summed s_new.(-g)): no pass at all
+        cur = ctx->board + first_dot_slot;
+    } else {   // alpha_0 numerator: s_{j0} . (-g)                                         2r
         OpTwoLoopFirst op{};
         op.in[0] = g->p; op.in[1] = h->s[jat(0)]->p;
         double* outs[1] = {dots + pp};
@@ -1032,36 +1041,41 @@ int lbfgs_hip_two_loop(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
     for (int i = 1; i < bound; ++i) {
         const int jp = jat(i - 1), jn = jat(i);
         const double* src = (i == 1) ? g->p : d->p;
+        double* nxt = dots + (pp ^ 1);
         if (i == 1)
-            rc = two_loop_step<true, false, 0>(h, src, h->y[jp]->p, h->s[jn]->p, d->p, dots + pp, jp, 0, gnum, gden,
-                                               dots + (pp ^ 1), LBFGS_HIP_K_TWOLOOP_STEP);
+            rc = two_loop_step<true, false, 0>(h, src, h->y[jp]->p, h->s[jn]->p, d->p, cur, jp, 0, gnum, gden, nxt,
+                                               LBFGS_HIP_K_TWOLOOP_STEP);
         else
-            rc = two_loop_step<false, false, 0>(h, src, h->y[jp]->p, h->s[jn]->p, d->p, dots + pp, jp, 0, gnum, gden,
-                                                dots + (pp ^ 1), LBFGS_HIP_K_TWOLOOP_STEP);
+            rc = two_loop_step<false, false, 0>(h, src, h->y[jp]->p, h->s[jn]->p, d->p, cur, jp, 0, gnum, gden, nxt,
+                                                LBFGS_HIP_K_TWOLOOP_STEP);
         if (rc != LBFGS_HIP_OK) return rc;
         pp ^= 1;
+        cur = dots + pp;
     }
     {   // transition: q = gamma*(q - alpha_last y_last) ; beta numerator y_last . q      2r 1w
         const int jl = jat(bound - 1);
+        double* nxt = dots + (pp ^ 1);
         if (bound == 1)
-            rc = two_loop_step<true, true, 1>(h, g->p, h->y[jl]->p, nullptr, d->p, dots + pp, jl, 0, gnum, gden,
-                                              dots + (pp ^ 1), LBFGS_HIP_K_TWOLOOP_EDGE);
+            rc = two_loop_step<true, true, 1>(h, g->p, h->y[jl]->p, nullptr, d->p, cur, jl, 0, gnum, gden, nxt,
+                                              LBFGS_HIP_K_TWOLOOP_EDGE);
         else
-            rc = two_loop_step<false, true, 1>(h, d->p, h->y[jl]->p, nullptr, d->p, dots + pp, jl, 0, gnum, gden,
-                                               dots + (pp ^ 1), LBFGS_HIP_K_TWOLOOP_EDGE);
+            rc = two_loop_step<false, true, 1>(h, d->p, h->y[jl]->p, nullptr, d->p, cur, jl, 0, gnum, gden, nxt,
+                                               LBFGS_HIP_K_TWOLOOP_EDGE);
         if (rc != LBFGS_HIP_OK) return rc;
         pp ^= 1;
+        cur = dots + pp;
     }
     // second loop (lbfgs.rs:594-601), slots in the reverse order: j = jat(bound-1) ... jat(0)
     for (int i = bound - 1; i >= 1; --i) {
         const int j = jat(i), jn = jat(i - 1);  // q += (alpha_j - beta_j) s_j ; next numerator y_{jn} . q   3r 1w
-        rc = two_loop_step<false, false, 0>(h, d->p, h->s[j]->p, h->y[jn]->p, d->p, dots + pp, j, 1, gnum, gden,
+        rc = two_loop_step<false, false, 0>(h, d->p, h->s[j]->p, h->y[jn]->p, d->p, cur, j, 1, gnum, gden,
                                             dots + (pp ^ 1), LBFGS_HIP_K_TWOLOOP_STEP);
         if (rc != LBFGS_HIP_OK) return rc;
         pp ^= 1;
+        cur = dots + pp;
     }
     // last step: q += (alpha_{j0} - beta_{j0}) s_{j0} ; ||d||^2 (lbfgs.rs:543) and g.d (core.rs:78-92)   3r 1w
-    return two_loop_step<false, false, 2>(h, d->p, h->s[jat(0)]->p, g->p, d->p, dots + pp, jat(0), 1, gnum, gden, dn,
+    return two_loop_step<false, false, 2>(h, d->p, h->s[jat(0)]->p, g->p, d->p, cur, jat(0), 1, gnum, gden, dn,
                                           LBFGS_HIP_K_TWOLOOP_EDGE);
 }
 

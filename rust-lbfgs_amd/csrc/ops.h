@@ -111,10 +111,12 @@ struct OpLineStep {
 };
 
 // ---------------------------------------------------------------- history update
-// lbfgs.rs:640-673, one pass: s = x-xp, y = g-gp, ||s||^2, y.s, y.y, ||x||^2, ||g||^2 [, s.bs]
+// lbfgs.rs:640-673, one pass: s = x-xp, y = g-gp, ||s||^2, y.s, y.y, ||x||^2, ||g||^2, s.bs (0 unless DAMP),
+// and s.(-g): the numerator of the two-loop's FIRST alpha (lbfgs.rs:587 with d = -g, core.rs:95-101), which
+// needs exactly the two vectors this kernel already holds.
 template <bool DAMP>
 struct OpHistUpdate {
-    static constexpr int NIN = 4, NOUT = 2, NRED = DAMP ? 6 : 5;
+    static constexpr int NIN = 4, NOUT = 2, NRED = 7;
     const double* in[4];  // x, xp, g, gp
     double* out[2];       // s, y
     double neg_step;      // -step (lbfgs.rs:671)
@@ -131,6 +133,7 @@ struct OpHistUpdate {
         acc[3] += v[0] * v[0];
         acc[4] += v[2] * v[2];
         if constexpr (DAMP) acc[5] += s * (v[3] * neg_step);
+        acc[6] += s * (-v[2]);
     }
 };
 

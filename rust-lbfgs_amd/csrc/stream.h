@@ -39,7 +39,7 @@ constexpr int MAX_GRID = 4096;      // upper bound on workgroups per launch
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-constexpr int RED_PTRS = 6;         // sums that may go to individually addressed slots
+constexpr int RED_PTRS = 8;         // sums that may go to individually addressed slots
 
 // ---- direct xGMI exchange of reduction results (communicator kind "p2p") ---------------------------
 // xGMI is point-to-point and fully connected and the messages are 8-48 bytes, so instead of a collective

@@ -71,6 +71,13 @@ class History:
                                                   dnorm_slot, C.byref(ne)))
         return ne.value
 
+    def two_loop_from(self, d, g, k, end, first_dot_slot, gamma_num_slot=7, gamma_den_slot=8, dnorm_slot=13):
+        """two_loop starting from the alpha_0 numerator that `update` left at out_slot+6."""
+        ne = C.c_int()
+        self.ctx.check(self._L.lbfgs_hip_two_loop_from(self._h, d._h, g._h, k, end, gamma_num_slot, gamma_den_slot,
+                                                       dnorm_slot, first_dot_slot, C.byref(ne)))
+        return ne.value
+
     def two_loop_gram(self, d, g, k, end, gamma_num_slot=7, gamma_den_slot=8, dnorm_slot=12):
         """Vector-free (Gram) variant [extension]: call after every history update."""
         ne = C.c_int()

@@ -205,14 +205,18 @@ int lbfgs_hip_history_update(lbfgs_hip_history* h, int slot, const lbfgs_hip_vec
     b[2] = oracle_vecdot(y, y, n);
     b[3] = oracle_vecdot(x->p->data(), x->p->data(), n);
     b[4] = oracle_vecdot(g->p->data(), g->p->data(), n);
-    int cnt = 5;
+    b[5] = 0.0;
     if (damping) {
         std::vector<double> bs(gp->p->begin(), gp->p->begin() + n);
         oracle_vecscale(bs.data(), -step, n);
         b[5] = oracle_vecdot(s, bs.data(), n);
-        cnt = 6;
     }
-    int rc = allreduce(c, b, cnt);
+    {   // s.(-g) as the reference's first two-loop dot computes it: vecdot(s, d) with d = -g
+        std::vector<double> d(n);
+        oracle_vecncpy(d.data(), g->p->data(), n);
+        b[6] = oracle_vecdot(s, d.data(), n);
+    }
+    int rc = allreduce(c, b, 7);
     h->ys[slot] = b[1];
     return rc;
 }
@@ -261,6 +265,11 @@ int lbfgs_hip_two_loop(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
     rc = gdot(h->ctx, d->p->data(), d->p->data(), h->ctx->board + dn);
     if (rc != 0) return rc;
     return gdot(h->ctx, g->p->data(), d->p->data(), h->ctx->board + dn + 1);
+}
+
+int lbfgs_hip_two_loop_from(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end, int gn,
+                            int gd, int dn, int, int* new_end) {
+    return lbfgs_hip_two_loop(h, d, g, k, end, gn, gd, dn, new_end);  // the test double always recomputes the dot
 }
 
 int lbfgs_hip_two_loop_gram(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end, int gn,

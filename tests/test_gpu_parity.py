@@ -192,6 +192,9 @@ def test_history_update(n, damping):
         assert abs(b[3] - O.vecdot(xh, xh)) <= RTOL * O.vecdot(xh, xh)
         assert abs(b[4] - O.vecdot(gh, gh)) <= RTOL * O.vecdot(gh, gh)
         assert hist.scalars()[0][1] == b[1]  # ys stored in the slot (lbfgs.rs:656)
+        first = ctx.scalars(12)[0]           # s.(-g): the two-loop's first alpha numerator, produced for free
+        ref_first = O.vecdot(so, -gh)
+        assert abs(first - ref_first) <= RTOL * float(np.sum(np.abs(so * gh)))
         if damping:
             bs = gph * (-step)
             assert abs(b[5] - O.vecdot(so, bs)) <= RTOL * float(np.sum(np.abs(so * bs)))
@@ -241,6 +244,16 @@ def test_two_loop_fused_vs_oracle(n, m, k, end):
         assert rel(alpha_f, alpha_o) <= RTOL
         dn2 = ctx.scalars(12)[0]
         assert abs(dn2 - O.vecdot(d_o, d_o)) <= RTOL * O.vecdot(d_o, d_o)
+        # starting from a first numerator that is already on the board (as the history update leaves it)
+        if min(m, k) >= 1:
+            j0 = end
+            tmp = DeviceVec(ctx)
+            tmp.vecncpy(gv)
+            hist.s(j0).vecdot_slot(tmp, 40)
+            tmp.free()
+            hist.set_scalars(alpha=np.zeros(m))
+            assert hist.two_loop_from(d, gv, k, end, 40, 7, 8, 12) == end_o
+            assert np.array_equal(d.to_numpy(), d_f)
         # on-device cross-check: the reference's unfused sequence of primitives
         hist.set_scalars(alpha=np.zeros(m))
         d.vecncpy(gv)
