@@ -123,6 +123,11 @@ struct lbfgs_hip_ctx {
     double* partials = nullptr;      // MAX_RED * MAX_GRID
     unsigned int* ticket = nullptr;
     double* pinned = nullptr;        // host staging, LBFGS_HIP_BOARD_SLOTS doubles
+    // host mirror of the board (stream.h MirrorCtl)
+    double* mirror = nullptr;              // host-mapped: SLOTS+2 doubles, then the sequence word
+    double* mirror_dev = nullptr;          // its device address
+    unsigned long long mirror_seq = 0;     // sequence number of the latest mirrored launch
+    bool mirror_valid[LBFGS_HIP_BOARD_SLOTS + 2] = {false};  // slot's latest value is (or will be) in the mirror
     int grid_default = 0;
     int grid_override = 0;
     int gram_grid = 0;  // workgroups of the Gram rows kernel (0 = same as the others)
@@ -219,6 +224,10 @@ P2PCtl next_p2p(lbfgs_hip_ctx* ctx) {
 // `ptrs` are device addresses (board or history scalars) just written by the last workgroup.
 int allreduce(lbfgs_hip_ctx* ctx, double* const* ptrs, int count) {
     if (ctx->comm_kind == LBFGS_HIP_COMM_NONE || count == 0) return LBFGS_HIP_OK;
+    for (int i = 0; i < count; ++i) {  // the reduced values will not be in the host mirror
+        const long idx = ptrs[i] - ctx->board;
+        if (idx >= 0 && idx < LBFGS_HIP_BOARD_SLOTS + 2) ctx->mirror_valid[idx] = false;
+    }
     ProfScope ps(ctx, LBFGS_HIP_K_COMM);
     if (ctx->comm_kind == LBFGS_HIP_COMM_RCCL) {
         // coalesce runs of consecutive addresses into one message each; group them into one launch
@@ -263,9 +272,12 @@ int allreduce(lbfgs_hip_ctx* ctx, double* const* ptrs, int count) {
 
 // ---- launch one operator ---------------------------------------------------------------------
 template <class Op>
-int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out) {
+int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out, double* dup_ptr = nullptr,
+           int dup_k = 0) {
     static_assert(Op::NRED <= MAX_RED, "the partials buffer holds MAX_RED sums per workgroup");
     RedCtl red{};
+    red.dup_ptr = dup_ptr;
+    red.dup_k = dup_k;
     red.partials = ctx->partials;
     red.ticket = ctx->ticket;
     if constexpr (Op::NRED <= RED_PTRS) {
@@ -276,6 +288,21 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out)
     const uint64_t n = ctx->shard.n_local;
     const bool in_kernel_exchange = Op::NRED > 0 && ctx->comm_kind == LBFGS_HIP_COMM_P2P;
     if (in_kernel_exchange) red.p2p = next_p2p(ctx);  // the last workgroup closes the reduction itself
+    if (Op::NRED > 0 && Op::NRED <= RED_PTRS) {
+        // totals are final inside the kernel (one rank, or in-kernel exchange): mirror them to the host
+        const bool final_in_kernel = ctx->comm_kind == LBFGS_HIP_COMM_NONE || in_kernel_exchange;
+        for (int k = 0; k < Op::NRED; ++k) {
+            const long idx = red_out[k] - ctx->board;
+            if (idx >= 0 && idx < LBFGS_HIP_BOARD_SLOTS + 2) ctx->mirror_valid[idx] = final_in_kernel && ctx->mirror;
+        }
+        if (final_in_kernel && ctx->mirror) {
+            red.mirror.host_board = ctx->mirror_dev;
+            red.mirror.board = ctx->board;
+            red.mirror.host_seq = reinterpret_cast<unsigned long long*>(ctx->mirror_dev + LBFGS_HIP_BOARD_SLOTS + 2);
+            red.mirror.seq = ++ctx->mirror_seq;
+            red.mirror.slots = LBFGS_HIP_BOARD_SLOTS + 2;
+        }
+    }
     constexpr int MAP = tuning<Op>::MAP, UNR = tuning<Op>::UNR;
     // streaming (`nt`) hints once the running vector cannot stay in the 256 MiB Infinity Cache next to the others
     const bool streaming = n * sizeof(double) >= ctx->nt_threshold_bytes;
@@ -570,6 +597,20 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     CTX_TRY(hipMalloc(&ctx->ticket, 64));
     CTX_TRY(hipMemsetAsync(ctx->ticket, 0, 64, ctx->stream));
     CTX_TRY(hipHostMalloc(&ctx->pinned, (LBFGS_HIP_BOARD_SLOTS + 1) * sizeof(double), hipHostMallocDefault));
+    if (!getenv("LBFGS_HIP_NO_MIRROR")) {
+        void* hm = nullptr;
+        if (hipHostMalloc(&hm, (LBFGS_HIP_BOARD_SLOTS + 4) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) ==
+            hipSuccess) {
+            memset(hm, 0, (LBFGS_HIP_BOARD_SLOTS + 4) * sizeof(double));
+            void* dv = nullptr;
+            if (hipHostGetDevicePointer(&dv, hm, 0) == hipSuccess) {
+                ctx->mirror = (double*)hm;
+                ctx->mirror_dev = (double*)dv;
+            } else {
+                (void)hipHostFree(hm);
+            }
+        }
+    }
     CTX_TRY(hipStreamSynchronize(ctx->stream));
 #undef CTX_TRY
 
@@ -657,6 +698,7 @@ void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* ctx) {
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->mirror) (void)hipHostFree(ctx->mirror);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -751,6 +793,33 @@ int lbfgs_hip_vec_swap(lbfgs_hip_vec* a, lbfgs_hip_vec* b) {
 int lbfgs_hip_scalars_read(lbfgs_hip_ctx* ctx, int first, int count, double* host) {
     if (!ctx || !host || !slot_ok(first, count)) return LBFGS_HIP_ERR_ARG;
     if (count == 0) return lbfgs_hip_sync(ctx);
+    if (ctx->mirror) {  // fast path: every requested slot was (or is being) published by a kernel's last workgroup
+        bool all = true;
+        for (int i = 0; i < count && all; ++i) all = ctx->mirror_valid[first + i];
+        if (all) {
+            const volatile unsigned long long* seq =
+                reinterpret_cast<volatile unsigned long long*>(ctx->mirror + LBFGS_HIP_BOARD_SLOTS + 2);
+            const unsigned long long want = ctx->mirror_seq;
+            bool ok = false;
+            for (long spin = 0; spin < 200000000L; ++spin) {  // kernels complete in order: latest seq => all earlier
+                if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) >= want) { ok = true; break; }
+                if ((spin & 1023) == 1023 && hipStreamQuery(ctx->stream) == hipSuccess) {
+                    ok = __atomic_load_n(seq, __ATOMIC_ACQUIRE) >= want;
+                    break;
+                }
+            }
+            if (ok) {
+                memcpy(host, ctx->mirror + first, count * sizeof(double));
+                if (ctx->p2p_err) {  // a timed-out exchange must not go unnoticed on the fast path either
+                    unsigned int flag = 0;
+                    HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->p2p_err, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                    if (flag) return fail(ctx, LBFGS_HIP_ERR_COMM, "P2P all-reduce timed out waiting for a peer");
+                }
+                return LBFGS_HIP_OK;
+            }
+        }
+    }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, ctx->board + first, count * sizeof(double), hipMemcpyDeviceToHost,
                                 ctx->stream));
     if (ctx->p2p_err)  // pinned[BOARD_SLOTS] is reserved for the P2P timeout flag
@@ -769,6 +838,7 @@ int lbfgs_hip_scalars_read(lbfgs_hip_ctx* ctx, int first, int count, double* hos
 int lbfgs_hip_scalars_write(lbfgs_hip_ctx* ctx, int first, int count, const double* host) {
     if (!ctx || !host || !slot_ok(first, count)) return LBFGS_HIP_ERR_ARG;
     if (count == 0) return LBFGS_HIP_OK;
+    for (int i = 0; i < count; ++i) ctx->mirror_valid[first + i] = false;
     memcpy(ctx->pinned, host, count * sizeof(double));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->board + first, ctx->pinned, count * sizeof(double), hipMemcpyHostToDevice,
                                 ctx->stream));
@@ -962,23 +1032,27 @@ int lbfgs_hip_history_update(lbfgs_hip_history* h, int slot, const lbfgs_hip_vec
     if (!slot_ok(out_slot, 7)) return LBFGS_HIP_ERR_ARG;
     double* b = ctx->board + out_slot;
     double* outs[7] = {b, b + 1, b + 2, b + 3, b + 4, b + 5, b + 6};
+    // totals final inside the kernel? (one rank, or in-kernel P2P exchange)
+    const bool single = ctx->comm_kind == LBFGS_HIP_COMM_NONE || ctx->comm_kind == LBFGS_HIP_COMM_P2P;
     int rc;
     if (damping) {
         OpHistUpdate<true> op{};
         op.in[0] = x->p; op.in[1] = xp->p; op.in[2] = g->p; op.in[3] = gp->p;
         op.out[0] = h->s[slot]->p; op.out[1] = h->y[slot]->p;
         op.neg_step = -step;
-        rc = launch(ctx, LBFGS_HIP_K_UPDATE, op, outs);
+        rc = launch(ctx, LBFGS_HIP_K_UPDATE, op, outs, single ? h->ys + slot : nullptr, 1);
     } else {
         OpHistUpdate<false> op{};
         op.in[0] = x->p; op.in[1] = xp->p; op.in[2] = g->p; op.in[3] = gp->p;
         op.out[0] = h->s[slot]->p; op.out[1] = h->y[slot]->p;
         op.neg_step = 0.0;
-        rc = launch(ctx, LBFGS_HIP_K_UPDATE, op, outs);
+        rc = launch(ctx, LBFGS_HIP_K_UPDATE, op, outs, single ? h->ys + slot : nullptr, 1);
     }
     if (rc != LBFGS_HIP_OK) return rc;
-    // lbfgs.rs:656 self.ys = ys (the GLOBAL y.s, i.e. after the all-reduce)
-    HIP_TRY(ctx, hipMemcpyAsync(h->ys + slot, b + 1, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    // lbfgs.rs:656 self.ys = ys (the GLOBAL y.s): stored by the kernel itself when its totals are final, else
+    // copied after the all-reduce
+    if (!single)
+        HIP_TRY(ctx, hipMemcpyAsync(h->ys + slot, b + 1, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     return LBFGS_HIP_OK;
 }
 

@@ -60,12 +60,26 @@ struct P2PCtl {
     unsigned long long timeout_ticks;         // wall_clock64 ticks (100 MHz)
 };
 
+// Host mirror of the scalar board: when the totals are FINAL (one rank, or closed by the in-kernel exchange)
+// the last workgroup also stores them into host-mapped memory and then bumps a sequence word, so the host
+// reads results with a short spin instead of a copy kernel + stream synchronisation.
+struct MirrorCtl {
+    double* host_board;             // device address of the host-mapped mirror (nullptr = off)
+    const double* board;            // the device board (to turn an output pointer into a slot index)
+    unsigned long long* host_seq;   // device address of the host-mapped sequence word
+    unsigned long long seq;         // this launch's sequence number
+    int slots;                      // mirrored slots
+};
+
 struct RedCtl {
     double* partials;        // [MAX_RED][MAX_GRID] workgroup partial sums
     unsigned int* ticket;    // arrival counter, self-resetting
     double* out[RED_PTRS];   // where the last workgroup puts the totals (NRED <= RED_PTRS) ...
     double* out_contig;      // ... or one contiguous array of NRED doubles (NRED > RED_PTRS)
+    double* dup_ptr;         // optional second destination of total number dup_k (ys[slot] of the history)
+    int dup_k;
     P2PCtl p2p;
+    MirrorCtl mirror;
 };
 
 __device__ __forceinline__ size_t p2p_word(unsigned epoch, int src_rank, int k, int half) {
@@ -202,7 +216,21 @@ __device__ __forceinline__ void grid_reduce(double (&acc)[NRED], const RedCtl& r
             if constexpr (NRED <= RED_PTRS) *red.out[k] = tot[k];
             else red.out_contig[k] = tot[k];
         }
+        if (red.dup_ptr) *red.dup_ptr = tot[red.dup_k < NRED ? red.dup_k : 0];
         __hip_atomic_store(red.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (NRED <= RED_PTRS) {
+            if (red.mirror.host_board) {  // publish the final totals to the host (system scope), then the sequence
+#pragma unroll
+                for (int k = 0; k < NRED; ++k) {
+                    const long idx = red.out[k] - red.mirror.board;
+                    if (idx >= 0 && idx < red.mirror.slots)
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(red.mirror.host_board + idx),
+                                           (unsigned long long)__double_as_longlong(tot[k]), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                __hip_atomic_store(red.mirror.host_seq, red.mirror.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 
