@@ -235,13 +235,25 @@ int lbfgs_hip_constrain_direction(lbfgs_hip_vec* d, const lbfgs_hip_vec* pg, uin
 enum {
     LBFGS_HIP_OBJ_QUADRATIC = 1,  /* hashed diagonal quadratic  (BASELINE.json configs 2, 4) */
     LBFGS_HIP_OBJ_LOGISTIC = 2,   /* hashed separable logistic  (config 3, with OWL-QN)      */
-    LBFGS_HIP_OBJ_ROSENBROCK = 3  /* src/lib.rs:79-94 default_evaluate (pairs must not straddle shards) */
+    LBFGS_HIP_OBJ_ROSENBROCK = 3, /* src/lib.rs:79-94 default_evaluate (pairs must not straddle shards) */
+    LBFGS_HIP_OBJ_LJ_ALLPAIRS = 4,  /* examples/lj.rs:20-64,113-118: exact all-pairs Lennard-Jones, x = 3*natoms; one rank */
+    LBFGS_HIP_OBJ_LJ_NEIGHBORS = 5  /* the same pair terms over a fixed neighbour table with a cutoff (shifted by v(rc)):
+                                       the substitute evaluator for BASELINE config 5 at 1e6 atoms; one rank */
 };
 typedef struct lbfgs_hip_objective {
     int32_t kind;
     int32_t _pad;
     uint64_t seed_a, seed_b;
+    /* LJ_NEIGHBORS: ELL table int32[max_nbr][natoms] in DEVICE memory (column-major, -1 = empty), from
+     * lbfgs_hip_device_buffer_create; cutoff rc */
+    const void* nbr_index;
+    uint32_t max_nbr;
+    uint32_t _pad2;
+    double cutoff;
 } lbfgs_hip_objective;
+/* raw device buffers for objective data (neighbour tables ...): allocate + upload; free */
+int lbfgs_hip_device_buffer_create(lbfgs_hip_ctx* ctx, const void* host, uint64_t bytes, void** out);
+void lbfgs_hip_device_buffer_destroy(lbfgs_hip_ctx* ctx, void* buf);
 /* g = grad f(x); board[out_slot] = f(x) (global sum).  1r 1w. */
 int lbfgs_hip_objective_eval(const lbfgs_hip_objective* obj, const lbfgs_hip_vec* x, lbfgs_hip_vec* g,
                              int out_slot);

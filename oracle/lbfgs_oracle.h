@@ -190,6 +190,14 @@ double oracle_obj_quadratic(void* user, const double* x, double* g, size_t n, in
 double oracle_obj_logistic(void* user, const double* x, double* g, size_t n, int* failed);
 /* Lennard-Jones all-pairs, x = 3*natoms coordinates; returns energy, g = dE/dx (examples/lj.rs:38-64,113-118) */
 double oracle_obj_lj(void* user, const double* x, double* g, size_t n, int* failed);
+/* the same pair terms over a fixed neighbour table with a cutoff (substitute evaluator, config 5) */
+typedef struct oracle_lj_nbr {
+    const int32_t* nbr;   /* int32 [max_nbr][natoms], column-major, -1 = empty */
+    uint32_t max_nbr;
+    uint32_t _pad;
+    double cutoff;
+} oracle_lj_nbr;
+double oracle_obj_lj_neighbors(void* user, const double* x, double* g, size_t n, int* failed);
 
 #ifdef __cplusplus
 }

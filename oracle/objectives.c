@@ -119,3 +119,37 @@ double oracle_obj_lj(void* user, const double* x, double* g, size_t n, int* fail
     for (size_t i = 0; i < n; ++i) g[i] *= -1.0;
     return energy;
 }
+
+/* The substitute evaluator of BASELINE config 5 (not in the reference): the pair terms of examples/lj.rs over a
+ * FIXED neighbour table (ELL, int32 [max_nbr][natoms], column-major, -1 = empty) with a cutoff rc and the energy
+ * shifted by v(rc): E = sum_{i<j, r<rc} [v(r) - v(rc)].  Every pair is listed from both ends. */
+double oracle_obj_lj_neighbors(void* user, const double* x, double* g, size_t n, int* failed) {
+    const oracle_lj_nbr* o = (const oracle_lj_nbr*)user;
+    (void)failed;
+    const size_t na = n / 3;
+    const double rc2 = o->cutoff * o->cutoff;
+    const double i6 = 1.0 / (rc2 * rc2 * rc2);
+    const double eshift = 4.0 * (i6 * i6 - i6);
+    double energy = 0.0;
+    for (size_t i = 0; i < na; ++i) {
+        double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
+        for (uint32_t k = 0; k < o->max_nbr; ++k) {
+            const int32_t j = o->nbr[(size_t)k * na + i];
+            if (j < 0) continue;
+            const double dx = x[3 * i] - x[3 * (size_t)j], dy = x[3 * i + 1] - x[3 * (size_t)j + 1],
+                         dz = x[3 * i + 2] - x[3 * (size_t)j + 2];
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            if (r2 < rc2) {
+                const double inv2 = 1.0 / r2;
+                const double s6 = inv2 * inv2 * inv2;
+                e += 4.0 * (s6 * s6 - s6);
+                const double c = 24.0 * (s6 - 2.0 * (s6 * s6)) * inv2;
+                fx += c * dx; fy += c * dy; fz += c * dz;
+                e -= eshift;
+            }
+        }
+        g[3 * i] = fx; g[3 * i + 1] = fy; g[3 * i + 2] = fz;
+        energy += 0.5 * e;
+    }
+    return energy;
+}

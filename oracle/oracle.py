@@ -252,6 +252,19 @@ def lj():
     return Builtin("oracle_obj_lj")
 
 
+class LjNbr(C.Structure):
+    _fields_ = [("nbr", C.POINTER(C.c_int32)), ("max_nbr", C.c_uint32), ("_pad", C.c_uint32), ("cutoff", C.c_double)]
+
+
+def lj_neighbors(nbr_index, cutoff):
+    """nbr_index: int32 array [max_nbr, natoms] (-1 = empty)."""
+    tab = np.ascontiguousarray(nbr_index, dtype=np.int32)
+    u = LjNbr(tab.ctypes.data_as(C.POINTER(C.c_int32)), tab.shape[0], 0, float(cutoff))
+    b = Builtin("oracle_obj_lj_neighbors", u)
+    b._keep = tab
+    return b
+
+
 def _resolve_eval(evaluate):
     """Return (callable pointer as c_void_p, user pointer, keepalive)."""
     L = lib()

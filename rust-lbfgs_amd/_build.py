@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 HIP_LIB = os.path.join(HERE, "liblbfgs_hip.so")
 SOLVER_LIB = os.path.join(HERE, "liblbfgs_solver.so")
 
-HIP_SRCS = [os.path.join(CSRC, f) for f in ("lbfgs_hip.hip", "ops.h", "stream.h", "gram.h")] + [
+HIP_SRCS = [os.path.join(CSRC, f) for f in ("lbfgs_hip.hip", "ops.h", "stream.h", "gram.h", "lj.h")] + [
     os.path.join(ROOT, "include", "lbfgs_hip.h")
 ]
 SOLVER_SRCS = [os.path.join(CSRC, "host", "solver.cpp"), os.path.join(ROOT, "include", "lbfgs_solver.h"),

@@ -23,7 +23,7 @@ HIP_ERR_ARG, HIP_ERR_HIP, HIP_ERR_COMM, HIP_ERR_NOMEM, HIP_ERR_NO_DEVICE = -101,
 LS_MORETHUENTE, LS_BT_ARMIJO, LS_BT_STRONGWOLFE, LS_BT_WOLFE = 0, 1, 2, 3
 EVAL_HOST, EVAL_DEVICE, EVAL_BUILTIN = 0, 1, 2
 COMM_NONE, COMM_RCCL, COMM_CALLBACK, COMM_P2P = 0, 1, 2, 3
-OBJ_QUADRATIC, OBJ_LOGISTIC, OBJ_ROSENBROCK = 1, 2, 3
+OBJ_QUADRATIC, OBJ_LOGISTIC, OBJ_ROSENBROCK, OBJ_LJ_ALLPAIRS, OBJ_LJ_NEIGHBORS = 1, 2, 3, 4, 5
 (K_TWOLOOP_STEP, K_TWOLOOP_EDGE, K_UPDATE, K_LINE, K_EVAL, K_OWLQN, K_BLAS1, K_COMM, K_TWOLOOP_ALL) = range(9)
 VEC_X, VEC_GX, VEC_XP, VEC_GP, VEC_PG, VEC_WP, VEC_D = range(7)
 VEC_S0, VEC_Y0 = 100, 200
@@ -44,7 +44,8 @@ class Comm(C.Structure):
 
 
 class Objective(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("seed_a", C.c_uint64), ("seed_b", C.c_uint64)]
+    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("seed_a", C.c_uint64), ("seed_b", C.c_uint64),
+                ("nbr_index", C.c_void_p), ("max_nbr", C.c_uint32), ("_pad2", C.c_uint32), ("cutoff", C.c_double)]
 
 
 class Param(C.Structure):
@@ -99,7 +100,8 @@ lbfgs_hip_history_create lbfgs_hip_history_destroy lbfgs_hip_history_s lbfgs_hip
 lbfgs_hip_history_scalars_read lbfgs_hip_history_scalars_write lbfgs_hip_history_update lbfgs_hip_history_damp
 lbfgs_hip_two_loop lbfgs_hip_two_loop_from lbfgs_hip_two_loop_gram lbfgs_hip_two_loop_unfused
 lbfgs_hip_owlqn_post_eval lbfgs_hip_orthant_select lbfgs_hip_constrain_direction
-lbfgs_hip_objective_eval lbfgs_hip_objective_line_eval
+lbfgs_hip_objective_eval lbfgs_hip_objective_line_eval lbfgs_hip_device_buffer_create
+lbfgs_hip_device_buffer_destroy
 lbfgs_hip_prof_enable lbfgs_hip_prof_reset lbfgs_hip_prof_read
 """.split()
 
@@ -168,6 +170,8 @@ def declare(L):
         "lbfgs_hip_constrain_direction": (i, [vp, vp, u64, u64, i]),
         "lbfgs_hip_objective_eval": (i, [C.POINTER(Objective), vp, vp, i]),
         "lbfgs_hip_objective_line_eval": (i, [C.POINTER(Objective), vp, vp, vp, dbl, vp, i]),
+        "lbfgs_hip_device_buffer_create": (i, [vp, vp, u64, C.POINTER(vp)]),
+        "lbfgs_hip_device_buffer_destroy": (None, [vp, vp]),
         "lbfgs_hip_prof_enable": (i, [vp, i]),
         "lbfgs_hip_prof_reset": (i, [vp]),
         "lbfgs_hip_prof_read": (i, [vp, i, C.POINTER(u64), dp]),

@@ -168,17 +168,35 @@ class BuiltinObjective:
     seed_a: int = 0
     seed_b: int = 0
     fuse_line_eval: bool = True
+    nbr_index: object = None   # LJ_NEIGHBORS: int32 [max_nbr, natoms] host table (-1 = empty), uploaded per context
+    cutoff: float = 0.0
+
+    def c_struct(self, ctx):
+        """lbfgs_hip_objective for `ctx` (uploads the neighbour table once per context and keeps it alive)."""
+        o = _ffi.Objective(self.kind, 0, self.seed_a, self.seed_b, None, 0, 0, float(self.cutoff))
+        if self.nbr_index is not None:
+            cache = self.__dict__.setdefault("_dev", {})
+            key = id(ctx)
+            if key not in cache:
+                tab = np.ascontiguousarray(self.nbr_index, dtype=np.int32)
+                buf = C.c_void_p()
+                ctx.check(ctx._L.lbfgs_hip_device_buffer_create(ctx._h, tab.ctypes.data_as(C.c_void_p), tab.nbytes,
+                                                                C.byref(buf)))
+                cache[key] = (buf, tab.shape[0], ctx)
+            buf, max_nbr, _ = cache[key]
+            o.nbr_index, o.max_nbr = buf, max_nbr
+        return o
 
 
-def _make_evaluator(evaluate):
+def _make_evaluator(evaluate, ctx=None):
     """-> (Evaluator struct, keepalive, error-holder)"""
     ev = _ffi.Evaluator()
     holder = {"exc": None}
     if isinstance(evaluate, BuiltinObjective):
         ev.kind = _ffi.EVAL_BUILTIN
         ev.fuse_line_eval = int(evaluate.fuse_line_eval)
-        ev.builtin = _ffi.Objective(evaluate.kind, 0, evaluate.seed_a, evaluate.seed_b)
-        return ev, None, holder
+        ev.builtin = evaluate.c_struct(ctx)
+        return ev, evaluate, holder
     if isinstance(evaluate, DeviceEvaluate):
         def dtramp(_user, xptr, gptr, n, stream, failed):
             try:
@@ -256,7 +274,7 @@ class LbfgsState:
         if len(x) != self.ctx.n_local:
             raise LbfgsError(_ffi.ERR_PARAM, f"x has {len(x)} elements, the context's shard {self.ctx.n_local}")
         self.m = int(param.m)
-        self._ev, self._keep, self._holder = _make_evaluator(evaluate)
+        self._ev, self._keep, self._holder = _make_evaluator(evaluate, self.ctx)
         self._h = C.c_void_p()
         p = Param()
         C.memmove(C.byref(p), C.byref(param), C.sizeof(Param))

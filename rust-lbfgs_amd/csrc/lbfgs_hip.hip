@@ -22,6 +22,7 @@
 
 #include "ops.h"
 #include "gram.h"
+#include "lj.h"
 
 using namespace lh;
 
@@ -402,6 +403,40 @@ int two_loop_step(lbfgs_hip_history* h, const double* src, const double* u, cons
 }  // namespace
 
 namespace {
+// Lennard-Jones objectives (lj.h): x holds 3*natoms coordinates of ONE rank
+int lj_eval(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, const lbfgs_hip_vec* x, lbfgs_hip_vec* g, double* out) {
+    if (ctx->shard.world != 1) return fail(ctx, LBFGS_HIP_ERR_ARG, "the LJ objectives need all atoms on one rank");
+    const uint64_t n = ctx->shard.n_local;
+    if (n % 3 != 0 || n / 3 > 0x7fffffffULL) return fail(ctx, LBFGS_HIP_ERR_ARG, "LJ needs n = 3*natoms");
+    const uint32_t natoms = (uint32_t)(n / 3);
+    RedCtl red{};
+    red.partials = ctx->partials;
+    red.ticket = ctx->ticket;
+    red.out[0] = out;
+    const long idx = out - ctx->board;
+    if (idx >= 0 && idx < LBFGS_HIP_BOARD_SLOTS + 2) ctx->mirror_valid[idx] = false;
+    {
+        ProfScope ps(ctx, LBFGS_HIP_K_EVAL);
+        if (obj->kind == LBFGS_HIP_OBJ_LJ_ALLPAIRS) {
+            const uint32_t grid = (natoms + BLOCK - 1) / BLOCK;
+            if (grid > MAX_GRID) return fail(ctx, LBFGS_HIP_ERR_ARG, "all-pairs LJ supports up to %d atoms", MAX_GRID * BLOCK);
+            hipLaunchKernelGGL(lj_allpairs_kernel, dim3(grid ? grid : 1), dim3(BLOCK), 0, ctx->stream, x->p, g->p, natoms, red);
+        } else {
+            if (!obj->nbr_index || obj->max_nbr == 0 || !(obj->cutoff > 0.0))
+                return fail(ctx, LBFGS_HIP_ERR_ARG, "LJ_NEIGHBORS needs a neighbour table and a cutoff");
+            const double rc2 = obj->cutoff * obj->cutoff;
+            const double i6 = 1.0 / (rc2 * rc2 * rc2);
+            const double eshift = 4.0 * (i6 * i6 - i6);
+            const uint32_t want = (natoms + BLOCK - 1) / BLOCK;
+            const uint32_t grid = want < (uint32_t)MAX_GRID ? want : (uint32_t)MAX_GRID;
+            hipLaunchKernelGGL(lj_neighbors_kernel, dim3(grid ? grid : 1), dim3(BLOCK), 0, ctx->stream, x->p, g->p,
+                               (const int32_t*)obj->nbr_index, obj->max_nbr, natoms, rc2, eshift, red);
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return LBFGS_HIP_OK;
+}
+
 int rosen_shape_ok(lbfgs_hip_ctx* ctx) {
     if ((ctx->shard.n_local & 1) || (ctx->shard.offset & 1))
         return fail(ctx, LBFGS_HIP_ERR_ARG, "Rosenbrock couples (x[2i], x[2i+1]): shard size and offset must be even");
@@ -1257,6 +1292,30 @@ int lbfgs_hip_constrain_direction(lbfgs_hip_vec* d, const lbfgs_hip_vec* pg, uin
 
 // ==================================================================================== objectives
 
+int lbfgs_hip_device_buffer_create(lbfgs_hip_ctx* ctx, const void* host, uint64_t bytes, void** out) {
+    if (!ctx || !out || (!host && bytes)) return LBFGS_HIP_ERR_ARG;
+    *out = nullptr;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 256);
+    if (e != hipSuccess) return fail(ctx, LBFGS_HIP_ERR_NOMEM, "hipMalloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
+    if (bytes) {
+        e = hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            return fail(ctx, LBFGS_HIP_ERR_HIP, "upload: %s", hipGetErrorString(e));
+        }
+    }
+    *out = p;
+    return LBFGS_HIP_OK;
+}
+
+void lbfgs_hip_device_buffer_destroy(lbfgs_hip_ctx* ctx, void* buf) {
+    if (!buf) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(buf);
+}
+
 int lbfgs_hip_objective_eval(const lbfgs_hip_objective* obj, const lbfgs_hip_vec* x, lbfgs_hip_vec* g, int out_slot) {
     if (!obj || !same_ctx(x, g) || !slot_ok(out_slot, 1)) return LBFGS_HIP_ERR_ARG;
     lbfgs_hip_ctx* ctx = x->ctx;
@@ -1279,6 +1338,9 @@ int lbfgs_hip_objective_eval(const lbfgs_hip_objective* obj, const lbfgs_hip_vec
             op.in[0] = x->p; op.out[0] = g->p;
             return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
         }
+        case LBFGS_HIP_OBJ_LJ_ALLPAIRS:
+        case LBFGS_HIP_OBJ_LJ_NEIGHBORS:
+            return lj_eval(ctx, obj, x, g, outs[0]);
         default:
             return fail(ctx, LBFGS_HIP_ERR_ARG, "unknown objective kind %d", obj->kind);
     }
@@ -1301,6 +1363,13 @@ int lbfgs_hip_objective_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec*
             op.in[0] = xp->p; op.in[1] = d->p; op.out[0] = x->p; op.out[1] = g->p;
             op.step = step; op.obj = {obj->seed_a, obj->seed_b};
             return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
+        }
+        case LBFGS_HIP_OBJ_LJ_ALLPAIRS:
+        case LBFGS_HIP_OBJ_LJ_NEIGHBORS: {  // gather pattern: line step, evaluate, g.d as three launches
+            int rc = lbfgs_hip_line_step(x, xp, d, step, nullptr, 0, 0);
+            if (rc != LBFGS_HIP_OK) return rc;
+            if ((rc = lj_eval(ctx, obj, x, g, outs[0])) != LBFGS_HIP_OK) return rc;
+            return lbfgs_hip_vecdot(g, d, out_slot + 1);
         }
         case LBFGS_HIP_OBJ_ROSENBROCK: {
             int rc = rosen_shape_ok(ctx);

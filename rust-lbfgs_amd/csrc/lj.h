@@ -1,0 +1,72 @@
+// rust-lbfgs_amd/csrc/lj.h -- device-resident Lennard-Jones objectives (BASELINE config 5).
+//
+// The USER objective of the reference's examples/lj.rs (epsilon = sigma = 1): E = sum_{i<j} 4 (r^-12 - r^-6),
+// gx = dE/dx (examples/lj.rs:20-64, :113-118).  Not part of the optimiser's hot path -- it is the `evaluate`
+// closure kept in HBM so that x and g never cross PCIe.  Two forms:
+//   all-pairs  exact semantics of the example, O(N^2): one thread per atom, positions staged through LDS in
+//              tiles of 256 atoms, every pair evaluated from both ends (no atomics => deterministic);
+//   neighbours a fixed ELL neighbour table (max_nbr x natoms, column-major, -1 = empty) and a cutoff:
+//              E = sum_{i<j, r<rc} [v(r) - v(rc)], the substitute evaluator for 1e6 atoms (documented deviation).
+#pragma once
+#include "stream.h"
+
+namespace lh {
+
+__device__ __forceinline__ void lj_pair(double dx, double dy, double dz, double& e, double& fx, double& fy, double& fz) {
+    const double r2 = dx * dx + dy * dy + dz * dz;
+    const double inv2 = 1.0 / r2;
+    const double s6 = inv2 * inv2 * inv2;
+    e += 4.0 * (s6 * s6 - s6);                       // pair_energy   lj.rs:22-25
+    const double c = 24.0 * (s6 - 2.0 * (s6 * s6)) * inv2;  // pair_gradient/r  lj.rs:28-32, :57-58
+    fx += c * dx; fy += c * dy; fz += c * dz;        // gx_i += g(r)/r * (x_i - x_j)
+}
+
+__global__ __launch_bounds__(BLOCK) void lj_allpairs_kernel(const double* __restrict__ x, double* __restrict__ g,
+                                                             const uint32_t natoms, const RedCtl red) {
+    __shared__ double tile[3 * BLOCK];
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = i < natoms;
+    double xi = 0, yi = 0, zi = 0;
+    if (live) { xi = x[3 * (size_t)i]; yi = x[3 * (size_t)i + 1]; zi = x[3 * (size_t)i + 2]; }
+    double e = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
+    for (uint32_t base = 0; base < natoms; base += BLOCK) {
+        const uint32_t cnt = min((uint32_t)BLOCK, natoms - base);
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < 3 * cnt; t += BLOCK) tile[t] = x[3 * (size_t)base + t];
+        __syncthreads();
+        if (live) {
+            for (uint32_t j = 0; j < cnt; ++j) {
+                if (base + j == i) continue;
+                lj_pair(xi - tile[3 * j], yi - tile[3 * j + 1], zi - tile[3 * j + 2], e, fx, fy, fz);
+            }
+        }
+    }
+    if (live) { g[3 * (size_t)i] = fx; g[3 * (size_t)i + 1] = fy; g[3 * (size_t)i + 2] = fz; }
+    double acc[1] = {0.5 * e};  // every pair was seen from both ends
+    grid_reduce<1>(acc, red);
+}
+
+__global__ __launch_bounds__(BLOCK) void lj_neighbors_kernel(const double* __restrict__ x, double* __restrict__ g,
+                                                              const int32_t* __restrict__ nbr, const uint32_t max_nbr,
+                                                              const uint32_t natoms, const double rc2, const double eshift,
+                                                              const RedCtl red) {
+    double e = 0.0;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < natoms; i += gridDim.x * BLOCK) {
+        const double xi = x[3 * (size_t)i], yi = x[3 * (size_t)i + 1], zi = x[3 * (size_t)i + 2];
+        double fx = 0.0, fy = 0.0, fz = 0.0;
+        for (uint32_t k = 0; k < max_nbr; ++k) {
+            const int32_t j = nbr[(size_t)k * natoms + i];  // coalesced across lanes
+            if (j < 0) continue;
+            const double dx = xi - x[3 * (size_t)j], dy = yi - x[3 * (size_t)j + 1], dz = zi - x[3 * (size_t)j + 2];
+            if (dx * dx + dy * dy + dz * dz < rc2) {
+                lj_pair(dx, dy, dz, e, fx, fy, fz);
+                e -= eshift;
+            }
+        }
+        g[3 * (size_t)i] = fx; g[3 * (size_t)i + 1] = fy; g[3 * (size_t)i + 2] = fz;
+    }
+    double acc[1] = {0.5 * e};
+    grid_reduce<1>(acc, red);
+}
+
+}  // namespace lh

@@ -117,15 +117,11 @@ def constrain_direction(d, pg, start, end, out_slot=13):
     d.ctx.check(d._L.lbfgs_hip_constrain_direction(d._h, pg._h, start, end, out_slot))
 
 
-def _obj(o: BuiltinObjective):
-    return _ffi.Objective(o.kind, 0, o.seed_a, o.seed_b)
-
-
 def objective_eval(obj: BuiltinObjective, x, g, out_slot=0):
-    o = _obj(obj)
+    o = obj.c_struct(x.ctx)
     x.ctx.check(x._L.lbfgs_hip_objective_eval(C.byref(o), x._h, g._h, out_slot))
 
 
 def objective_line_eval(obj: BuiltinObjective, x, xp, d, step, g, out_slot=0):
-    o = _obj(obj)
+    o = obj.c_struct(x.ctx)
     x.ctx.check(x._L.lbfgs_hip_objective_line_eval(C.byref(o), x._h, xp._h, d._h, float(step), g._h, out_slot))

@@ -23,3 +23,34 @@ def Logistic(fuse_line_eval=True):
 
 def Rosenbrock(fuse_line_eval=True):
     return BuiltinObjective(_ffi.OBJ_ROSENBROCK, 0, 0, fuse_line_eval)
+
+
+def LennardJones():
+    """examples/lj.rs:20-64,113-118: exact all-pairs LJ (epsilon = sigma = 1); x = 3*natoms coordinates; one rank."""
+    return BuiltinObjective(_ffi.OBJ_LJ_ALLPAIRS, fuse_line_eval=True)
+
+
+def LennardJonesNeighbors(nbr_index, cutoff):
+    """Substitute evaluator for BASELINE config 5 at scale: the same pair terms over a fixed neighbour table
+    (int32 [max_nbr, natoms], -1 = empty, every pair listed from both ends) with a cutoff, energy shifted by v(rc)."""
+    return BuiltinObjective(_ffi.OBJ_LJ_NEIGHBORS, fuse_line_eval=True, nbr_index=nbr_index, cutoff=float(cutoff))
+
+
+def cubic_lattice_neighbors(nside, spacing, cutoff):
+    """Neighbour table of an nside^3 simple-cubic lattice (open boundaries): every site within `cutoff` at the
+    ideal positions, so it stays valid while atoms move by less than half the skin.  -> (x0 [3*natoms], table)."""
+    import numpy as np
+
+    r = int(np.floor(cutoff / spacing))
+    offs = [(a, b, c) for a in range(-r, r + 1) for b in range(-r, r + 1) for c in range(-r, r + 1)
+            if (a, b, c) != (0, 0, 0) and (a * a + b * b + c * c) * spacing * spacing < cutoff * cutoff]
+    n = nside ** 3
+    idx = np.arange(n, dtype=np.int64)
+    ix, iy, iz = idx // (nside * nside), (idx // nside) % nside, idx % nside
+    tab = np.full((len(offs), n), -1, dtype=np.int32)
+    for k, (a, b, c) in enumerate(offs):
+        jx, jy, jz = ix + a, iy + b, iz + c
+        ok = (jx >= 0) & (jx < nside) & (jy >= 0) & (jy < nside) & (jz >= 0) & (jz < nside)
+        tab[k, ok] = ((jx * nside + jy) * nside + jz)[ok].astype(np.int32)
+    x0 = np.stack([ix, iy, iz], axis=1).astype(np.float64).reshape(-1) * spacing
+    return x0, tab

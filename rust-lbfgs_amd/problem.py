@@ -82,7 +82,7 @@ class Problem:
         if owlqn is not None:
             p.orthantwise, p.owl_c, p.owl_start = 1, owlqn.c, owlqn.start
             p.owl_end = -1 if owlqn.end is None else owlqn.end
-        self._ev, self._keep, self._holder = _make_evaluator(evaluate)
+        self._ev, self._keep, self._holder = _make_evaluator(evaluate, self.ctx)
         self._h = C.c_void_p()
         rc = L.lbfgs_problem_new(C.byref(self._h), self.ctx._h, C.byref(p), _dp(x), C.byref(self._ev))
         if rc != 0:

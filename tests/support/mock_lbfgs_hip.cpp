@@ -14,6 +14,7 @@
 // closed through the callback communicator (torch.distributed / gloo in the tests).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -312,10 +313,22 @@ static int eval_obj(const lbfgs_hip_objective* obj, lbfgs_hip_ctx* c, const doub
             if ((c->shard.n_local & 1) || (c->shard.offset & 1)) return fail(c, LBFGS_HIP_ERR_ARG, "Rosenbrock needs even shards");
             *f = oracle_obj_rosenbrock(nullptr, x, g, nl(c), &failed);
             break;
+        case LBFGS_HIP_OBJ_LJ_ALLPAIRS: *f = oracle_obj_lj(nullptr, x, g, nl(c), &failed); break;
+        case LBFGS_HIP_OBJ_LJ_NEIGHBORS: {
+            oracle_lj_nbr u2{(const int32_t*)obj->nbr_index, obj->max_nbr, 0, obj->cutoff};
+            *f = oracle_obj_lj_neighbors(&u2, x, g, nl(c), &failed);
+            break;
+        }
         default: return fail(c, LBFGS_HIP_ERR_ARG, "unknown objective");
     }
     return LBFGS_HIP_OK;
 }
+int lbfgs_hip_device_buffer_create(lbfgs_hip_ctx*, const void* host, uint64_t bytes, void** out) {
+    *out = malloc(bytes ? bytes : 1);
+    if (bytes) memcpy(*out, host, bytes);
+    return LBFGS_HIP_OK;
+}
+void lbfgs_hip_device_buffer_destroy(lbfgs_hip_ctx*, void* buf) { free(buf); }
 int lbfgs_hip_objective_eval(const lbfgs_hip_objective* obj, const lbfgs_hip_vec* x, lbfgs_hip_vec* g, int o) {
     lbfgs_hip_ctx* c = x->ctx;
     int rc = eval_obj(obj, c, x->p->data(), g->p->data(), c->board + o);

@@ -648,3 +648,78 @@ def test_device_closure_bridge_with_torch():
         assert a[:2] == b[:2]
         assert abs(a[2] - b[2]) <= 1e-9 * abs(a[2]) and abs(a[3] - b[3]) <= 1e-7 * max(a[3], 1e-9)
     assert np.max(np.abs(xh - xd)) <= 1e-8
+
+
+# ---------------------------------------------------------------------------------------------
+# device-resident Lennard-Jones objectives (BASELINE config 5)
+# ---------------------------------------------------------------------------------------------
+def _lj_cluster(natoms, seed):
+    """a jittered cubic arrangement: no two atoms closer than ~0.8 sigma"""
+    side = int(np.ceil(natoms ** (1 / 3)))
+    grid = np.array([(i, j, k) for i in range(side) for j in range(side) for k in range(side)], dtype=np.float64)[:natoms]
+    return (grid * 1.12 + np.random.default_rng(seed).uniform(-0.08, 0.08, grid.shape)).reshape(-1)
+
+
+@pytest.mark.parametrize("natoms", [2, 38, 257, 1000])
+def test_lj_allpairs_matches_oracle(natoms):
+    """examples/lj.rs:20-64,113-118 on the device against the oracle's C restatement: energy and gradient."""
+    x = _lj_cluster(natoms, natoms)
+    fo, go = O.eval_builtin(O.lj(), x)
+    with R.Context(3 * natoms) as ctx:
+        xv, gv = DeviceVec(ctx, x), DeviceVec(ctx)
+        H.objective_eval(objectives.LennardJones(), xv, gv, 0)
+        f = ctx.scalars(0)[0]
+        assert abs(f - fo) <= RTOL * max(abs(fo), 1.0)
+        assert rel(gv.to_numpy(), go) <= RTOL
+        xv.free(); gv.free()
+
+
+def test_lj_neighbors_matches_oracle_and_allpairs_limit():
+    nside, spacing, rc = 6, 1.12, 2.6
+    x0, tab = objectives.cubic_lattice_neighbors(nside, spacing, rc + 0.3)
+    x = x0 + np.random.default_rng(3).uniform(-0.05, 0.05, x0.shape)
+    fo, go = O.eval_builtin(O.lj_neighbors(tab, rc), x)
+    obj = objectives.LennardJonesNeighbors(tab, rc)
+    with R.Context(len(x)) as ctx:
+        xv, gv = DeviceVec(ctx, x), DeviceVec(ctx)
+        H.objective_eval(obj, xv, gv, 0)
+        assert abs(ctx.scalars(0)[0] - fo) <= RTOL * abs(fo)
+        assert rel(gv.to_numpy(), go) <= RTOL
+        xv.free(); gv.free()
+    # with a cutoff beyond the cluster the neighbour form is the all-pairs form minus the shifts
+    x0, tab = objectives.cubic_lattice_neighbors(3, spacing, 10.0)
+    x = x0 + np.random.default_rng(4).uniform(-0.05, 0.05, x0.shape)
+    fa, ga = O.eval_builtin(O.lj(), x)
+    fn, gn = O.eval_builtin(O.lj_neighbors(tab, 10.0), x)
+    npairs = 27 * 26 // 2
+    eshift = 4.0 * (10.0 ** -12 - 10.0 ** -6)
+    assert abs(fn - (fa - npairs * eshift)) <= 1e-9 * abs(fa) and rel(gn, ga) <= 1e-9
+
+
+def test_lj38_damped_device_objective():
+    """BASELINE config 5 (parity size) with the objective RESIDENT on the device: damped L-BFGS on an LJ cluster."""
+    x0 = _lj_cluster(38, 11)
+    cfg = lambda b: b.with_damping(True).with_max_iterations(30)
+    fields = ("niter", "neval", "fx", "gnorm", "step")
+
+    def oracle_run(mode):
+        O.lib().oracle_set_dot_mode(mode)
+        try:
+            rows, x = [], x0.copy()
+            cfg(O.lbfgs()).minimize(x, O.lj(), lambda p: rows.append(tuple(p[f] for f in fields)) and False)
+            return rows
+        finally:
+            O.lib().oracle_set_dot_mode(0)
+
+    rows_o, rows_w = oracle_run(0), oracle_run(1)
+    rows_p, xp = [], x0.copy()
+    cfg(R.lbfgs()).minimize(xp, objectives.LennardJones(), lambda p: rows_p.append((p.niter, p.neval, p.fx, p.gnorm, p.step)) and False)
+    assert len(rows_p) == len(rows_o) >= 10
+    floor = 0.0
+    for a, w, b in zip(rows_o, rows_w, rows_p):
+        if a[:2] != w[:2]:
+            break
+        floor = max(floor, max(abs(u - v) / max(abs(u), 1e-3) for u, v in zip(a[2:], w[2:])))
+        assert a[:2] == b[:2]
+        for u, v in zip(a[2:], b[2:]):
+            assert abs(u - v) <= max(1e-10, 50.0 * floor) * max(abs(u), 1e-3), (a, b, floor)
