@@ -333,6 +333,8 @@ struct GramArgs {
     const double* rows;    // 3 x nb in POSITION order of the rows kernel
     double* delta;         // nb coefficients out (basis order)
     double* alpha;         // history alpha[m] (kept for API parity, lbfgs.rs:587)
+    const double* ys;      // history ys[m]: the STORED y.s (lbfgs.rs:656) -- under Powell damping it is the
+                           // pre-damping value and differs from the Gram entry of the damped y
     const double *gnum, *gden;
     int m, bound;
     int row_basis[3];                 // basis index of the three refreshed rows
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(64) void gram_coef_kernel(const GramArgs a) {
             const int j = a.order[it];
             double dot = 0.0;
             for (int t = 0; t < nb; ++t) dot += G[j * nb + t] * delta[t];        // s_j . q
-            const double al = dot / G[j * nb + (m + j)];                          // / ys_j
+            const double al = dot / a.ys[j];                                      // / ys_j (stored, lbfgs.rs:587)
             alpha[j] = al;
             delta[m + j] = delta[m + j] + (-al);                                  // q -= alpha*y_j
         }
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(64) void gram_coef_kernel(const GramArgs a) {
             const int j = a.order[it];
             double dot = 0.0;
             for (int t = 0; t < nb; ++t) dot += G[(m + j) * nb + t] * delta[t];  // y_j . q
-            const double beta = dot / G[j * nb + (m + j)];
+            const double beta = dot / a.ys[j];                                    // lbfgs.rs:597
             delta[j] = delta[j] + (alpha[j] - beta);                              // q += (alpha-beta)*s_j
         }
         for (int t = 0; t < nb; ++t) a.delta[t] = delta[t];
@@ -502,7 +504,7 @@ int two_loop_gram_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
         if (rc != LBFGS_HIP_OK) return rc;
     }
     // scalar recursion on the coefficients
-    ga.G = h->gram; ga.rows = h->gram_rows; ga.delta = h->gram_delta; ga.alpha = h->alpha;
+    ga.G = h->gram; ga.rows = h->gram_rows; ga.delta = h->gram_delta; ga.alpha = h->alpha; ga.ys = h->ys;
     ga.gnum = gnum; ga.gden = gden; ga.m = M; ga.bound = bound;
     ga.row_basis[0] = end; ga.row_basis[1] = M + end; ga.row_basis[2] = 2 * M;
     for (int i = 0; i < bound; ++i) ga.order[i] = ((e1 - 1 - i) % M + M) % M;

@@ -446,7 +446,7 @@ def test_two_loop_gram_vs_oracle_over_a_run(n, m):
     assert worst <= RTOL
 
 
-@pytest.mark.parametrize("case", ["quadratic_m7", "rosen_m10", "logistic_owlqn"])
+@pytest.mark.parametrize("case", ["quadratic_m7", "rosen_m10", "logistic_owlqn", "quadratic_damped"])
 def test_vector_free_runs_match_exact_runs(case):
     """Whole runs with with_vector_free(True) against the exact recursion on the same device."""
     cfg = {
@@ -454,6 +454,10 @@ def test_vector_free_runs_match_exact_runs(case):
         "rosen_m10": (lambda b: b.with_m(10).with_max_iterations(30), objectives.Rosenbrock, P.rosenbrock_x0(1000)),
         "logistic_owlqn": (lambda b: b.with_orthantwise(0.5, 0, None).with_max_iterations(25), objectives.Logistic,
                            np.zeros(4096)),
+        # regression (found by the random sweep): under Powell damping the recursion divides by the STORED,
+        # pre-damping ys (lbfgs.rs:656 before :680), not by the Gram entry of the damped y
+        "quadratic_damped": (lambda b: b.with_m(5).with_damping(True).with_linesearch_algorithm("BacktrackingStrongWolfe")
+                             .with_max_iterations(25), objectives.Quadratic, 3.0 * np.random.default_rng(2).standard_normal(2000)),
     }[case]
     rows = {}
     for vf in (False, True):
@@ -723,3 +727,40 @@ def test_lj38_damped_device_objective():
         assert a[:2] == b[:2]
         for u, v in zip(a[2:], b[2:]):
             assert abs(u - v) <= max(1e-10, 50.0 * floor) * max(abs(u), 1e-3), (a, b, floor)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_configurations_match_oracle(seed):
+    """The seeded random sweep of tests/fuzz_common.py on the HIP path: same error code, same discrete decisions
+    (neval, ncall) and values within the run's calibrated tolerance (20x the oracle's own sensitivity to the
+    summation order, floor 1e-10) for as long as the oracle itself is insensitive to that order."""
+    from tests import fuzz_common as F
+
+    c = F.make_case(seed)
+    ro, xo, eo = F.run_oracle(c, 0)
+    rw, _, ew = F.run_oracle(c, 1)
+    for vf in (False, True):
+        c["vector_free"] = vf
+        rp, xp, ep = F.run_product(R, objectives, c)
+        stable = eo == ew and len(ro) == len(rw)
+        floor = 0.0
+        f0 = max(abs(ro[0][3]), 1e-3) if ro else 1.0
+        g0 = max(ro[0][5], 1e-6) if ro else 1.0
+        for i, (a, w) in enumerate(zip(ro, rw)):
+            if a[:3] != w[:3]:
+                stable = False
+                break
+            scale = (max(abs(a[3]), 1e-6 * f0), max(a[4], 1e-300), max(a[5], 1e-6 * g0), abs(a[6]))
+            floor = max(floor, max(abs(u - v) / s for u, v, s in zip(a[3:], w[3:], scale)))
+            if floor > 1e-8:  # the run has become chaotic for ANY summation order: stop comparing
+                stable = False
+                break
+            assert i < len(rp), (c, "product stopped early", ep)
+            b = rp[i]
+            assert a[:3] == b[:3], (c, a, b)
+            tol = max(1e-10, 20.0 * floor) * (50.0 if vf else 1.0)
+            for u, v, s in zip(a[3:], b[3:], scale):
+                assert abs(u - v) <= tol * s, (c, i, a, b, floor)
+        if stable:
+            assert ep == eo, (c, eo, ep)
+            assert len(rp) == len(ro)

@@ -276,3 +276,17 @@ def test_problem_and_linesearch_public_api():
         po = so.propagate()
         assert (ncall, step, prb.fx) == (po["ncall"], po["step"], po["fx"])
         so.close()
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_configurations_match_oracle_exactly(seed):
+    """Seeded random (n, m, line search, damping, OWL-QN range, step clamp, h0, gtol, max_linesearch, objective):
+    host logic on the CPU test double == oracle, bit for bit, including WHICH error ends the run."""
+    from tests import fuzz_common as F
+
+    c = F.make_case(seed)
+    ro, xo, eo = F.run_oracle(c)
+    rp, xp, ep = F.run_product(R, objectives, c)
+    assert eo == ep, (c, eo, ep)
+    assert ro == rp, c
+    assert np.array_equal(xo, xp), c
