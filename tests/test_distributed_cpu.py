@@ -35,7 +35,14 @@ assert ctx.n_local == hi - lo and ctx.shard.offset == lo
 b = R.lbfgs().with_m(case["m"]).with_max_iterations(case["iters"]).with_epsilon(0.0)
 if case.get("owl"):
     b = b.with_orthantwise(*case["owl"])
-if case["objective"] == "quadratic":
+if case["objective"] == "fuzz":
+    from tests import fuzz_common as F
+    fc = case["fuzz"]
+    b = F.configure(R.lbfgs(), fc)
+    if fc.get("vector_free") and fc["m"] <= 10:
+        b = b.with_vector_free(True)
+    ev = {"quadratic": objectives.Quadratic, "logistic": objectives.Logistic, "rosenbrock": objectives.Rosenbrock}[fc["kind"]]()
+elif case["objective"] == "quadratic":
     ev = objectives.Quadratic()
 elif case["objective"] == "logistic":
     ev = objectives.Logistic()
@@ -48,17 +55,27 @@ else:
         return float(np.sum(0.5 * a * (x - 0.5) ** 2))
 rows = []
 x = np.zeros(ctx.n_local)
-st = b.build(x, ev, ctx=ctx)
-while not st.is_converged():
-    p = st.propagate()
-    rows.append([p.niter, p.neval, p.ncall, p.fx, p.xnorm, p.gnorm, p.step])
-xs = st.download("x")
-st.close()
+err = 0
+if case["objective"] == "fuzz":
+    x = F.x0_of(fc)[lo:hi].copy()
+try:
+    st = b.build(x, ev, ctx=ctx)
+    try:
+        while not st.is_converged():
+            p = st.propagate()
+            rows.append([p.niter, p.neval, p.ncall, p.fx, p.xnorm, p.gnorm, p.step])
+    except R.LbfgsError as e:
+        err = e.code
+    xs = st.download("x")
+    st.close()
+except R.LbfgsError as e:
+    err = e.code
+    xs = x
 nred, _ = ctx.prof_read(_ffi.K_COMM)   # the test double counts its all-reduces here
 if os.environ.get("LBFGS_WORKER_PRODUCT") == "1":
     nred = 1
 ctx.close()
-out = dict(rank=rank, lo=lo, hi=hi, rows=rows, x=xs.tolist(), allreduces=nred)
+out = dict(rank=rank, lo=lo, hi=hi, rows=rows, x=xs.tolist(), allreduces=nred, err=err)
 json.dump(out, open(os.path.join(os.environ["LBFGS_OUT"], f"rank{rank}.json"), "w"))
 dist.barrier()
 dist.destroy_process_group()
@@ -146,3 +163,47 @@ def test_shard_range_properties():
                 if hi > lo:  # non-empty shards start on a 256-element (2 KiB) boundary
                     assert lo % 256 == 0 and (hi % 256 == 0 or hi == n)
     assert shard_range(10**8, 7, 8) == (87501568, 100000000)
+
+
+@pytest.mark.parametrize("seed", [3, 7, 12, 21, 33])
+def test_random_configurations_two_ranks(seed, tmp_path):
+    """The seeded random sweep (tests/fuzz_common.py) SHARDED over two gloo ranks against the single-rank oracle:
+    same error code and discrete decisions, values within the run's calibrated tolerance."""
+    compare_sharded_fuzz(seed, tmp_path, vector_free=False)
+
+
+def compare_sharded_fuzz(seed, tmp_path, vector_free):
+    from tests import fuzz_common as F
+
+    c = F.make_case(seed)
+    c["n"] = max(c["n"], 600)  # two non-empty shards (boundaries are multiples of 256)
+    if c["kind"] == "rosenbrock":
+        c["n"] -= c["n"] % 2
+    c["vector_free"] = vector_free
+    ro, xo, eo = F.run_oracle(c, 0)
+    rw, _, ew = F.run_oracle(c, 1)
+    outs = run_world(dict(name=f"fuzz{seed}", n=c["n"], m=c["m"], iters=c["iters"], objective="fuzz", fuzz=c), 2, tmp_path)
+    assert outs[0]["rows"] == outs[1]["rows"] and outs[0]["err"] == outs[1]["err"]
+    rp, ep = outs[0]["rows"], outs[0]["err"]
+    stable = eo == ew and len(ro) == len(rw)
+    floor = 0.0
+    f0 = max(abs(ro[0][3]), 1e-3) if ro else 1.0
+    g0 = max(ro[0][5], 1e-6) if ro else 1.0
+    for i, (a, w) in enumerate(zip(ro, rw)):
+        if tuple(a[:3]) != tuple(w[:3]):
+            stable = False
+            break
+        scale = (max(abs(a[3]), 1e-6 * f0), max(a[4], 1e-300), max(a[5], 1e-6 * g0), abs(a[6]))
+        floor = max(floor, max(abs(u - v) / s_ for u, v, s_ in zip(a[3:], w[3:], scale)))
+        if floor > 1e-8:
+            stable = False
+            break
+        assert i < len(rp), (c, "sharded run stopped early", ep)
+        b = rp[i]
+        assert list(a[:3]) == list(b[:3]), (c, a, b)
+        tol = max(1e-10, 20.0 * floor) * (50.0 if vector_free else 1.0)
+        for u, v, s_ in zip(a[3:], b[3:], scale):
+            assert abs(u - v) <= tol * s_, (c, i, a, b, floor)
+    if stable:
+        assert ep == eo, (c, eo, ep)
+        assert len(rp) == len(ro)

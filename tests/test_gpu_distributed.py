@@ -11,7 +11,7 @@ import pytest
 import rust_lbfgs_amd as R
 from rust_lbfgs_amd import _ffi
 from rust_lbfgs_amd.math import DeviceVec
-from tests.test_distributed_cpu import oracle_rows, run_world
+from tests.test_distributed_cpu import compare_sharded_fuzz, oracle_rows, run_world
 from tests.test_gpu_parity import product_library  # noqa: F401
 
 pytestmark = pytest.mark.gpu
@@ -60,3 +60,13 @@ def test_rccl_single_rank_communicator():
         assert x.vec2norm() == np.sqrt(4.0 * n)
         nred, ms = ctx.prof_read(_ffi.K_COMM)
         x.free(); y.free()
+
+
+@pytest.mark.parametrize("seed,vector_free", [(3, False), (12, True), (33, False), (41, True)])
+def test_random_configurations_two_processes_p2p(seed, vector_free, tmp_path, monkeypatch):
+    """Random configurations sharded over two processes on one GPU with the in-kernel P2P exchange."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("covered by tests/test_distributed_cpu.py")
+    monkeypatch.setenv("LBFGS_WORKER_PRODUCT", "1")
+    monkeypatch.setenv("LBFGS_COMM_KIND", "p2p")
+    compare_sharded_fuzz(seed, tmp_path, vector_free)
