@@ -193,6 +193,19 @@ int main(int argc, char** argv) {
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             printf("20 dependent step kernels at n=%llu: %.1f us each\n", (unsigned long long)b.n, ms * 1000 / 20);
         }
+        {   // the same chain without a reduction (axpy with a device coefficient): launch + ramp only
+            OpAxpy ax{};
+            ax.in[0] = b.q; ax.in[1] = b.u; ax.out[0] = b.q; ax.c_host = 0.0; ax.c_dev = b.board;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipEventRecord(e0, 0));
+                for (int i = 0; i < 20; ++i)
+                    hipLaunchKernelGGL((stream_kernel<OpAxpy, 2, 0u, 0u, 1, 1>), dim3(216), dim3(BLOCK), 0, 0, ax, b.n, 0, red);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("20 dependent axpy kernels (no reduction) at n=%llu: %.1f us each\n", (unsigned long long)b.n, ms * 1000 / 20);
+            }
+        }
         return 0;
     }
     // 22 vectors for the Gram kernels
