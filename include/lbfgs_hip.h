@@ -199,6 +199,12 @@ int lbfgs_hip_two_loop(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
  * lbfgs_hip_history_update left at out_slot+6 for the slot `end` and this `g`): 8*bound - 1 passes */
 int lbfgs_hip_two_loop_from(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
                             int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end);
+/* two-loop under OWL-QN with constrain_search_direction (orthantwise.rs:140-161, lbfgs.rs:554) folded into the
+ * last step, which streams pg anyway:  board[dnorm_slot+0] = ||d||^2 BEFORE the projection (lbfgs.rs:543),
+ * +2 = ||d||^2 after it (caller asserts != 0), +3 = pg.d after it (the next dginit, core.rs:90); +1 unused. */
+int lbfgs_hip_two_loop_owlqn(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* pg, uint64_t k, int end,
+                             int gamma_num_slot, int gamma_den_slot, int dnorm_slot, uint64_t start, uint64_t end_,
+                             int* new_end);
 /* EXTENSION: the same recursion in the coefficient space of the basis [s_j.., y_j.., g]
  * ("vector-free" L-BFGS): one pass refreshes the three changed rows of the Gram matrix B^T B, a scalar
  * kernel runs lbfgs.rs:582-601 on 2m+1 coefficients, one pass forms d.  4m+3 passes and 2 all-reduces
@@ -261,6 +267,13 @@ int lbfgs_hip_objective_eval(const lbfgs_hip_objective* obj, const lbfgs_hip_vec
  *   x = xp + step*d ; g = grad f(x) ; board[out_slot] = f(x) ; board[out_slot+1] = g.d.   2r 2w. */
 int lbfgs_hip_objective_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
                                   const lbfgs_hip_vec* d, double step, lbfgs_hip_vec* g, int out_slot);
+
+/* one OWL-QN line-search trial in ONE pass (line.rs:740-743): take_line_step with the orthant projection
+ * (core.rs:155-164), evaluate (core.rs:119-126) incl. x1norm and the pseudo-gradient, dg_unchecked:
+ *   board[out_slot+0] = f(x), +1 = g.d, +2 = sum c*|x| on [start,end), +3 = ||pg||^2, +4 = ||x||^2.   3r 3w */
+int lbfgs_hip_objective_owlqn_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
+                                        const lbfgs_hip_vec* d, double step, const lbfgs_hip_vec* wp, lbfgs_hip_vec* g,
+                                        lbfgs_hip_vec* pg, double c, uint64_t start, uint64_t end, int out_slot);
 
 /* ------------------------------------------------------------------------- */
 /* measurement                                                                 */

@@ -98,9 +98,10 @@ lbfgs_hip_vecdiff lbfgs_hip_vec2norm_sq
 lbfgs_hip_line_step lbfgs_hip_norms_sq
 lbfgs_hip_history_create lbfgs_hip_history_destroy lbfgs_hip_history_s lbfgs_hip_history_y
 lbfgs_hip_history_scalars_read lbfgs_hip_history_scalars_write lbfgs_hip_history_update lbfgs_hip_history_damp
-lbfgs_hip_two_loop lbfgs_hip_two_loop_from lbfgs_hip_two_loop_gram lbfgs_hip_two_loop_unfused
+lbfgs_hip_two_loop lbfgs_hip_two_loop_from lbfgs_hip_two_loop_owlqn lbfgs_hip_two_loop_gram lbfgs_hip_two_loop_unfused
 lbfgs_hip_owlqn_post_eval lbfgs_hip_orthant_select lbfgs_hip_constrain_direction
-lbfgs_hip_objective_eval lbfgs_hip_objective_line_eval lbfgs_hip_device_buffer_create
+lbfgs_hip_objective_eval lbfgs_hip_objective_line_eval lbfgs_hip_objective_owlqn_line_eval
+lbfgs_hip_device_buffer_create
 lbfgs_hip_device_buffer_destroy
 lbfgs_hip_prof_enable lbfgs_hip_prof_reset lbfgs_hip_prof_read
 """.split()
@@ -163,6 +164,7 @@ def declare(L):
         "lbfgs_hip_history_damp": (i, [vp, i, vp, dbl, dbl]),
         "lbfgs_hip_two_loop": (i, [vp, vp, vp, u64, i, i, i, i, C.POINTER(i)]),
         "lbfgs_hip_two_loop_from": (i, [vp, vp, vp, u64, i, i, i, i, i, C.POINTER(i)]),
+        "lbfgs_hip_two_loop_owlqn": (i, [vp, vp, vp, u64, i, i, i, i, u64, u64, C.POINTER(i)]),
         "lbfgs_hip_two_loop_gram": (i, [vp, vp, vp, u64, i, i, i, i, C.POINTER(i)]),
         "lbfgs_hip_two_loop_unfused": (i, [vp, vp, u64, i, i, i, C.POINTER(i)]),
         "lbfgs_hip_owlqn_post_eval": (i, [vp, vp, vp, dbl, u64, u64, i]),
@@ -170,6 +172,7 @@ def declare(L):
         "lbfgs_hip_constrain_direction": (i, [vp, vp, u64, u64, i]),
         "lbfgs_hip_objective_eval": (i, [C.POINTER(Objective), vp, vp, i]),
         "lbfgs_hip_objective_line_eval": (i, [C.POINTER(Objective), vp, vp, vp, dbl, vp, i]),
+        "lbfgs_hip_objective_owlqn_line_eval": (i, [C.POINTER(Objective), vp, vp, vp, dbl, vp, vp, vp, dbl, u64, u64, i]),
         "lbfgs_hip_device_buffer_create": (i, [vp, vp, u64, C.POINTER(vp)]),
         "lbfgs_hip_device_buffer_destroy": (None, [vp, vp]),
         "lbfgs_hip_prof_enable": (i, [vp, i]),

@@ -297,6 +297,23 @@ int trial(lbfgs_state* st, double t, bool want_dg, double* dg_out) {
         st->neval += 1;
         return LBFGS_OK;
     }
+    if (st->eval.kind == LBFGS_EVAL_BUILTIN && st->eval.fuse_line_eval && st->owlqn()) {
+        // OWL-QN trial in one pass: projected line step + evaluate + x1norm + pseudo-gradient (+ g.d)
+        TRY(owl_range(st));
+        TRYB(st, lbfgs_hip_objective_owlqn_line_eval(&st->eval.builtin, st->x, st->xp, st->d, t, st->wp, st->gx, st->pg,
+                                                     st->vars.owl_c, st->owl_start, st->owl_end, S_F));
+        double b[5];
+        TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_F, 5, b));
+        st->fx = b[S_F];
+        st->fx += b[S_L1];  // core.rs:124
+        st->gnorm2 = b[S_PGN2];
+        st->xnorm2 = b[S_XN2_OWL];
+        st->norms_valid = true;
+        if (dg_out) *dg_out = b[S_DG];
+        st->neval += 1;
+        st->evaluated = true;
+        return LBFGS_OK;
+    }
     TRYB(st, lbfgs_hip_line_step(st->x, st->xp, st->d, t, st->owlqn() ? st->wp : nullptr, st->owl_start,
                                  st->owl_end));  // core.rs:155-164
     return evaluate_here(st, want_dg, dg_out);
@@ -760,13 +777,19 @@ int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
         }
     }
     int new_end = st->end;
+    bool projected = false;  // constrain_search_direction already applied by the two-loop's last step?
     if (st->vars.vector_free)
         TRYB(st, lbfgs_hip_two_loop_gram(st->hist, st->d, st->grad_for_direction(), st->k - 1, st->end, S_UPD + 1,
                                          S_UPD + 2, S_DNORM2, &new_end));
-    else  // without OWL-QN and damping the update kernel already summed s_new.(-g): start from it
+    else if (st->owlqn()) {  // :554 folded into the last step (it streams pg anyway); slots S_DNORM2C follow S_DNORM2
+        static_assert(S_DNORM2C == S_DNORM2 + 2, "two_loop_owlqn writes 4 adjacent slots");
+        TRYB(st, lbfgs_hip_two_loop_owlqn(st->hist, st->d, st->pg, st->k - 1, st->end, S_UPD + 1, S_UPD + 2, S_DNORM2,
+                                          st->owl_start, st->owl_end, &new_end));
+        projected = true;
+    } else  // without OWL-QN the update kernel already summed s_new.(-g): start from it
         TRYB(st, lbfgs_hip_two_loop_from(st->hist, st->d, st->grad_for_direction(), st->k - 1, st->end, S_UPD + 1,
                                          S_UPD + 2, S_DNORM2, st->owlqn() ? -1 : S_UPD + 6, &new_end));
-    if (st->owlqn())  // :554, orthantwise.rs:140-161 (after dnorm, as in the reference)
+    if (st->owlqn() && !projected)  // :554, orthantwise.rs:140-161 (after dnorm, as in the reference)
         TRYB(st, lbfgs_hip_constrain_direction(st->d, st->pg, st->owl_start, st->owl_end, S_DNORM2C));
     TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_UPD, S_END_BLOCK - S_UPD, u));
     if (!early) TRY(check_update());

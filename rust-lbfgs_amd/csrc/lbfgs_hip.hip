@@ -389,7 +389,7 @@ namespace {
 template <bool NEG_SRC, bool SCALE, int VMODE>
 int two_loop_step(lbfgs_hip_history* h, const double* src, const double* u, const double* v, double* dst,
                   const double* dot_in, int j, int mode_b, const double* gnum, const double* gden, double* out,
-                  int kclass) {
+                  int kclass, uint64_t owl_start = 0, uint64_t owl_end = 0) {
     OpTwoLoopStep<NEG_SRC, SCALE, VMODE> op{};
     op.in[0] = src; op.in[1] = u; op.in[2] = v;
     op.out[0] = dst;
@@ -399,7 +399,9 @@ int two_loop_step(lbfgs_hip_history* h, const double* src, const double* u, cons
     op.gamma_num = gnum;
     op.gamma_den = gden;
     op.mode_b = mode_b;
-    double* outs[2] = {out, out + 1};  // VMODE 2 produces two adjacent sums
+    op.owl_start = owl_start;
+    op.owl_end = owl_end;
+    double* outs[4] = {out, out + 1, out + 2, out + 3};  // VMODE 2 / 3 produce 2 / 4 adjacent sums
     return launch(h->ctx, kclass, op, outs);
 }
 }  // namespace
@@ -523,6 +525,10 @@ int two_loop_gram_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
     return launch(ctx, LBFGS_HIP_K_TWOLOOP_STEP, cmb, outs2);
 }
 }  // namespace
+
+static int two_loop_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
+                         int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end,
+                         bool owl, uint64_t owl_start, uint64_t owl_end);
 
 // ==================================================================================== context
 extern "C" {
@@ -1112,6 +1118,21 @@ int lbfgs_hip_two_loop(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
 
 int lbfgs_hip_two_loop_from(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
                             int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end) {
+    return two_loop_impl(h, d, g, k, end, gamma_num_slot, gamma_den_slot, dnorm_slot, first_dot_slot, new_end, false, 0, 0);
+}
+
+int lbfgs_hip_two_loop_owlqn(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* pg, uint64_t k, int end,
+                             int gamma_num_slot, int gamma_den_slot, int dnorm_slot, uint64_t start, uint64_t end_,
+                             int* new_end) {
+    if (!slot_ok(dnorm_slot, 4)) return LBFGS_HIP_ERR_ARG;
+    return two_loop_impl(h, d, pg, k, end, gamma_num_slot, gamma_den_slot, dnorm_slot, -1, new_end, true, start, end_);
+}
+
+}  // extern "C"
+
+static int two_loop_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
+                         int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end,
+                         bool owl, uint64_t owl_start, uint64_t owl_end) {
     if (first_dot_slot >= 0 && !slot_ok(first_dot_slot, 1)) return LBFGS_HIP_ERR_ARG;
     if (!h || !d || !g || d->ctx != h->ctx || g->ctx != h->ctx || end < 0 || end >= h->m || !new_end)
         return LBFGS_HIP_ERR_ARG;
@@ -1131,7 +1152,9 @@ int lbfgs_hip_two_loop_from(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_
         OpScaleDevNorm op{};
         op.in[0] = g->p; op.out[0] = d->p; op.gn = gnum; op.gd = gden;
         double* outs[2] = {dn, dn + 1};
-        return launch(ctx, LBFGS_HIP_K_TWOLOOP_EDGE, op, outs);
+        int rc0 = launch(ctx, LBFGS_HIP_K_TWOLOOP_EDGE, op, outs);
+        if (rc0 != LBFGS_HIP_OK || !owl) return rc0;
+        return lbfgs_hip_constrain_direction(d, g, owl_start, owl_end, dnorm_slot + 2);
     }
     // slot visited at first-loop step i (i = 0..bound-1): j_i = (e1 - 1 - i) mod m   (lbfgs.rs:583)
     auto jat = [&](int i) { return ((e1 - 1 - i) % m + m) % m; };
@@ -1186,9 +1209,14 @@ int lbfgs_hip_two_loop_from(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_
         cur = dots + pp;
     }
     // last step: q += (alpha_{j0} - beta_{j0}) s_{j0} ; ||d||^2 (lbfgs.rs:543) and g.d (core.rs:78-92)   3r 1w
+    if (owl)  // ... plus the orthant projection of d and the post-projection ||d||^2, pg.d (orthantwise.rs:140-161)
+        return two_loop_step<false, false, 3>(h, d->p, h->s[jat(0)]->p, g->p, d->p, cur, jat(0), 1, gnum, gden, dn,
+                                              LBFGS_HIP_K_TWOLOOP_EDGE, owl_start, owl_end);
     return two_loop_step<false, false, 2>(h, d->p, h->s[jat(0)]->p, g->p, d->p, cur, jat(0), 1, gnum, gden, dn,
                                           LBFGS_HIP_K_TWOLOOP_EDGE);
 }
+
+extern "C" {
 
 // Unfused reference sequence (lbfgs.rs:582-601 as written: dot, axpy, ..., scale, dot, axpy, ...)
 
@@ -1383,6 +1411,38 @@ int lbfgs_hip_objective_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec*
         }
         default:
             return fail(ctx, LBFGS_HIP_ERR_ARG, "unknown objective kind %d", obj->kind);
+    }
+}
+
+int lbfgs_hip_objective_owlqn_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
+                                        const lbfgs_hip_vec* d, double step, const lbfgs_hip_vec* wp, lbfgs_hip_vec* g,
+                                        lbfgs_hip_vec* pg, double c, uint64_t start, uint64_t end, int out_slot) {
+    if (!obj || !same_ctx(x, xp) || !same_ctx(x, d) || !same_ctx(x, wp) || !same_ctx(x, g) || !same_ctx(x, pg) ||
+        !slot_ok(out_slot, 5))
+        return LBFGS_HIP_ERR_ARG;
+    lbfgs_hip_ctx* ctx = x->ctx;
+    double* b = ctx->board + out_slot;
+    double* outs[5] = {b, b + 1, b + 2, b + 3, b + 4};
+    switch (obj->kind) {
+        case LBFGS_HIP_OBJ_QUADRATIC: {
+            OpObjOwlLineEval<ObjQuadratic> op{};
+            op.in[0] = xp->p; op.in[1] = d->p; op.in[2] = wp->p; op.out[0] = x->p; op.out[1] = g->p; op.out[2] = pg->p;
+            op.step = step; op.c = c; op.start = start; op.end = end; op.obj = {obj->seed_a, obj->seed_b};
+            return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
+        }
+        case LBFGS_HIP_OBJ_LOGISTIC: {
+            OpObjOwlLineEval<ObjLogistic> op{};
+            op.in[0] = xp->p; op.in[1] = d->p; op.in[2] = wp->p; op.out[0] = x->p; op.out[1] = g->p; op.out[2] = pg->p;
+            op.step = step; op.c = c; op.start = start; op.end = end; op.obj = {obj->seed_a, obj->seed_b};
+            return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
+        }
+        default: {  // objectives without a fused form: the three separate passes
+            int rc = lbfgs_hip_line_step(x, xp, d, step, wp, start, end);
+            if (rc != LBFGS_HIP_OK) return rc;
+            if ((rc = lbfgs_hip_objective_eval(obj, x, g, out_slot)) != LBFGS_HIP_OK) return rc;
+            if ((rc = lbfgs_hip_owlqn_post_eval(x, g, pg, c, start, end, out_slot + 2)) != LBFGS_HIP_OK) return rc;
+            return lbfgs_hip_vecdot(g, d, out_slot + 1);
+        }
     }
 }
 

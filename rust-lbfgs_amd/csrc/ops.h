@@ -168,6 +168,9 @@ struct OpTwoLoopFirst {
 //   VMODE 1: w = u  (gamma transition)    (2r 1w)
 //   VMODE 2: w = q  (last step): sums ||d||^2 AND g.d, the next line search's dginit
 //            (core.rs:78-92), reading g as the third stream                      (3r 1w)
+//   VMODE 3: VMODE 2 under OWL-QN: the third stream is pg; ||d||^2 is summed BEFORE the orthant projection
+//            (lbfgs.rs:543 precedes :554), then d_i = 0 where signum(d_i) != signum(-pg_i) on [start,end)
+//            (orthantwise.rs:140-161), and ||d||^2, pg.d of the projected direction are summed too   (3r 1w)
 // The coefficient is formed on the device from the previous reduction (no host round trip):
 //   mode A (first loop, lbfgs.rs:587-589):  alpha_j = dot/ys_j ; c = -alpha_j   (alpha_j is stored)
 //   mode B (second loop, lbfgs.rs:597-599): beta = dot/ys_j ;    c = alpha_j - beta
@@ -176,9 +179,9 @@ struct TwoLoopCoef {
 };
 template <bool NEG_SRC, bool SCALE, int VMODE>
 struct OpTwoLoopStep {
-    static constexpr int NIN = (VMODE == 1) ? 2 : 3, NOUT = 1, NRED = (VMODE == 2) ? 2 : 1;
+    static constexpr int NIN = (VMODE == 1) ? 2 : 3, NOUT = 1, NRED = (VMODE == 2) ? 2 : (VMODE == 3 ? 4 : 1);
     // measured best for the 3r+1w shape on MI355X: fine grid-stride, 2 chunks in flight per stream
-    static constexpr int TUNE_MAP = (VMODE == 1) ? DEFAULT_MAP : 1, TUNE_UNROLL = (VMODE == 1) ? UNROLL : 2;
+    static constexpr int TUNE_MAP = (VMODE == 1) ? DEFAULT_MAP : 1, TUNE_UNROLL = (VMODE == 1) ? UNROLL : 2;  // 3r+1w shapes
     const double* in[3];  // src, u, v (VMODE 2: g)
     double* out[1];       // dst (= d)
     const double* dot_in; // previous reduction (global sum)
@@ -187,6 +190,7 @@ struct OpTwoLoopStep {
     const double* gamma_num;
     const double* gamma_den;
     int mode_b;
+    uint64_t owl_start, owl_end;  // VMODE 3 only
     typedef TwoLoopCoef Coef;
     __device__ Coef setup() const {
         Coef cf;
@@ -200,14 +204,19 @@ struct OpTwoLoopStep {
         cf.gamma = SCALE ? (*gamma_num / *gamma_den) : 1.0;  // lbfgs.rs:691 ys/yy
         return cf;
     }
-    __device__ void elem(const Coef& cf, const double* v, double* w, double* acc, uint64_t) const {
+    __device__ void elem(const Coef& cf, const double* v, double* w, double* acc, uint64_t gi) const {
         const double src = NEG_SRC ? -v[0] : v[0];
         double q = src + cf.c * v[1];          // math.rs:35
         if constexpr (SCALE) q = q * cf.gamma; // math.rs:47
-        w[0] = q;
         const double wv = (VMODE == 0) ? v[2] : (VMODE == 1 ? v[1] : q);
         acc[0] += wv * q;                      // math.rs:41
         if constexpr (VMODE == 2) acc[1] += v[2] * q;  // g.d
+        if constexpr (VMODE == 3) {
+            if (gi >= owl_start && gi < owl_end && signum0(q) != signum0(-v[2])) q = 0.0;
+            acc[2] += q * q;
+            acc[3] += v[2] * q;                // pg.d (core.rs:90)
+        }
+        w[0] = q;
     }
 };
 
@@ -388,6 +397,44 @@ struct OpObjLineEval {  // take_line_step + evaluate + dg_unchecked (core.rs:155
         w[1] = g;
         acc[0] += f;
         acc[1] += g * v[1];
+    }
+};
+
+// OWL-QN trial in ONE pass (line.rs:740-743 with core.rs:155-164, :119-126, :114-116):
+//   x = project(xp + step*d ; wp) ; g = grad f(x) ; pg = pseudo-gradient(x, g)
+//   sums: f, g.d, c*sum|x|, ||pg||^2, ||x||^2                                  3r 3w (separately: 6r 3w)
+template <class Obj>
+struct OpObjOwlLineEval {
+    static constexpr int NIN = 3, NOUT = 3, NRED = 5;
+    const double* in[3];  // xp, d, wp
+    double* out[3];       // x, g, pg
+    double step, c;
+    uint64_t start, end;
+    Obj obj;
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double* w, double* acc, uint64_t gi) const {
+        double x = v[0] + step * v[1];
+        const bool reg = gi >= start && gi < end;
+        if (reg && signum0(x) != signum0(v[2])) x = 0.0;       // orthantwise.rs:165-171
+        double f, g;
+        obj.eval(x, gi, f, g);
+        double pg = g;
+        if (reg) {                                             // orthantwise.rs:70-112
+            acc[2] += c * fabs(x);
+            if (x != 0.0) {
+                const double sg = (x != x) ? x : ((__double_as_longlong(x) < 0) ? -1.0 : 1.0);
+                pg = g + sg * c;
+            } else {
+                const double right_partial = g + c, left_partial = g - c;
+                pg = (right_partial < 0.0) ? right_partial : ((left_partial > 0.0) ? left_partial : 0.0);
+            }
+        }
+        w[0] = x; w[1] = g; w[2] = pg;
+        acc[0] += f;
+        acc[1] += g * v[1];
+        acc[3] += pg * pg;
+        acc[4] += x * x;
     }
 };
 

@@ -241,11 +241,22 @@ __device__ __forceinline__ d2 ld16(const double* base, uint64_t pair) {
     if constexpr (NT) return __builtin_nontemporal_load(p);
     else return *p;
 }
+#ifndef LH_STORE_POLICY
+#define LH_STORE_POLICY 0   // tuning experiments only (tools/tune_stream.hip): 1 = sc1, 2 = sc0 sc1, 3 = nt sc1
+#endif
 template <bool NT>
 __device__ __forceinline__ void st16(double* base, uint64_t pair, d2 v) {
     d2* p = reinterpret_cast<d2*>(base) + pair;
+#if LH_STORE_POLICY == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif LH_STORE_POLICY == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#elif LH_STORE_POLICY == 3
+    asm volatile("global_store_dwordx4 %0, %1, off nt sc1" ::"v"(p), "v"(v) : "memory");
+#else
     if constexpr (NT) __builtin_nontemporal_store(v, p);
     else *p = v;
+#endif
 }
 
 // per-stream hint selection (s is a compile-time constant after unrolling)

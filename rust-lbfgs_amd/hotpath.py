@@ -78,6 +78,13 @@ class History:
                                                        dnorm_slot, first_dot_slot, C.byref(ne)))
         return ne.value
 
+    def two_loop_owlqn(self, d, pg, k, end, start, end_, gamma_num_slot=7, gamma_den_slot=8, dnorm_slot=13):
+        """two_loop under OWL-QN with the orthant projection of d folded into the last step."""
+        ne = C.c_int()
+        self.ctx.check(self._L.lbfgs_hip_two_loop_owlqn(self._h, d._h, pg._h, k, end, gamma_num_slot, gamma_den_slot,
+                                                        dnorm_slot, start, end_, C.byref(ne)))
+        return ne.value
+
     def two_loop_gram(self, d, g, k, end, gamma_num_slot=7, gamma_den_slot=8, dnorm_slot=12):
         """Vector-free (Gram) variant [extension]: call after every history update."""
         ne = C.c_int()
@@ -125,3 +132,10 @@ def objective_eval(obj: BuiltinObjective, x, g, out_slot=0):
 def objective_line_eval(obj: BuiltinObjective, x, xp, d, step, g, out_slot=0):
     o = obj.c_struct(x.ctx)
     x.ctx.check(x._L.lbfgs_hip_objective_line_eval(C.byref(o), x._h, xp._h, d._h, float(step), g._h, out_slot))
+
+
+def objective_owlqn_line_eval(obj: BuiltinObjective, x, xp, d, step, wp, g, pg, c, start, end, out_slot=0):
+    """One OWL-QN trial in one pass: projected line step + evaluate + x1norm + pseudo-gradient (+ g.d)."""
+    o = obj.c_struct(x.ctx)
+    x.ctx.check(x._L.lbfgs_hip_objective_owlqn_line_eval(C.byref(o), x._h, xp._h, d._h, float(step), wp._h, g._h, pg._h,
+                                                         float(c), start, end, out_slot))

@@ -273,6 +273,14 @@ int lbfgs_hip_two_loop_from(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_
     return lbfgs_hip_two_loop(h, d, g, k, end, gn, gd, dn, new_end);  // the test double always recomputes the dot
 }
 
+int lbfgs_hip_constrain_direction(lbfgs_hip_vec* d, const lbfgs_hip_vec* pg, uint64_t start, uint64_t end, int o);
+int lbfgs_hip_two_loop_owlqn(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* pg, uint64_t k, int end, int gn,
+                             int gd, int dn, uint64_t start, uint64_t end_, int* new_end) {
+    int rc = lbfgs_hip_two_loop(h, d, pg, k, end, gn, gd, dn, new_end);
+    if (rc != 0) return rc;
+    return lbfgs_hip_constrain_direction(d, pg, start, end_, dn + 2);
+}
+
 int lbfgs_hip_two_loop_gram(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end, int gn,
                             int gd, int dn, int* new_end) {
     return lbfgs_hip_two_loop(h, d, g, k, end, gn, gd, dn, new_end);  // the test double has one recursion
@@ -342,6 +350,16 @@ int lbfgs_hip_objective_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec*
     if (rc) return rc;
     c->board[o + 1] = oracle_vecdot(g->p->data(), d->p->data(), nl(c));
     return allreduce(c, c->board + o, 2);
+}
+
+int lbfgs_hip_objective_owlqn_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
+                                        const lbfgs_hip_vec* d, double step, const lbfgs_hip_vec* wp, lbfgs_hip_vec* g,
+                                        lbfgs_hip_vec* pg, double c, uint64_t start, uint64_t end, int o) {
+    int rc = lbfgs_hip_line_step(x, xp, d, step, wp, start, end);
+    if (rc) return rc;
+    if ((rc = lbfgs_hip_objective_eval(obj, x, g, o))) return rc;
+    if ((rc = lbfgs_hip_owlqn_post_eval(x, g, pg, c, start, end, o + 2))) return rc;
+    return lbfgs_hip_vecdot(g, d, o + 1);
 }
 
 int lbfgs_hip_prof_enable(lbfgs_hip_ctx*, int) { return LBFGS_HIP_OK; }

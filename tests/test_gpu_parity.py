@@ -764,3 +764,53 @@ def test_random_configurations_match_oracle(seed):
         if stable:
             assert ep == eo, (c, eo, ep)
             assert len(rp) == len(ro)
+
+
+@pytest.mark.parametrize("n", [7, 1001, 70001])
+def test_fused_owlqn_kernels_equal_their_unfused_sequences(n):
+    """objective_owlqn_line_eval == line_step(project) + objective_eval + owlqn_post_eval + dot, and
+    two_loop_owlqn == two_loop + constrain_direction: vectors bit for bit, sums to rounding."""
+    r = np.random.default_rng(n)
+    xp_h, d_h = 0.3 * rnd(n, 41), rnd(n, 42)
+    xp_h[r.random(n) < 0.3] = 0.0
+    wp_h = np.sign(r.standard_normal(n)) * (r.random(n) < 0.8)
+    c, start, end = 0.4, (n // 6 if n > 10 else 0), n - (n // 9 if n > 10 else 0)
+    with R.Context(n) as ctx:
+        x, xp, d, wp, g, pg = (DeviceVec(ctx) for _ in range(6))
+        x2, g2, pg2 = (DeviceVec(ctx) for _ in range(3))
+        xp.upload(xp_h); d.upload(d_h); wp.upload(wp_h)
+        for obj in (objectives.Logistic(), objectives.Quadratic(), objectives.Rosenbrock() if n % 2 == 0 else objectives.Quadratic()):
+            H.objective_owlqn_line_eval(obj, x, xp, d, 0.37, wp, g, pg, c, start, end, 20)
+            fused = ctx.scalars(20, 5)
+            H.line_step(x2, xp, d, 0.37, wp, start, end)
+            H.objective_eval(obj, x2, g2, 30)
+            H.owlqn_post_eval(x2, g2, pg2, c, start, end, 32)
+            g2.vecdot_slot(d, 31)
+            ref = ctx.scalars(30, 5)
+            assert np.array_equal(x.to_numpy(), x2.to_numpy())
+            assert np.array_equal(g.to_numpy(), g2.to_numpy())
+            assert np.array_equal(pg.to_numpy(), pg2.to_numpy())
+            for a, b in zip(fused, ref):
+                assert abs(a - b) <= 1e-12 * max(abs(b), 1e-300), (fused, ref)
+        # two-loop with the projection folded in
+        m = 5
+        S, Y, ys = _random_history(n, m, 7 + n)
+        hist = H.History(ctx, m)
+        for j in range(m):
+            hist.s(j).upload(S[j]); hist.y(j).upload(Y[j])
+        hist.set_scalars(ys=ys)
+        ctx.set_scalars(7, [ys[2], O.vecdot(Y[2], Y[2])])
+        pgv, d1, d2 = DeviceVec(ctx, rnd(n, 43)), DeviceVec(ctx), DeviceVec(ctx)
+        ne1 = hist.two_loop_owlqn(d1, pgv, 9, 2, start, end, 7, 8, 40)
+        a = ctx.scalars(40, 4)
+        ne2 = hist.two_loop(d2, pgv, 9, 2, 7, 8, 50)
+        pre = ctx.scalars(50)[0]
+        H.constrain_direction(d2, pgv, start, end, 52)
+        post = ctx.scalars(52, 2)
+        assert ne1 == ne2
+        assert np.array_equal(d1.to_numpy(), d2.to_numpy())
+        assert abs(a[0] - pre) <= 1e-12 * pre and abs(a[2] - post[0]) <= 1e-12 * max(post[0], 1e-300)
+        assert abs(a[3] - post[1]) <= 1e-12 * max(abs(post[1]), 1e-300)
+        hist.free()
+        for v in (x, xp, d, wp, g, pg, x2, g2, pg2, pgv, d1, d2):
+            v.free()

@@ -29,13 +29,15 @@ def gpu_run(n, builder, evaluate, warm, timed, m):
         rows.append(st.propagate())
     ctx.prof_enable(True)
     ctx.prof_reset()
+    ctx.prof_enable(False)
     ctx.sync()
     t0 = time.perf_counter()
     done = 0
     trials = 0
-    for _ in range(timed):
+    for it in range(timed):
         if st.is_converged():
             break
+        ctx.prof_enable(it % 5 == 0)  # sampled kernel timing, as bench.py
         p = st.propagate()
         trials += p.ncall
         done += 1

@@ -168,6 +168,13 @@ int main(int argc, char** argv) {
     bd[0] = 1e-12;  // tiny coefficient so q stays bounded across repetitions
     CK(hipMemcpy(b.board, bd, sizeof(bd), hipMemcpyHostToDevice));
 
+    if (argc > 2 && atoi(argv[2]) == -2) {  // store-policy experiment: build with -DLH_STORE_POLICY=k
+        std::vector<int> g1 = {200, 216, 232};
+        printf("LH_STORE_POLICY=%d\n", LH_STORE_POLICY);
+        sweep_step<2, ~0u, ~0u, 1, 1>(b, g1);
+        sweep_copy<4, ~0u, ~0u, 2>(b, g1);
+        return 0;
+    }
     if (argc > 2 && atoi(argv[2]) == -1) {  // fixed-overhead probe: tiny vectors, back-to-back launches
         std::vector<int> g1 = {216};
         constexpr unsigned NO = 0u;
