@@ -511,7 +511,8 @@ def default_progress():
 
     def prgr_fn(prgr):
         print(f"Iteration {prgr.niter}, Evaluation {prgr.neval}:")
-        print(f" fx = {prgr.fx:<12.6f} xnorm = {prgr.xnorm:<12.6f}, gnorm = {prgr.gnorm:<12.6f}, "
+        # Rust `{:-12.6}`: width 12, 6 decimals, right-aligned (the `-` flag is unused)
+        print(f" fx = {prgr.fx:12.6f} xnorm = {prgr.xnorm:12.6f}, gnorm = {prgr.gnorm:12.6f}, "
               f"ls = {prgr.ncall}, step = {prgr.step}")
         return False
 
