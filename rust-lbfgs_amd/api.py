@@ -77,6 +77,9 @@ class Context:
 
     def close(self):
         if self._h:
+            for buf in getattr(self, "_buffers", []):  # objective data uploaded for this context
+                self._L.lbfgs_hip_device_buffer_destroy(self._h, buf)
+            self._buffers = []
             self._L.lbfgs_hip_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -85,6 +88,14 @@ class Context:
 
     def __exit__(self, *a):
         self.close()
+
+    def upload_buffer(self, array):
+        """Raw device buffer holding `array` (objective data); freed with the context."""
+        a = np.ascontiguousarray(array)
+        buf = C.c_void_p()
+        self.check(self._L.lbfgs_hip_device_buffer_create(self._h, a.ctypes.data_as(C.c_void_p), a.nbytes, C.byref(buf)))
+        self.__dict__.setdefault("_buffers", []).append(buf)
+        return buf
 
     # scalar board
     def scalars(self, first, count=1):
@@ -175,15 +186,11 @@ class BuiltinObjective:
         """lbfgs_hip_objective for `ctx` (uploads the neighbour table once per context and keeps it alive)."""
         o = _ffi.Objective(self.kind, 0, self.seed_a, self.seed_b, None, 0, 0, float(self.cutoff))
         if self.nbr_index is not None:
-            cache = self.__dict__.setdefault("_dev", {})
-            key = id(ctx)
-            if key not in cache:
+            cache = ctx.__dict__.setdefault("_objective_tables", {})  # one upload per (context, objective)
+            if id(self) not in cache:
                 tab = np.ascontiguousarray(self.nbr_index, dtype=np.int32)
-                buf = C.c_void_p()
-                ctx.check(ctx._L.lbfgs_hip_device_buffer_create(ctx._h, tab.ctypes.data_as(C.c_void_p), tab.nbytes,
-                                                                C.byref(buf)))
-                cache[key] = (buf, tab.shape[0], ctx)
-            buf, max_nbr, _ = cache[key]
+                cache[id(self)] = (ctx.upload_buffer(tab), tab.shape[0], self)
+            buf, max_nbr, _ = cache[id(self)]
             o.nbr_index, o.max_nbr = buf, max_nbr
         return o
 
