@@ -207,3 +207,18 @@ def compare_sharded_fuzz(seed, tmp_path, vector_free):
     if stable:
         assert ep == eo, (c, eo, ep)
         assert len(rp) == len(ro)
+
+
+def test_three_ranks_uneven_shards(tmp_path):
+    """world = 3: the last shard is shorter (and 256-aligned boundaries leave it ragged)."""
+    case = dict(name="quadratic3", n=1000, m=4, iters=15, objective="quadratic")
+    outs = run_world(case, 3, tmp_path)
+    ref_rows, ref_x = oracle_rows(case)
+    assert [o["hi"] - o["lo"] for o in outs] == [512, 488, 0]  # ceil(1000/3) -> 334 -> 512-aligned shards
+    assert outs[0]["rows"] == outs[1]["rows"] == outs[2]["rows"]
+    for got, ref in zip(outs[0]["rows"], ref_rows):
+        assert got[:3] == ref[:3]
+        for a, b in zip(got[3:], ref[3:]):
+            assert abs(a - b) <= 1e-9 * max(abs(b), 1e-6)
+    x = np.concatenate([np.array(o["x"]) for o in outs])
+    assert np.max(np.abs(x - ref_x)) <= 1e-9 * max(np.max(np.abs(ref_x)), 1e-12)

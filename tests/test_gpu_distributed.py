@@ -70,3 +70,22 @@ def test_random_configurations_two_processes_p2p(seed, vector_free, tmp_path, mo
     monkeypatch.setenv("LBFGS_WORKER_PRODUCT", "1")
     monkeypatch.setenv("LBFGS_COMM_KIND", "p2p")
     compare_sharded_fuzz(seed, tmp_path, vector_free)
+
+
+@pytest.mark.parametrize("kind", ["p2p", "callback"])
+def test_three_processes_one_gpu_with_an_empty_shard(kind, tmp_path, monkeypatch):
+    """world = 3 on one GPU: shards of 512, 488 and 0 elements (an EMPTY shard still takes part in every
+    reduction and in the P2P exchange)."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("covered by tests/test_distributed_cpu.py")
+    monkeypatch.setenv("LBFGS_WORKER_PRODUCT", "1")
+    monkeypatch.setenv("LBFGS_COMM_KIND", kind)
+    case = dict(name="quadratic3", n=1000, m=4, iters=15, objective="quadratic")
+    outs = run_world(case, 3, tmp_path)
+    ref_rows, ref_x = oracle_rows(case)
+    assert [o["hi"] - o["lo"] for o in outs] == [512, 488, 0]
+    assert outs[0]["rows"] == outs[1]["rows"] == outs[2]["rows"]
+    for got, ref in zip(outs[0]["rows"], ref_rows):
+        assert got[:3] == ref[:3]
+        for a, b in zip(got[3:], ref[3:]):
+            assert abs(a - b) <= 1e-9 * max(abs(b), 1e-6)
