@@ -8,8 +8,8 @@
 A "step" is ONE L-BFGS iteration (LbfgsState::propagate, reference src/lbfgs.rs:503-560) of the
 synthetic diagonal quadratic of BASELINE.json config 4: n = 1e8, m = 10, More-Thuente, f64, the
 crate's default parameters, everything resident in HBM (device objective, no PCIe in the timed
-region).  One step = the line search (fused line-step + evaluate + g.d per trial), the history
-update and the fused two-loop recursion.  With N > 1 the n-vector is sharded contiguously over the
+region).  One step = the line search (per trial one pass over xp and d that returns f and g.d), the
+history update (which also forms the accepted x and g) and the fused two-loop recursion.  With N > 1 the n-vector is sharded contiguously over the
 ranks (total work fixed => "strong" scaling) and every reduction is closed by an all-reduce of its
 f64 scalars: RCCL ncclAllReduce on the compute stream, or the direct xGMI mailbox exchange ("p2p").
 With --comm auto (default) both are measured -- RCCL first, then p2p if its start-up self-test
@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--pg-backend", default="nccl", help="torch.distributed backend used for rendezvous/barriers")
     ap.add_argument("--no-vector-free", action="store_true",
                     help="skip the extra measurement of the vector-free (Gram) two-loop extension")
+    ap.add_argument("--line-eval", type=int, default=2, choices=[0, 1, 2],
+                    help="lbfgs_evaluator.fuse_line_eval: 2 = trials write no vectors (default), 1 = every trial writes x and g, "
+                         "0 = separate passes")
     ap.add_argument("--device", type=int, default=-1, help="force a device index (testing: several ranks on one GPU)")
     return ap.parse_args()
 
@@ -192,12 +195,12 @@ def measure(env, ctx, label, vector_free=False):
                 raise  # backend / communicator failure
             # converged to rounding error (the line search cannot make progress): start over
             hold["state"].close()
-            hold["state"] = builder.build(x0, objectives.Quadratic(), ctx=ctx)
+            hold["state"] = builder.build(x0, objectives.Quadratic(fuse_line_eval=a.line_eval), ctx=ctx)
             hold["restarts"] += 1
             return hold["state"].propagate()
 
     try:
-        hold["state"] = builder.build(x0, objectives.Quadratic(), ctx=ctx)
+        hold["state"] = builder.build(x0, objectives.Quadratic(fuse_line_eval=a.line_eval), ctx=ctx)
         for _ in range(prefill + a.warmup):
             step()
         if not a.no_prof:

@@ -268,6 +268,23 @@ int lbfgs_hip_objective_eval(const lbfgs_hip_objective* obj, const lbfgs_hip_vec
 int lbfgs_hip_objective_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
                                   const lbfgs_hip_vec* d, double step, lbfgs_hip_vec* g, int out_slot);
 
+/* Deferred trial points, for objectives that are evaluated element by element (QUADRATIC, LOGISTIC).
+ * A line search reads two scalars from each trial (line.rs:283-288: f and g.d); the vectors x and g of a trial
+ * are only used if it is the LAST one (by IterationData::update, lbfgs.rs:525).  So:
+ *   lbfgs_hip_objective_line_probe      f(xp + step*d) and grad.d, nothing written.                 2r 0w
+ *   lbfgs_hip_history_update_from_step  x = xp + t*d ; g = grad f(x) ; then lbfgs_hip_history_update's
+ *                                       s, y and seven sums (same board layout) in the same pass.  3r 4w
+ * A search with T trials + the update moves 2T + 7 passes instead of 4T + 6.  The arithmetic per element is that of
+ * lbfgs_hip_objective_line_eval followed by lbfgs_hip_history_update (s = (xp + t*d) - xp, not t*d).
+ * lbfgs_hip_objective_is_elementwise: 1 if `obj` supports the two calls, else 0 (they return LBFGS_HIP_ERR_ARG). */
+int lbfgs_hip_objective_is_elementwise(const lbfgs_hip_objective* obj);
+int lbfgs_hip_objective_line_probe(const lbfgs_hip_objective* obj, const lbfgs_hip_vec* xp, const lbfgs_hip_vec* d,
+                                   double step, int out_slot);
+int lbfgs_hip_history_update_from_step(lbfgs_hip_history* h, int slot, const lbfgs_hip_objective* obj,
+                                       lbfgs_hip_vec* x, const lbfgs_hip_vec* xp, const lbfgs_hip_vec* d, double t,
+                                       lbfgs_hip_vec* g, const lbfgs_hip_vec* gp, double step, int damping,
+                                       int out_slot);
+
 /* one OWL-QN line-search trial in ONE pass (line.rs:740-743): take_line_step with the orthant projection
  * (core.rs:155-164), evaluate (core.rs:119-126) incl. x1norm and the pseudo-gradient, dg_unchecked:
  *   board[out_slot+0] = f(x), +1 = g.d, +2 = sum c*|x| on [start,end), +3 = ||pg||^2, +4 = ||x||^2.   3r 3w */

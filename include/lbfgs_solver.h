@@ -79,7 +79,10 @@ typedef double (*lbfgs_device_eval_cb)(void* user, const void* x_dev, void* g_de
                                        int* failed);
 typedef struct lbfgs_evaluator {
     int32_t kind;
-    int32_t fuse_line_eval;  /* BUILTIN without OWL-QN: line step + evaluate + g.d in one pass */
+    int32_t fuse_line_eval;  /* BUILTIN: 0 = line step, evaluate, g.d as separate passes; 1 = one pass per trial;
+                                2 = additionally, for element-wise objectives without OWL-QN inside propagate,
+                                trials write no vectors and the accepted point is formed by the history update
+                                (lbfgs_hip_objective_line_probe / lbfgs_hip_history_update_from_step) */
     lbfgs_host_eval_cb host;
     lbfgs_device_eval_cb device;
     void* user;

@@ -178,7 +178,7 @@ class BuiltinObjective:
     kind: int
     seed_a: int = 0
     seed_b: int = 0
-    fuse_line_eval: bool = True
+    fuse_line_eval: int = 1    # 0 / 1 / 2, see lbfgs_solver.h (bools accepted)
     nbr_index: object = None   # LJ_NEIGHBORS: int32 [max_nbr, natoms] host table (-1 = empty), uploaded per context
     cutoff: float = 0.0
 

@@ -184,6 +184,11 @@ struct lbfgs_state {
     double last_gamma = 0.0;
     double dginit_next = 0.0;  // g.d of the direction just built (fused into the two-loop's last kernel)
     bool dginit_valid = false;
+    // deferred trial points (lbfgs_hip_objective_line_probe): trials of the running search leave x/gx unwritten;
+    // the accepted point t_eval is materialised by lbfgs_hip_history_update_from_step
+    bool defer_trials = false, point_deferred = false;
+    double t_eval = 0.0;
+    uint64_t trials = 0;  // trial steps evaluated by the running search
     std::string err, ls_err;
 
     bool owlqn() const { return vars.orthantwise != 0; }
@@ -287,6 +292,19 @@ int evaluate_here(lbfgs_state* st, bool want_dg, double* dg_out) {
 
 // take_line_step + evaluate + dg_unchecked (line.rs:283-288 / :740-753) for one trial step.
 int trial(lbfgs_state* st, double t, bool want_dg, double* dg_out) {
+    st->trials += 1;
+    if (st->defer_trials) {  // f and g.d only; x and gx stay unwritten until the update
+        TRYB(st, lbfgs_hip_objective_line_probe(&st->eval.builtin, st->xp, st->d, t, S_F));
+        double b[2];
+        TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_F, 2, b));
+        st->fx = b[0];
+        if (dg_out) *dg_out = b[1];
+        st->norms_valid = false;
+        st->neval += 1;
+        st->t_eval = t;
+        st->point_deferred = true;
+        return LBFGS_OK;
+    }
     if (st->eval.kind == LBFGS_EVAL_BUILTIN && st->eval.fuse_line_eval && !st->owlqn()) {
         TRYB(st, lbfgs_hip_objective_line_eval(&st->eval.builtin, st->x, st->xp, st->d, t, st->gx, S_F));
         double b[2];
@@ -508,9 +526,18 @@ int search_backtracking(lbfgs_state* st, double& stp, uint64_t* ncall, const cha
     return LBFGS_OK;
 }
 
-// LineSearch::find (line.rs:193-223).  Expects xp/gp to hold the base point.
-int line_search_find(lbfgs_state* st, double& step, uint64_t* ncall) {
+// LineSearch::find (line.rs:193-223).  Expects xp/gp to hold the base point.  may_defer: the caller will hand
+// the accepted step to lbfgs_hip_history_update_from_step (st->point_deferred tells it to).
+int line_search_find(lbfgs_state* st, double& step, uint64_t* ncall, bool may_defer = false) {
     const lbfgs_param& pr = st->vars;
+    st->trials = 0;
+    st->point_deferred = false;
+    st->defer_trials = may_defer && st->eval.kind == LBFGS_EVAL_BUILTIN && st->eval.fuse_line_eval >= 2 &&
+                       !st->owlqn() && lbfgs_hip_objective_is_elementwise(&st->eval.builtin);
+    struct Reset {
+        lbfgs_state* s;
+        ~Reset() { s->defer_trials = false; }
+    } reset{st};
     if (!sign_positive(step)) {
         char b[96];
         snprintf(b, sizeof(b), "A logic error (negative line-search step: %g) occurred.", step);
@@ -530,7 +557,12 @@ int line_search_find(lbfgs_state* st, double& step, uint64_t* ncall) {
     if (bail) {  // swallowed: revert and report 0 calls (line.rs:213-220)
         st->ls_err = bail;
         TRY(revert(st));
+        st->point_deferred = false;
         *ncall = 0;
+    } else if (st->trials == 0) {
+        // max_linesearch <= 1: the loops (line.rs:258, :738) run no trial and x stays the saved point.  Here
+        // save_state exchanged buffers instead of copying, so x/gx have to be made equal to xp/gp now.
+        TRY(revert(st));
     }
     return LBFGS_OK;
 }
@@ -740,7 +772,7 @@ int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
     st->norms_valid = false;
 
     uint64_t ncall = 0;
-    TRY(line_search_find(st, st->step, &ncall));  // :517-521
+    TRY(line_search_find(st, st->step, &ncall, true));  // :517-521
     st->ncall = ncall;
     const double step_ls = st->step;
 
@@ -752,7 +784,12 @@ int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
     // decision sits in between (Powell damping), the early read is kept.
     const int damping = st->vars.damping;
     const bool early = damping || !st->ls_err.empty();
-    TRYB(st, lbfgs_hip_history_update(st->hist, st->end, st->x, st->xp, st->gx, st->gp, st->step, damping, S_UPD));
+    if (st->point_deferred) {  // the trials left x and gx unwritten: take the accepted step in the update's pass
+        TRYB(st, lbfgs_hip_history_update_from_step(st->hist, st->end, &st->eval.builtin, st->x, st->xp, st->d, st->t_eval,
+                                                    st->gx, st->gp, st->step, damping, S_UPD));
+        st->point_deferred = false;
+    } else
+        TRYB(st, lbfgs_hip_history_update(st->hist, st->end, st->x, st->xp, st->gx, st->gp, st->step, damping, S_UPD));
     double u[S_END_BLOCK - S_UPD] = {0};
     auto check_update = [&]() -> int {
         const double snorm = std::sqrt(u[0]), yy = u[2];

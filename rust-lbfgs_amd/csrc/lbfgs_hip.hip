@@ -130,6 +130,7 @@ struct lbfgs_hip_ctx {
     unsigned long long mirror_seq = 0;     // sequence number of the latest mirrored launch
     bool mirror_valid[LBFGS_HIP_BOARD_SLOTS + 2] = {false};  // slot's latest value is (or will be) in the mirror
     int grid_default = 0;
+    int cu_count = 0;
     int grid_override = 0;
     int gram_grid = 0;  // workgroups of the Gram rows kernel (0 = same as the others)
     size_t nt_threshold_bytes = (size_t)128 << 20;  // measured crossover: 95 MiB vectors prefer plain, 190 MiB prefer nt
@@ -178,8 +179,8 @@ inline bool slot_ok(int first, int count) {
     return first >= 0 && count >= 0 && first + count <= LBFGS_HIP_BOARD_SLOTS;
 }
 
-int grid_for(const lbfgs_hip_ctx* ctx) {
-    int g = ctx->grid_override > 0 ? ctx->grid_override : ctx->grid_default;
+int grid_for(const lbfgs_hip_ctx* ctx, int x32 = 27) {
+    int g = ctx->grid_override > 0 ? ctx->grid_override : (x32 == 27 ? ctx->grid_default : std::max(1, ctx->cu_count * x32 / 32));
     if (g > MAX_GRID) g = MAX_GRID;
     if (g < 1) g = 1;
     return g;
@@ -305,15 +306,16 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out,
         }
     }
     constexpr int MAP = tuning<Op>::MAP, UNR = tuning<Op>::UNR;
+    const int grid = grid_for(ctx, tuning<Op>::GRID_X32);
     // streaming (`nt`) hints once the running vector cannot stay in the 256 MiB Infinity Cache next to the others
     const bool streaming = n * sizeof(double) >= ctx->nt_threshold_bytes;
     {
         ProfScope ps(ctx, kclass);
         if (streaming)
-            hipLaunchKernelGGL((stream_kernel<Op, UNR, ~0u, ~0u, MAP>), dim3(grid_for(ctx)), dim3(BLOCK), 0, ctx->stream,
+            hipLaunchKernelGGL((stream_kernel<Op, UNR, ~0u, ~0u, MAP>), dim3(grid), dim3(BLOCK), 0, ctx->stream,
                                op, n, ctx->shard.offset, red);
         else
-            hipLaunchKernelGGL((stream_kernel<Op, UNR, 0u, 0u, MAP>), dim3(grid_for(ctx)), dim3(BLOCK), 0, ctx->stream,
+            hipLaunchKernelGGL((stream_kernel<Op, UNR, 0u, 0u, MAP>), dim3(grid), dim3(BLOCK), 0, ctx->stream,
                                op, n, ctx->shard.offset, red);
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -629,6 +631,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     CTX_TRY(hipGetDeviceProperties(&prop, device));
     // ~0.85 workgroups per CU: measured optimum of the windowed streaming map on MI355X (216 of 256 CUs);
     // more workgroups only add concurrent DRAM pages (tools/tune_stream.hip)
+    ctx->cu_count = prop.multiProcessorCount;
     ctx->grid_default = std::max(1, prop.multiProcessorCount * 27 / 32);
     ctx->gram_grid = prop.multiProcessorCount;  // the 21-stream Gram rows pass peaks at one workgroup per CU
     if (const char* e = getenv("LBFGS_HIP_NT_THRESHOLD_MB")) ctx->nt_threshold_bytes = (size_t)atoll(e) << 20;
@@ -1412,6 +1415,79 @@ int lbfgs_hip_objective_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec*
         default:
             return fail(ctx, LBFGS_HIP_ERR_ARG, "unknown objective kind %d", obj->kind);
     }
+}
+
+int lbfgs_hip_objective_is_elementwise(const lbfgs_hip_objective* obj) {
+    return obj && (obj->kind == LBFGS_HIP_OBJ_QUADRATIC || obj->kind == LBFGS_HIP_OBJ_LOGISTIC);
+}
+
+int lbfgs_hip_objective_line_probe(const lbfgs_hip_objective* obj, const lbfgs_hip_vec* xp, const lbfgs_hip_vec* d,
+                                   double step, int out_slot) {
+    if (!obj || !same_ctx(xp, d) || !slot_ok(out_slot, 2)) return LBFGS_HIP_ERR_ARG;
+    lbfgs_hip_ctx* ctx = xp->ctx;
+    double* outs[2] = {ctx->board + out_slot, ctx->board + out_slot + 1};
+    switch (obj->kind) {
+        case LBFGS_HIP_OBJ_QUADRATIC: {
+            OpObjLineProbe<ObjQuadratic> op{};
+            op.in[0] = xp->p; op.in[1] = d->p; op.step = step; op.obj = {obj->seed_a, obj->seed_b};
+            return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
+        }
+        case LBFGS_HIP_OBJ_LOGISTIC: {
+            OpObjLineProbe<ObjLogistic> op{};
+            op.in[0] = xp->p; op.in[1] = d->p; op.step = step; op.obj = {obj->seed_a, obj->seed_b};
+            return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
+        }
+        default:
+            return fail(ctx, LBFGS_HIP_ERR_ARG, "objective kind %d is not evaluated element by element", obj->kind);
+    }
+}
+
+}  // extern "C"
+
+template <class Obj, bool DAMP>
+static int update_from_step(lbfgs_hip_history* h, int slot, const lbfgs_hip_objective* obj, lbfgs_hip_vec* x,
+                            const lbfgs_hip_vec* xp, const lbfgs_hip_vec* d, double t, lbfgs_hip_vec* g,
+                            const lbfgs_hip_vec* gp, double step, double** outs, bool single) {
+    OpHistUpdateFromStep<Obj, DAMP> op{};
+    op.in[0] = xp->p; op.in[1] = d->p; op.in[2] = gp->p;
+    op.out[0] = x->p; op.out[1] = g->p; op.out[2] = h->s[slot]->p; op.out[3] = h->y[slot]->p;
+    op.t = t;
+    op.neg_step = DAMP ? -step : 0.0;
+    op.obj = {obj->seed_a, obj->seed_b};
+    return launch(h->ctx, LBFGS_HIP_K_UPDATE, op, outs, single ? h->ys + slot : nullptr, 1);
+}
+
+extern "C" {
+
+int lbfgs_hip_history_update_from_step(lbfgs_hip_history* h, int slot, const lbfgs_hip_objective* obj,
+                                       lbfgs_hip_vec* x, const lbfgs_hip_vec* xp, const lbfgs_hip_vec* d, double t,
+                                       lbfgs_hip_vec* g, const lbfgs_hip_vec* gp, double step, int damping,
+                                       int out_slot) {
+    if (!h || slot < 0 || slot >= h->m || !obj || !x || !xp || !d || !g || !gp) return LBFGS_HIP_ERR_ARG;
+    lbfgs_hip_ctx* ctx = h->ctx;
+    if (x->ctx != ctx || xp->ctx != ctx || d->ctx != ctx || g->ctx != ctx || gp->ctx != ctx) return LBFGS_HIP_ERR_ARG;
+    if (!slot_ok(out_slot, 7)) return LBFGS_HIP_ERR_ARG;
+    if (x == xp || g == gp) return fail(ctx, LBFGS_HIP_ERR_ARG, "update_from_step: x/g must not alias xp/gp");
+    double* b = ctx->board + out_slot;
+    double* outs[7] = {b, b + 1, b + 2, b + 3, b + 4, b + 5, b + 6};
+    const bool single = ctx->comm_kind == LBFGS_HIP_COMM_NONE || ctx->comm_kind == LBFGS_HIP_COMM_P2P;
+    int rc;
+    switch (obj->kind) {
+        case LBFGS_HIP_OBJ_QUADRATIC:
+            rc = damping ? update_from_step<ObjQuadratic, true>(h, slot, obj, x, xp, d, t, g, gp, step, outs, single)
+                         : update_from_step<ObjQuadratic, false>(h, slot, obj, x, xp, d, t, g, gp, step, outs, single);
+            break;
+        case LBFGS_HIP_OBJ_LOGISTIC:
+            rc = damping ? update_from_step<ObjLogistic, true>(h, slot, obj, x, xp, d, t, g, gp, step, outs, single)
+                         : update_from_step<ObjLogistic, false>(h, slot, obj, x, xp, d, t, g, gp, step, outs, single);
+            break;
+        default:
+            return fail(ctx, LBFGS_HIP_ERR_ARG, "objective kind %d is not evaluated element by element", obj->kind);
+    }
+    if (rc != LBFGS_HIP_OK) return rc;
+    if (!single)  // lbfgs.rs:656 self.ys = the GLOBAL y.s (see lbfgs_hip_history_update)
+        HIP_TRY(ctx, hipMemcpyAsync(h->ys + slot, b + 1, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return LBFGS_HIP_OK;
 }
 
 int lbfgs_hip_objective_owlqn_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,

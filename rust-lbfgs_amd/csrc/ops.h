@@ -400,6 +400,59 @@ struct OpObjLineEval {  // take_line_step + evaluate + dg_unchecked (core.rs:155
     }
 };
 
+// A trial step that leaves NO vectors behind: f(xp + step*d) and grad.d are all a line search reads from a
+// trial (line.rs:283-288), so a search that needs T trials moves 2T passes instead of 4T.  The accepted point is
+// materialised by OpHistUpdateFromStep below, which needs x and g anyway.  Same arithmetic as OpObjLineEval.  2r 0w.
+template <class Obj>
+struct OpObjLineProbe {
+    static constexpr int NIN = 2, NOUT = 0, NRED = 2;
+    static constexpr int TUNE_GRID_X32 = 64;  // ALU-bound on the hashed objectives: 2 workgroups per CU (grid A/B)
+    const double* in[2];  // xp, d
+    double* out[1];
+    double step;
+    Obj obj;
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double*, double* acc, uint64_t gi) const {
+        const double x = v[0] + step * v[1];
+        double f, g;
+        obj.eval(x, gi, f, g);
+        acc[0] += f;
+        acc[1] += g * v[1];
+    }
+};
+
+// take_line_step + evaluate at the ACCEPTED step (core.rs:155-158, :119-121) fused with IterationData::update
+// (lbfgs.rs:640-673): x = xp + t*d ; g = grad f(x) ; s = x - xp ; y = g - gp and OpHistUpdate's seven sums.
+// 3r 4w, where line eval (2r 2w) + update (4r 2w) move 6r 4w.  s is formed as (xp + t*d) - xp, never as t*d.
+template <class Obj, bool DAMP>
+struct OpHistUpdateFromStep {
+    static constexpr int NIN = 3, NOUT = 4, NRED = 7;
+    static constexpr int TUNE_GRID_X32 = 64;
+    const double* in[3];  // xp, d, gp
+    double* out[4];       // x, g, s, y
+    double t;             // the accepted trial step
+    double neg_step;      // -step handed to update() (lbfgs.rs:671)
+    Obj obj;
+    typedef NoCoef Coef;
+    __device__ Coef setup() const { return {}; }
+    __device__ void elem(const Coef&, const double* v, double* w, double* acc, uint64_t gi) const {
+        const double x = v[0] + t * v[1];
+        double f, g;
+        obj.eval(x, gi, f, g);
+        const double s = x - v[0];
+        const double y = g - v[2];
+        w[0] = x; w[1] = g; w[2] = s; w[3] = y;
+        acc[0] += s * s;
+        acc[1] += y * s;
+        acc[2] += y * y;
+        acc[3] += x * x;
+        acc[4] += g * g;
+        if constexpr (DAMP) acc[5] += s * (v[2] * neg_step);
+        acc[6] += s * (-g);
+    }
+};
+
 // OWL-QN trial in ONE pass (line.rs:740-743 with core.rs:155-164, :119-126, :114-116):
 //   x = project(xp + step*d ; wp) ; g = grad f(x) ; pg = pseudo-gradient(x, g)
 //   sums: f, g.d, c*sum|x|, ||pg||^2, ||x||^2                                  3r 3w (separately: 6r 3w)

@@ -298,8 +298,13 @@ struct tuning {
     template <class T> static constexpr int map(...) { return DEFAULT_MAP; }
     template <class T> static constexpr int unr(decltype(T::TUNE_UNROLL)*) { return T::TUNE_UNROLL; }
     template <class T> static constexpr int unr(...) { return UNROLL; }
+    // workgroups per 32 CUs (TUNE_GRID_X32): 27 for the bandwidth-bound shapes (more workgroups only add concurrent
+    // DRAM pages); operators with real arithmetic per element (hashed objectives) want >= 2 workgroups per CU
+    template <class T> static constexpr int gx32(decltype(T::TUNE_GRID_X32)*) { return T::TUNE_GRID_X32; }
+    template <class T> static constexpr int gx32(...) { return 27; }
     static constexpr int MAP = map<Op>(nullptr);
     static constexpr int UNR = unr<Op>(nullptr);
+    static constexpr int GRID_X32 = gx32<Op>(nullptr);
 };
 
 template <class Op>

@@ -61,6 +61,12 @@ class History:
         self.ctx.check(self._L.lbfgs_hip_history_update(self._h, slot, x._h, xp._h, g._h, gp._h, float(step),
                                                         int(damping), out_slot))
 
+    def update_from_step(self, slot, obj, x, xp, d, t, g, gp, step=1.0, damping=False, out_slot=6):
+        """x = xp + t*d ; g = grad f(x) ; then `update` in the same pass (element-wise objectives).  3r 4w."""
+        o = obj.c_struct(self.ctx)
+        self.ctx.check(self._L.lbfgs_hip_history_update_from_step(self._h, slot, C.byref(o), x._h, xp._h, d._h, float(t),
+                                                                  g._h, gp._h, float(step), int(damping), out_slot))
+
     def damp(self, slot, gp, step, theta):
         self.ctx.check(self._L.lbfgs_hip_history_damp(self._h, slot, gp._h, float(step), float(theta)))
 
@@ -132,6 +138,12 @@ def objective_eval(obj: BuiltinObjective, x, g, out_slot=0):
 def objective_line_eval(obj: BuiltinObjective, x, xp, d, step, g, out_slot=0):
     o = obj.c_struct(x.ctx)
     x.ctx.check(x._L.lbfgs_hip_objective_line_eval(C.byref(o), x._h, xp._h, d._h, float(step), g._h, out_slot))
+
+
+def objective_line_probe(obj: BuiltinObjective, xp, d, step, out_slot=0):
+    """f(xp + step*d) and grad.d with nothing written (element-wise objectives).  2r 0w."""
+    o = obj.c_struct(xp.ctx)
+    xp.ctx.check(xp._L.lbfgs_hip_objective_line_probe(C.byref(o), xp._h, d._h, float(step), out_slot))
 
 
 def objective_owlqn_line_eval(obj: BuiltinObjective, x, xp, d, step, wp, g, pg, c, start, end, out_slot=0):

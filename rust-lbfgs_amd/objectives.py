@@ -11,12 +11,14 @@ SEED_QUAD_A, SEED_QUAD_B = 0x5EED0001, 0x5EED0002
 SEED_LOGI_A, SEED_LOGI_T = 0x5EED0003, 0x5EED0004
 
 
-def Quadratic(fuse_line_eval=True):
+# fuse_line_eval (lbfgs_solver.h): 0/False = separate passes per trial, 1/True = one pass per trial,
+# 2 = trials write no vectors, the accepted point is formed in the history update's pass (element-wise objectives)
+def Quadratic(fuse_line_eval=2):
     """f = sum x_i*(0.5*a_i*x_i - b_i), a_i = 1 + 999*u_i^2 (cond 1e3), b_i = 2*u'_i - 1."""
     return BuiltinObjective(_ffi.OBJ_QUADRATIC, SEED_QUAD_A, SEED_QUAD_B, fuse_line_eval)
 
 
-def Logistic(fuse_line_eval=True):
+def Logistic(fuse_line_eval=2):
     """f = sum log(1+exp(-t_i*a_i*x_i)), a_i = 0.5 + 1.5*u_i, t_i = +-1."""
     return BuiltinObjective(_ffi.OBJ_LOGISTIC, SEED_LOGI_A, SEED_LOGI_T, fuse_line_eval)
 

@@ -24,6 +24,10 @@ def make_case(seed):
         end = None if r.random() < 0.4 else int(r.integers(0, n + 20))  # may be <= start (panic) or > n (clamped)
         c["owl"] = (float([1.0, 0.3, 0.0][int(r.integers(0, 3))]), start, end)
     c["x0_scale"] = float([0.0, 0.5, 3.0][int(r.integers(0, 3))])
+    # derived from the seed, not drawn, so the cases above keep their values:
+    c["fuse"] = [2, 1, 0][seed % 3]          # lbfgs_evaluator.fuse_line_eval: deferred trial points / fused / separate
+    if seed % 11 == 5:
+        c["max_ls"] = seed % 2               # 0 or 1: the search runs NO trial (line.rs:258, :738)
     return c
 
 
@@ -65,7 +69,8 @@ def run_oracle(c, mode=0):
 
 
 def run_product(R, objectives, c):
-    dev = {"quadratic": objectives.Quadratic, "logistic": objectives.Logistic, "rosenbrock": objectives.Rosenbrock}[c["kind"]]()
+    dev = {"quadratic": objectives.Quadratic, "logistic": objectives.Logistic, "rosenbrock": objectives.Rosenbrock}[c["kind"]](
+        fuse_line_eval=c.get("fuse", 2))
     rows, x = [], x0_of(c)
     try:
         b = configure(R.lbfgs(), c)

@@ -352,6 +352,35 @@ int lbfgs_hip_objective_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec*
     return allreduce(c, c->board + o, 2);
 }
 
+int lbfgs_hip_objective_is_elementwise(const lbfgs_hip_objective* obj) {
+    return obj && (obj->kind == LBFGS_HIP_OBJ_QUADRATIC || obj->kind == LBFGS_HIP_OBJ_LOGISTIC);
+}
+// the deferred-trial pair as the reference's own sequence on scratch / on the real vectors
+int lbfgs_hip_objective_line_probe(const lbfgs_hip_objective* obj, const lbfgs_hip_vec* xp, const lbfgs_hip_vec* d,
+                                   double step, int o) {
+    lbfgs_hip_ctx* c = xp->ctx;
+    if (!lbfgs_hip_objective_is_elementwise(obj)) return fail(c, LBFGS_HIP_ERR_ARG, "not elementwise");
+    const size_t n = nl(c);
+    std::vector<double> x(n), g(n);
+    oracle_veccpy(x.data(), xp->p->data(), n);
+    oracle_vecadd(x.data(), d->p->data(), step, n);
+    int rc = eval_obj(obj, c, x.data(), g.data(), c->board + o);
+    if (rc) return rc;
+    c->board[o + 1] = oracle_vecdot(g.data(), d->p->data(), n);
+    return allreduce(c, c->board + o, 2);
+}
+int lbfgs_hip_history_update_from_step(lbfgs_hip_history* h, int slot, const lbfgs_hip_objective* obj,
+                                       lbfgs_hip_vec* x, const lbfgs_hip_vec* xp, const lbfgs_hip_vec* d, double t,
+                                       lbfgs_hip_vec* g, const lbfgs_hip_vec* gp, double step, int damping, int o) {
+    lbfgs_hip_ctx* c = h->ctx;
+    if (!lbfgs_hip_objective_is_elementwise(obj)) return fail(c, LBFGS_HIP_ERR_ARG, "not elementwise");
+    lbfgs_hip_line_step(x, xp, d, t, nullptr, 0, 0);
+    double f;
+    int rc = eval_obj(obj, c, x->p->data(), g->p->data(), &f);
+    if (rc) return rc;
+    return lbfgs_hip_history_update(h, slot, x, xp, g, gp, step, damping, o);
+}
+
 int lbfgs_hip_objective_owlqn_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
                                         const lbfgs_hip_vec* d, double step, const lbfgs_hip_vec* wp, lbfgs_hip_vec* g,
                                         lbfgs_hip_vec* pg, double c, uint64_t start, uint64_t end, int o) {

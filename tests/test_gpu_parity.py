@@ -814,3 +814,84 @@ def test_fused_owlqn_kernels_equal_their_unfused_sequences(n):
         hist.free()
         for v in (x, xp, d, wp, g, pg, x2, g2, pg2, pgv, d1, d2):
             v.free()
+
+
+@pytest.mark.parametrize("n", [1, 2, 513, 1001, 70001, 262144 * 2 + 3])
+@pytest.mark.parametrize("damping", [False, True])
+def test_deferred_trial_kernels_equal_line_eval_plus_update(n, damping):
+    """objective_line_probe == objective_line_eval's two sums with nothing written, and
+    history.update_from_step == objective_line_eval followed by history.update: x, g, s, y bit for bit, the seven
+    sums to rounding; both against the oracle's objective as well."""
+    xp_h, d_h, gp_h = 0.3 * rnd(n, 51), rnd(n, 52), rnd(n, 53)
+    t, step = 0.37, 0.61
+    with R.Context(n) as ctx:
+        xp, d, gp = (DeviceVec(ctx, a) for a in (xp_h, d_h, gp_h))
+        x1, g1, x2, g2 = (DeviceVec(ctx) for _ in range(4))
+        for obj, obj_o, exact_g in ((objectives.Quadratic(), O.quadratic(), True), (objectives.Logistic(), O.logistic(), False)):
+            sentinel = np.full(n, 7.25)
+            x1.upload(sentinel); g1.upload(sentinel)
+            H.objective_line_probe(obj, xp, d, t, 20)
+            probe = ctx.scalars(20, 2)
+            H.objective_line_eval(obj, x2, xp, d, t, g2, 30)
+            ref = ctx.scalars(30, 2)
+            x_o = xp_h.copy(); O.vecadd(x_o, d_h, t)
+            f_o, g_o = O.eval_builtin(obj_o, x_o)
+            assert np.array_equal(x2.to_numpy(), x_o)
+            if exact_g:
+                assert np.array_equal(g2.to_numpy(), g_o)
+            else:
+                assert rel(g2.to_numpy(), g_o) <= 1e-14  # libm (glibc vs ocml) exp/log1p differ by an ulp
+            g_o = g2.to_numpy()  # from here on: the product's own unfused sequence is the reference
+            fabs = max(abs(f_o), 1.0)
+            assert abs(probe[0] - ref[0]) <= 1e-12 * max(abs(ref[0]), 1e-300)
+            assert abs(probe[1] - ref[1]) <= 1e-12 * float(np.sum(np.abs(g_o * d_h)))
+            assert abs(probe[0] - f_o) <= RTOL * fabs
+            assert abs(probe[1] - O.vecdot(g_o, d_h)) <= RTOL * float(np.sum(np.abs(g_o * d_h)))
+            h1, h2 = H.History(ctx, 2), H.History(ctx, 2)
+            h1.update_from_step(1, obj, x1, xp, d, t, g1, gp, step, damping, 40)
+            a = ctx.scalars(40, 7)
+            h2.update(1, x2, xp, g2, gp, step, damping, 50)
+            b = ctx.scalars(50, 7)
+            assert np.array_equal(x1.to_numpy(), x_o) and np.array_equal(g1.to_numpy(), g_o)  # sentinels overwritten
+            assert np.array_equal(h1.s(1).to_numpy(), h2.s(1).to_numpy())
+            assert np.array_equal(h1.y(1).to_numpy(), h2.y(1).to_numpy())
+            assert np.array_equal(h1.s(1).to_numpy(), x_o - xp_h)  # (xp + t*d) - xp, not t*d
+            s_h, y_h = x_o - xp_h, g_o - gp_h
+            mags = [np.sum(s_h * s_h), np.sum(np.abs(y_h * s_h)), np.sum(y_h * y_h), np.sum(x_o * x_o),
+                    np.sum(g_o * g_o), np.sum(np.abs(s_h * gp_h * step)), np.sum(np.abs(s_h * g_o))]
+            for u, v, mag in zip(a, b, mags):
+                assert abs(u - v) <= 1e-12 * max(float(mag), 1e-300), (a, b)
+            assert h1.scalars()[0][1] == a[1]  # ys stored in the slot (lbfgs.rs:656)
+            if not damping:
+                assert a[5] == 0.0
+            h1.free(); h2.free()
+        for v in (xp, d, gp, x1, g1, x2, g2):
+            v.free()
+
+
+def test_deferred_trial_points_reject_other_objectives():
+    with R.Context(64) as ctx:
+        xp, d = DeviceVec(ctx, np.ones(64)), DeviceVec(ctx, np.ones(64))
+        with pytest.raises(R.LbfgsError):
+            H.objective_line_probe(objectives.Rosenbrock(), xp, d, 0.5, 20)
+        xp.free(); d.free()
+
+
+@pytest.mark.parametrize("kind", ["quadratic", "logistic"])
+@pytest.mark.parametrize("damping", [False, True])
+def test_runs_with_and_without_deferred_trial_points_agree(kind, damping):
+    """fuse_line_eval = 2 (trials write nothing) against 1 (every trial writes x, g): the same iterates."""
+    make = {"quadratic": objectives.Quadratic, "logistic": objectives.Logistic}[kind]
+    n = 30011
+    out = []
+    for fuse in (1, 2):
+        x, rows = np.zeros(n), []
+        b = R.lbfgs().with_m(7).with_epsilon(0.0).with_max_iterations(25).with_damping(damping)
+        b.minimize(x, make(fuse_line_eval=fuse), lambda p: rows.append((p.niter, p.neval, p.ncall, p.fx, p.xnorm, p.gnorm, p.step)) and False)
+        out.append((rows, x))
+    (r1, x1), (r2, x2) = out
+    assert [r[:3] for r in r1] == [r[:3] for r in r2]
+    for u, v in zip(r1, r2):
+        for a, b_ in zip(u[3:], v[3:]):
+            assert abs(a - b_) <= 1e-9 * max(abs(b_), 1e-12)
+    assert np.max(np.abs(x1 - x2)) <= 1e-9 * np.max(np.abs(x2))

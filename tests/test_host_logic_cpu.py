@@ -88,12 +88,37 @@ def test_builtin_objectives_identical():
     for obj_o, obj_p, cfg in [
         (O.quadratic(), objectives.Quadratic(), lambda b: b.with_m(7).with_epsilon(1e-9).with_max_iterations(40)),
         (O.quadratic(), objectives.Quadratic(fuse_line_eval=False), lambda b: b.with_max_iterations(25)),
+        (O.quadratic(), objectives.Quadratic(fuse_line_eval=1), lambda b: b.with_m(7).with_max_iterations(25)),
+        (O.quadratic(), objectives.Quadratic(fuse_line_eval=2), lambda b: b.with_damping(True).with_max_iterations(25)),
+        (O.quadratic(), objectives.Quadratic(fuse_line_eval=2),  # every search ends by exhaustion after ONE trial
+         lambda b: b.with_max_linesearch(2).with_max_iterations(25)),
+        (O.logistic(), objectives.Logistic(fuse_line_eval=2),
+         lambda b: b.with_linesearch_algorithm("BacktrackingStrongWolfe").with_max_iterations(25)),
         (O.logistic(), objectives.Logistic(), lambda b: b.with_orthantwise(0.5, 0, None).with_max_iterations(40)),
         (O.rosenbrock(), objectives.Rosenbrock(), lambda b: b),
     ]:
         a, b = run_pair(cfg, np.zeros(1000) if obj_o.name != "oracle_obj_rosenbrock" else P.rosenbrock_x0(), obj_o, obj_p)
         assert len(a[1]) > 5
         assert_identical(a, b)
+
+
+@pytest.mark.parametrize("max_ls", [0, 1])
+@pytest.mark.parametrize("algo", ["MoreThuente", "BacktrackingWolfe"])
+def test_a_search_without_trials_leaves_x_unchanged(max_ls, algo):
+    """max_linesearch <= 1: the trial loops (line.rs:258, :738) do not run, find() returns Ok(max_linesearch) with
+    x untouched, and update() fails with "x not changed" (lbfgs.rs:646).  The product exchanges buffers in
+    save_state, so this is the case that would expose a stale x."""
+    for o_ev, p_ev, x0 in [(O.rosenbrock(), R.default_evaluate(), P.rosenbrock_x0()),
+                           (O.quadratic(), objectives.Quadratic(), np.zeros(300)),
+                           (O.quadratic(), objectives.Quadratic(fuse_line_eval=1), np.zeros(300))]:
+        cfg = lambda b: b.with_max_linesearch(max_ls).with_linesearch_algorithm(algo)
+        xo, xp = x0.copy(), x0.copy()
+        with pytest.raises(O.OracleError) as eo:
+            cfg(O.lbfgs()).minimize(xo, o_ev)
+        with pytest.raises(R.LbfgsError) as ep:
+            cfg(R.lbfgs()).minimize(xp, p_ev)
+        assert eo.value.code == ep.value.code == -4
+        assert np.array_equal(xo, xp) and np.array_equal(xp, x0)
 
 
 def test_booth_and_poisson():

@@ -20,6 +20,8 @@ PASSES = [
     (r"OpTwoLoopStep<(true|false), true, 1>", (2, 1), "two-loop gamma transition"),
     (r"OpTwoLoopStep<false, false, 2>", (3, 1), "two-loop last step + ||d||^2 + g.d (g re-read for the next dginit)"),
     (r"OpTwoLoopFirst", (2, 0), "two-loop first dot s.(-g)"),
+    (r"OpHistUpdateFromStep<", (3, 4), "accepted step: x,g + history update s,y + 7 sums"),
+    (r"OpObjLineProbe<", (2, 0), "trial step: f and g.d, nothing written"),
     (r"OpHistUpdate<", (4, 2), "history update s,y + 5 sums"),
     (r"OpObjLineEval<", (2, 2), "line step + quadratic eval + g.d"),
     (r"OpObjEval<", (1, 1), "objective eval"),
