@@ -1,0 +1,20 @@
+#!/bin/bash
+# The round's judged profile of `python bench.py` (n=1e8, m=10, one MI355X).  Run on the GPU box from the repo root:
+#     bash tools/profile_round.sh r01
+# Writes gpurun_out/prof_<tag>/{bench.json, stats/, pmc_fetch/, pmc_write/, summary.md}; copy summary.md, bench.json and
+# the kernel_stats csv into profiles/.  PMC counters are collected in their own passes, with --kernel-trace only.
+set -e
+tag=${1:-r01}
+root=$(pwd)
+out=$root/gpurun_out/prof_$tag
+rm -rf "$out"; mkdir -p "$out"
+export TMPDIR=/tmp
+python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --steps 30 --warmup 12 --no-cpu-baseline --no-vector-free > "$out/stats.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 4 --warmup 12 --no-cpu-baseline --no-prof --no-vector-free > "$out/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 4 --warmup 12 --no-cpu-baseline --no-prof --no-vector-free > "$out/pmc_write.log" 2>&1
+python3 tools/summarize_profile.py "$out/stats" "$out/pmc_fetch" "$out/pmc_write" 100000000 "$out/summary.md" > /dev/null
+cp "$out"/stats/*/*_kernel_stats.csv "$out/kernel_stats.csv"
+# keep only the small artefacts (the traces are hundreds of MB)
+rm -rf "$out/stats" "$out/pmc_fetch" "$out/pmc_write"
+cat "$out/summary.md"; cut -c1-200 "$out/bench.json"
