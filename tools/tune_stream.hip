@@ -13,6 +13,109 @@
 
 using namespace lh;
 
+// EXPERIMENT (not adopted, see DESIGN.md section 7 and profiles/r01_tune_peek_pair.log): operators for issuing the
+// recursion two steps at a time.  They live here, not in ops.h, because the product does not use them.
+namespace lh {
+// ---- the recursion two steps at a time: "peek, then apply both" -------------------------------------------
+// A write pass costs 1.67x a read pass on MI355X (0.183 ms vs 0.110 ms per 0.8 GB, fitted on every kernel shape of
+// profiles/r01_bench_n1e8_m10.md).  Consecutive steps a, b of the recursion
+//     q_a = q + c_a*u_a ; dot_a = w_a.q_a        q_b = q_a + c_b*u_b ; dot_b = w_b.q_b
+// where c_b needs the GLOBAL sum dot_a are therefore issued as
+//     peek  : dot_a over q + c_a*u_a, q_a NOT written                                    (3r 0w)
+//     pair  : q_b = (q + c_a*u_a) + c_b*u_b written once, dot_b                          (4r 1w)
+// = 7r 1w per two steps instead of 6r 2w: the same element-wise arithmetic in the same order (q_a is recomputed, to
+// the same bits, never re-associated), one write pass fewer.
+//
+// One step of the recursion as the kernels see it (lbfgs.rs:582-601):
+struct TwoLoopStepRef {
+    const double* dot_in;  // numerator produced by the previous reduction (global sum)
+    const double* ys_j;    // ys of the slot whose coefficient this step applies
+    double* alpha_j;       // alpha of that slot (stored in mode A, read in mode B)
+    int mode_b;            // 0: first loop  c = -(dot/ys), alpha := dot/ys      1: second loop  c = alpha - dot/ys
+    double sign;           // -1.0 when the source is g and the recursion starts from d = -g (core.rs:95-101), else 1.0
+    int scale;             // 1: this step is followed by q *= gamma (lbfgs.rs:591), gamma = board ratio ys/yy
+};
+__device__ __forceinline__ double two_loop_coef(const TwoLoopStepRef& r, bool store_alpha) {
+    const double q = *r.dot_in / *r.ys_j;
+    if (r.mode_b) return *r.alpha_j - q;
+    if (store_alpha && blockIdx.x == 0 && threadIdx.x == 0) *r.alpha_j = q;
+    return -q;
+}
+struct TwoLoopPairCoef {
+    double sign, c1, g1, c2, g2;
+};
+
+// peek: the sum a step would produce, without writing its vector.  WMODE 0: w is a third stream; 1: w = u (the
+// gamma transition).  x*1.0 and x*(+-1.0) are exact, so the optional scale and sign are plain multiplications.
+template <int WMODE>
+struct OpTwoLoopPeek {
+    static constexpr int NIN = (WMODE == 1) ? 2 : 3, NOUT = 0, NRED = 1;
+    static constexpr int TUNE_MAP = 1, TUNE_UNROLL = 2;
+    const double* in[3];  // src, u, w
+    double* out[1];
+    TwoLoopStepRef a;
+    const double* gamma_num;
+    const double* gamma_den;
+    typedef TwoLoopPairCoef Coef;
+    __device__ Coef setup() const {
+        Coef cf;
+        cf.sign = a.sign;
+        cf.c1 = two_loop_coef(a, true);
+        cf.g1 = a.scale ? (*gamma_num / *gamma_den) : 1.0;
+        cf.c2 = 0.0;
+        cf.g2 = 1.0;
+        return cf;
+    }
+    __device__ void elem(const Coef& cf, const double* v, double*, double* acc, uint64_t) const {
+        double q = cf.sign * v[0] + cf.c1 * v[1];  // math.rs:35
+        q = q * cf.g1;                             // math.rs:47 (exact no-op when g1 == 1)
+        acc[0] += ((WMODE == 1) ? v[1] : v[2]) * q;
+    }
+};
+
+// pair: apply step a (whose sum the peek produced) and step b, write once, produce b's sum(s).
+//   VMODE 0: w_b is a fourth stream (4r 1w); 1: w_b = u_b (b is the gamma transition, 3r 1w);
+//   VMODE 2: b is the last step: ||d||^2 and g.d with g as the fourth stream; 3: the same under OWL-QN (see OpTwoLoopStep)
+template <int VMODE>
+struct OpTwoLoopPair {
+    static constexpr int NIN = (VMODE == 1) ? 3 : 4, NOUT = 1, NRED = (VMODE == 2) ? 2 : (VMODE == 3 ? 4 : 1);
+    static constexpr int TUNE_MAP = 1, TUNE_UNROLL = 2;
+    const double* in[4];  // src, u_a, u_b, w_b (VMODE 2/3: g / pg)
+    double* out[1];       // dst (= d)
+    TwoLoopStepRef a, b;
+    const double* gamma_num;
+    const double* gamma_den;
+    uint64_t owl_start, owl_end;  // VMODE 3 only
+    typedef TwoLoopPairCoef Coef;
+    __device__ Coef setup() const {
+        Coef cf;
+        const double gamma = (a.scale || b.scale) ? (*gamma_num / *gamma_den) : 1.0;  // lbfgs.rs:691 ys/yy
+        cf.sign = a.sign;
+        cf.c1 = two_loop_coef(a, false);  // alpha_a was stored by the peek
+        cf.g1 = a.scale ? gamma : 1.0;
+        cf.c2 = two_loop_coef(b, true);
+        cf.g2 = b.scale ? gamma : 1.0;
+        return cf;
+    }
+    __device__ void elem(const Coef& cf, const double* v, double* w, double* acc, uint64_t gi) const {
+        double q = cf.sign * v[0] + cf.c1 * v[1];
+        q = q * cf.g1;
+        q = q + cf.c2 * v[2];
+        q = q * cf.g2;
+        const double wv = (VMODE == 0) ? v[3] : (VMODE == 1 ? v[2] : q);
+        acc[0] += wv * q;
+        if constexpr (VMODE == 2) acc[1] += v[3] * q;  // g.d
+        if constexpr (VMODE == 3) {
+            if (gi >= owl_start && gi < owl_end && signum0(q) != signum0(-v[3])) q = 0.0;
+            acc[2] += q * q;
+            acc[3] += v[3] * q;                        // pg.d (core.rs:90)
+        }
+        w[0] = q;
+    }
+};
+
+}  // namespace lh
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 struct Bufs {
@@ -147,6 +250,24 @@ void sweep_rows(const Bufs& b, const std::vector<int>& grids, double** vecs) {
     }
 }
 
+template <int UNR, unsigned NTL, unsigned NTS, int MAP, int SPAN = 1>
+void sweep_peek_pair(const Bufs& b, const std::vector<int>& grids, double* extra[4]) {
+    TwoLoopStepRef ra{b.board, b.board + 1, b.board + 10, 1, 1.0, 0}, rb{b.board, b.board + 1, b.board + 11, 1, 1.0, 0};
+    OpTwoLoopPeek<0> pk{};
+    pk.in[0] = b.q; pk.in[1] = b.u; pk.in[2] = b.v; pk.a = ra; pk.gamma_num = b.board; pk.gamma_den = b.board + 1;
+    OpTwoLoopPair<0> pr{};
+    pr.in[0] = b.q; pr.in[1] = b.u; pr.in[2] = b.v; pr.in[3] = extra[0]; pr.out[0] = b.q; pr.a = ra; pr.b = rb;
+    pr.gamma_num = b.board; pr.gamma_den = b.board + 1;
+    for (int g : grids) {
+        int occ = 0;
+        float ms1 = run<decltype(pk), UNR, NTL, NTS, MAP, SPAN>(pk, b, g, 15, &occ);
+        float ms2 = run<decltype(pr), UNR, NTL, NTS, MAP, SPAN>(pr, b, g, 15, &occ);
+        printf("peek3r+pair4r1w_s%d map=%d unroll=%d ntl=%d nts=%d grid=%5d (%.2f/CU, occ=%d) : peek %8.3f ms %7.1f GB/s | pair %8.3f ms %7.1f GB/s | both %8.3f ms\n",
+               SPAN, MAP, UNR, (int)(NTL & 15u), (int)(NTS & 15u), g, g / 256.0, occ, ms1, 24.0 * b.n / ms1 / 1e6, ms2,
+               40.0 * b.n / ms2 / 1e6, ms1 + ms2);
+    }
+}
+
 int main(int argc, char** argv) {
     Bufs b{};
     b.n = argc > 1 ? strtoull(argv[1], nullptr, 10) : 100000000ULL;
@@ -173,6 +294,21 @@ int main(int argc, char** argv) {
         printf("LH_STORE_POLICY=%d\n", LH_STORE_POLICY);
         sweep_step<2, ~0u, ~0u, 1, 1>(b, g1);
         sweep_copy<4, ~0u, ~0u, 2>(b, g1);
+        return 0;
+    }
+    if (argc > 2 && atoi(argv[2]) == -3) {  // two steps of the recursion as peek (3r) + pair (4r 1w) against 2 x (3r 1w)
+        double* extra[4];
+        for (auto& e : extra) { CK(hipMalloc(&e, bytes)); CK(hipMemcpy(e, h.data(), bytes, hipMemcpyHostToDevice)); }
+        std::vector<int> g1 = {192, 216, 240, 256, 320, 432, 512};
+        constexpr unsigned ALL = ~0u;
+        sweep_step<2, ALL, ALL, 1, 1>(b, {216});
+        sweep_peek_pair<1, ALL, ALL, 1, 1>(b, g1, extra);
+        sweep_peek_pair<2, ALL, ALL, 1, 1>(b, g1, extra);
+        sweep_peek_pair<4, ALL, ALL, 1, 1>(b, g1, extra);
+        sweep_peek_pair<2, ALL, ALL, 2, 1>(b, g1, extra);
+        sweep_peek_pair<4, ALL, ALL, 2, 1>(b, g1, extra);
+        sweep_peek_pair<2, ALL, ALL, 2, 2>(b, g1, extra);
+        sweep_peek_pair<2, ALL, ALL, 0, 1>(b, g1, extra);
         return 0;
     }
     if (argc > 2 && atoi(argv[2]) == -1) {  // fixed-overhead probe: tiny vectors, back-to-back launches
