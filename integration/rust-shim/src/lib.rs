@@ -1,0 +1,381 @@
+//! `liblbfgs` API (ybyygu/rust-lbfgs v0.2.0) on an MI355X: same builder, same `minimize` signature, every
+//! n-vector resident in HBM.  UNTESTED -- written against the C headers in an image without a Rust toolchain;
+//! see INTEGRATION.md.  The numerical behaviour is that of `liblbfgs_solver.so` (parity-tested against a CPU
+//! restatement of the crate), not of this file: everything below is argument marshalling.
+//!
+//! ```ignore
+//! use liblbfgs_hip::lbfgs;
+//! let mut x = vec![0.0; 1_000_000];
+//! let report = lbfgs()
+//!     .with_max_iterations(100)
+//!     .minimize(&mut x, |x, gx| { /* fill gx, return Ok(fx) */ Ok(0.0) }, |prgr| { println!("{}", prgr.fx); false })?;
+//! ```
+//! `minimize` keeps `E: FnMut(&[f64], &mut [f64]) -> Result<f64>` (src/lbfgs.rs:401): x is downloaded and gx
+//! uploaded around every evaluation.  That is the compatibility path (PCIe-bound); `minimize_builtin` runs one of
+//! the device-resident objectives with no host traffic, and a device-pointer closure can be passed through
+//! `ffi::lbfgs_evaluator { kind: LBFGS_EVAL_DEVICE, .. }` by callers that own HIP kernels.
+pub mod ffi;
+
+use anyhow::{anyhow, bail, Result};
+use std::ffi::CStr;
+use std::os::raw::{c_int, c_void};
+use std::panic::{catch_unwind, AssertUnwindSafe};
+use std::ptr;
+
+/// Progress (src/core.rs:223-250).  `x` and `gx` are host copies made for the callback; they are empty when
+/// `with_progress_vectors(false)` was requested (saves two PCIe transfers per iteration).
+pub struct Progress<'a> {
+    pub x: &'a [f64],
+    pub gx: &'a [f64],
+    pub fx: f64,
+    pub xnorm: f64,
+    pub gnorm: f64,
+    pub step: f64,
+    pub niter: usize,
+    pub neval: usize,
+    pub ncall: usize,
+}
+
+/// Report (src/core.rs:273-285)
+#[derive(Debug, Clone)]
+pub struct Report {
+    pub fx: f64,
+    pub xnorm: f64,
+    pub gnorm: f64,
+    pub neval: usize,
+}
+
+/// Device-resident objectives of `include/lbfgs_hip.h` (BASELINE.json's synthetic workloads + Rosenbrock).
+#[derive(Clone, Copy)]
+pub enum Builtin {
+    Quadratic,
+    Logistic,
+    Rosenbrock,
+}
+
+/// `Lbfgs` (src/lbfgs.rs:181-383): the same `with_*` setters with the same assertions.
+#[derive(Clone)]
+pub struct Lbfgs {
+    param: ffi::lbfgs_param,
+    device: c_int,
+    progress_vectors: bool,
+}
+
+/// src/lib.rs:74
+pub fn lbfgs() -> Lbfgs {
+    Lbfgs::default()
+}
+
+impl Default for Lbfgs {
+    fn default() -> Self {
+        let mut p = std::mem::MaybeUninit::<ffi::lbfgs_param>::zeroed();
+        // lbfgs.rs:161-176, line.rs:151-162, orthantwise.rs:47-55
+        let param = unsafe {
+            ffi::lbfgs_param_default(p.as_mut_ptr());
+            p.assume_init()
+        };
+        Lbfgs { param, device: 0, progress_vectors: true }
+    }
+}
+
+impl Lbfgs {
+    pub fn with_epsilon(mut self, epsilon: f64) -> Self {
+        assert!(epsilon.is_sign_positive(), "Invalid parameter epsilon specified.");
+        self.param.epsilon = epsilon;
+        self
+    }
+    pub fn with_initial_step_size(mut self, b: f64) -> Self {
+        assert!(b.is_sign_positive(), "Invalid beta parameter for scaling the initial step size.");
+        self.param.initial_inverse_hessian = b;
+        self
+    }
+    pub fn with_max_step_size(mut self, s: f64) -> Self {
+        assert!(s.is_sign_positive(), "Invalid max_step_size parameter.");
+        self.param.max_step_size = s;
+        self
+    }
+    pub fn with_damping(mut self, damped: bool) -> Self {
+        self.param.damping = damped as i32;
+        self
+    }
+    pub fn with_orthantwise(mut self, c: f64, start: usize, end: impl Into<Option<usize>>) -> Self {
+        assert!(c.is_sign_positive(), "Invalid parameter orthantwise c parameter specified.");
+        self.param.orthantwise = 1;
+        self.param.owl_c = c;
+        self.param.owl_start = start as u64;
+        self.param.owl_end = end.into().map(|e| e as i64).unwrap_or(-1);
+        self
+    }
+    pub fn with_linesearch_ftol(mut self, ftol: f64) -> Self {
+        assert!(ftol >= 0.0, "Invalid parameter ftol specified.");
+        self.param.ftol = ftol;
+        self
+    }
+    pub fn with_linesearch_gtol(mut self, gtol: f64) -> Self {
+        assert!(gtol >= 0.0 && gtol < 1.0 && gtol > self.param.ftol, "Invalid parameter gtol specified.");
+        self.param.gtol = gtol;
+        self
+    }
+    pub fn with_gradient_only(mut self) -> Self {
+        self.param.gradient_only = 1;
+        self.param.damping = 1;
+        self.param.ls_algorithm = ffi::LBFGS_LS_BACKTRACKING_STRONGWOLFE;
+        self
+    }
+    pub fn with_max_linesearch(mut self, n: usize) -> Self {
+        self.param.max_linesearch = n as u64;
+        self
+    }
+    pub fn with_linesearch_xtol(mut self, xtol: f64) -> Self {
+        assert!(xtol >= 0.0, "Invalid parameter xtol specified.");
+        self.param.xtol = xtol;
+        self
+    }
+    pub fn with_linesearch_min_step(mut self, min_step: f64) -> Self {
+        assert!(min_step >= 0.0, "Invalid parameter min_step specified.");
+        self.param.min_step = min_step;
+        self
+    }
+    pub fn with_max_iterations(mut self, niter: usize) -> Self {
+        self.param.max_iterations = niter as u64;
+        self
+    }
+    pub fn with_max_evaluations(mut self, neval: usize) -> Self {
+        self.param.max_evaluations = neval as u64;
+        self
+    }
+    pub fn with_fx_delta(mut self, delta: f64, past: usize) -> Self {
+        assert!(delta >= 0.0, "Invalid parameter delta specified.");
+        self.param.past = past as u64;
+        self.param.delta = delta;
+        self
+    }
+    pub fn with_linesearch_algorithm(mut self, algo: &str) -> Self {
+        self.param.ls_algorithm = match algo {
+            "MoreThuente" => ffi::LBFGS_LS_MORETHUENTE,
+            "BacktrackingArmijo" => ffi::LBFGS_LS_BACKTRACKING_ARMIJO,
+            "BacktrackingStrongWolfe" => ffi::LBFGS_LS_BACKTRACKING_STRONGWOLFE,
+            "BacktrackingWolfe" | "Backtracking" => ffi::LBFGS_LS_BACKTRACKING_WOLFE,
+            _ => unimplemented!(), // src/lbfgs.rs:379
+        };
+        self
+    }
+    /// EXTENSION: number of corrections (the reference has no setter: always 6).
+    pub fn with_m(mut self, m: usize) -> Self {
+        assert!((1..=64).contains(&m), "m must be in 1..=64");
+        self.param.m = m as u64;
+        self
+    }
+    /// EXTENSION: HIP device index (default 0).
+    pub fn with_device(mut self, device: i32) -> Self {
+        self.device = device;
+        self
+    }
+    /// EXTENSION: hand host copies of x and gx to the progress callback (default true, as the reference does).
+    pub fn with_progress_vectors(mut self, on: bool) -> Self {
+        self.progress_vectors = on;
+        self
+    }
+
+    /// src/lbfgs.rs:399-421, same signature.  `x` is the start point and receives the result in place.
+    pub fn minimize<E, G>(self, x: &mut [f64], mut eval_fn: E, prgr_fn: G) -> Result<Report>
+    where
+        E: FnMut(&[f64], &mut [f64]) -> Result<f64>,
+        G: FnMut(&Progress) -> bool,
+    {
+        let mut bridge = HostBridge { f: &mut eval_fn, err: None };
+        let ev = ffi::lbfgs_evaluator {
+            kind: ffi::LBFGS_EVAL_HOST,
+            fuse_line_eval: 0,
+            host: Some(host_trampoline::<E>),
+            device: None,
+            user: &mut bridge as *mut HostBridge<E> as *mut c_void,
+            builtin: no_objective(),
+        };
+        let r = self.run(x, &ev, prgr_fn);
+        match (r, bridge.err.take()) {
+            (Err(_), Some(user_err)) => Err(user_err), // the closure's own Err, as lbfgs.rs:454 propagates it
+            (r, _) => r,
+        }
+    }
+
+    /// The same loop with a device-resident objective: nothing crosses PCIe except the progress copies.
+    pub fn minimize_builtin<G>(self, x: &mut [f64], objective: Builtin, prgr_fn: G) -> Result<Report>
+    where
+        G: FnMut(&Progress) -> bool,
+    {
+        let mut obj = no_objective();
+        match objective {
+            Builtin::Quadratic => { obj.kind = ffi::LBFGS_HIP_OBJ_QUADRATIC; obj.seed_a = 0x5EED0001; obj.seed_b = 0x5EED0002; }
+            Builtin::Logistic => { obj.kind = ffi::LBFGS_HIP_OBJ_LOGISTIC; obj.seed_a = 0x5EED0003; obj.seed_b = 0x5EED0004; }
+            Builtin::Rosenbrock => { obj.kind = ffi::LBFGS_HIP_OBJ_ROSENBROCK; }
+        }
+        let ev = ffi::lbfgs_evaluator {
+            kind: ffi::LBFGS_EVAL_BUILTIN,
+            fuse_line_eval: 2,
+            host: None,
+            device: None,
+            user: ptr::null_mut(),
+            builtin: obj,
+        };
+        self.run(x, &ev, prgr_fn)
+    }
+
+    fn run<G>(self, x: &mut [f64], ev: &ffi::lbfgs_evaluator, mut prgr_fn: G) -> Result<Report>
+    where
+        G: FnMut(&Progress) -> bool,
+    {
+        let n = x.len();
+        let ctx = Context::new(self.device, n)?;
+        let state = State::build(&ctx, &self.param, x, ev)?;
+        let (mut hx, mut hg) = if self.progress_vectors { (vec![0.0; n], vec![0.0; n]) } else { (vec![], vec![]) };
+        let result = (|| -> Result<Report> {
+            loop {
+                if state.is_converged()? {
+                    break;
+                }
+                let p = state.propagate()?;
+                if self.progress_vectors {
+                    state.download(ffi::LBFGS_VEC_X, &mut hx)?;
+                    state.download(ffi::LBFGS_VEC_GX, &mut hg)?;
+                }
+                let prgr = Progress {
+                    x: &hx, gx: &hg, fx: p.fx, xnorm: p.xnorm, gnorm: p.gnorm, step: p.step,
+                    niter: p.niter as usize, neval: p.neval as usize, ncall: p.ncall as usize,
+                };
+                if prgr_fn(&prgr) {
+                    break; // cancelled (lbfgs.rs:412-416)
+                }
+            }
+            state.report()
+        })();
+        // `x: &mut [f64]` is updated in place in the reference, also when the run ends with Err
+        let copied = state.download(ffi::LBFGS_VEC_X, x);
+        let report = result?;
+        copied?;
+        Ok(report)
+    }
+}
+
+fn no_objective() -> ffi::lbfgs_hip_objective {
+    ffi::lbfgs_hip_objective { kind: 0, _pad: 0, seed_a: 0, seed_b: 0, nbr_index: ptr::null(), max_nbr: 0, _pad2: 0, cutoff: 0.0 }
+}
+
+// ---- the host closure behind the C callback ----------------------------------------------------------
+struct HostBridge<'a, E> {
+    f: &'a mut E,
+    err: Option<anyhow::Error>,
+}
+
+unsafe extern "C" fn host_trampoline<E>(user: *mut c_void, x: *const f64, g: *mut f64, n_local: u64, failed: *mut c_int) -> f64
+where
+    E: FnMut(&[f64], &mut [f64]) -> Result<f64>,
+{
+    // never unwind across the FFI boundary: a panic in the closure is reported as a failed evaluation
+    let outcome = catch_unwind(AssertUnwindSafe(|| {
+        let bridge = &mut *(user as *mut HostBridge<E>);
+        let xs = std::slice::from_raw_parts(x, n_local as usize);
+        let gs = std::slice::from_raw_parts_mut(g, n_local as usize);
+        match (bridge.f)(xs, gs) {
+            Ok(fx) => Some(fx),
+            Err(e) => {
+                bridge.err = Some(e);
+                None
+            }
+        }
+    }));
+    match outcome {
+        Ok(Some(fx)) => fx,
+        _ => {
+            *failed = 1;
+            0.0
+        }
+    }
+}
+
+// ---- RAII handles ---------------------------------------------------------------------------------
+struct Context {
+    raw: *mut ffi::lbfgs_hip_ctx,
+}
+
+impl Context {
+    fn new(device: c_int, n: usize) -> Result<Self> {
+        let mut raw = ptr::null_mut();
+        let rc = unsafe { ffi::lbfgs_hip_ctx_create(&mut raw, device, n as u64, ptr::null(), ptr::null(), ptr::null_mut()) };
+        if rc != ffi::LBFGS_HIP_OK {
+            // there is no CPU fallback: no GPU => an error, never a silent slow path
+            bail!("lbfgs_hip_ctx_create failed ({}): {}", rc, cstr(unsafe { ffi::lbfgs_hip_last_error(ptr::null()) }));
+        }
+        Ok(Context { raw })
+    }
+}
+
+impl Drop for Context {
+    fn drop(&mut self) {
+        unsafe { ffi::lbfgs_hip_ctx_destroy(self.raw) }
+    }
+}
+
+struct State<'c> {
+    raw: *mut ffi::lbfgs_state,
+    _ctx: &'c Context, // the state must not outlive its context
+}
+
+impl<'c> State<'c> {
+    fn build(ctx: &'c Context, param: &ffi::lbfgs_param, x0: &[f64], ev: &ffi::lbfgs_evaluator) -> Result<Self> {
+        let mut raw = ptr::null_mut();
+        let rc = unsafe { ffi::lbfgs_build(&mut raw, ctx.raw, param, x0.as_ptr(), ev) };
+        if rc != ffi::LBFGS_HIP_OK {
+            return Err(status_error(rc, cstr(unsafe { ffi::lbfgs_state_error(ptr::null()) })));
+        }
+        Ok(State { raw, _ctx: ctx })
+    }
+    fn check(&self, rc: c_int) -> Result<()> {
+        if rc == ffi::LBFGS_HIP_OK {
+            Ok(())
+        } else {
+            Err(status_error(rc, cstr(unsafe { ffi::lbfgs_state_error(self.raw) })))
+        }
+    }
+    fn is_converged(&self) -> Result<bool> {
+        let mut c: c_int = 0;
+        self.check(unsafe { ffi::lbfgs_is_converged(self.raw, &mut c) })?;
+        Ok(c != 0)
+    }
+    fn propagate(&self) -> Result<ffi::lbfgs_progress> {
+        let mut p = ffi::lbfgs_progress::default();
+        self.check(unsafe { ffi::lbfgs_propagate(self.raw, &mut p) })?;
+        Ok(p)
+    }
+    fn report(&self) -> Result<Report> {
+        let mut r = ffi::lbfgs_report::default();
+        self.check(unsafe { ffi::lbfgs_get_report(self.raw, &mut r) })?;
+        Ok(Report { fx: r.fx, xnorm: r.xnorm, gnorm: r.gnorm, neval: r.neval as usize })
+    }
+    fn download(&self, which: c_int, host: &mut [f64]) -> Result<()> {
+        self.check(unsafe { ffi::lbfgs_state_download(self.raw, which, host.as_mut_ptr()) })
+    }
+}
+
+impl<'c> Drop for State<'c> {
+    fn drop(&mut self) {
+        unsafe { ffi::lbfgs_state_free(self.raw) }
+    }
+}
+
+fn cstr(p: *const std::os::raw::c_char) -> String {
+    if p.is_null() {
+        String::new()
+    } else {
+        unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned()
+    }
+}
+
+/// Status codes of include/lbfgs_solver.h.  The reference *panics* at two sites (orthantwise.rs:64, :160); the C
+/// library reports them as codes and the panic is re-raised here so callers see the crate's behaviour.
+fn status_error(rc: c_int, msg: String) -> anyhow::Error {
+    if rc == ffi::LBFGS_PANIC_OWLQN_RANGE || rc == ffi::LBFGS_PANIC_ZERO_DIRECTION {
+        panic!("{}", msg);
+    }
+    anyhow!("{} (status {})", msg, rc)
+}

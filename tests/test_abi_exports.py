@@ -65,3 +65,82 @@ def test_product_libraries_do_not_link_the_oracle(libs):
 
 def test_abi_version(libs):
     assert libs[0].lbfgs_hip_abi_version() == 1
+
+
+# ---------------------------------------------------------------------------------------------
+# struct layouts: C headers (gcc, offsetof) == ctypes binding == the Rust shim's #[repr(C)] mirrors
+# ---------------------------------------------------------------------------------------------
+STRUCTS = {  # C / Rust name -> ctypes mirror
+    "lbfgs_hip_shard": _ffi.Shard, "lbfgs_hip_comm": _ffi.Comm, "lbfgs_hip_objective": _ffi.Objective,
+    "lbfgs_param": _ffi.Param, "lbfgs_evaluator": _ffi.Evaluator, "lbfgs_progress": _ffi.CProgress,
+    "lbfgs_report": _ffi.CReport,
+}
+RUST_FFI = os.path.join(ROOT, "integration", "rust-shim", "src", "ffi.rs")
+
+
+def test_ctypes_structs_match_the_c_headers(tmp_path):
+    import subprocess
+
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "lbfgs_solver.h"', "int main(void) {"]
+    for cname, cls in STRUCTS.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    seen = 0
+    for ln in out.splitlines():
+        cname, field, val = ln.split()
+        cls = STRUCTS[cname]
+        if field == "size":
+            assert C.sizeof(cls) == int(val), cname
+        else:
+            assert getattr(cls, field).offset == int(val), (cname, field)
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in STRUCTS.values())
+
+
+def _rust_structs():
+    txt = open(RUST_FFI).read()
+    out = {}
+    for m in re.finditer(r"pub struct (\w+) \{\n(.*?)\n\}", txt, flags=re.S):
+        fields = re.findall(r"pub (\w+): ([^,\n]+),", m.group(2))
+        if fields:
+            out[m.group(1)] = fields
+    return out
+
+
+def test_rust_shim_mirrors_the_abi(libs):
+    """integration/rust-shim cannot be compiled here (no rustc): at least every function it declares exists, and
+    every #[repr(C)] struct lists the same fields, in the same order and of the same width, as the ctypes binding
+    (which the test above ties to the C headers)."""
+    txt = open(RUST_FFI).read()
+    fns = re.findall(r"pub fn (lbfgs_\w+)\s*\(", txt)
+    assert len(fns) >= 40
+    for nm in fns:
+        assert hasattr(libs[0], nm) or hasattr(libs[1], nm), nm
+    width = {"i32": 4, "u32": 4, "i64": 8, "u64": 8, "f64": 8}
+    rs = _rust_structs()
+    for cname, cls in STRUCTS.items():
+        assert cname in rs, cname
+        assert [f for f, _ in rs[cname]] == [f for f, _ in cls._fields_], cname
+        for (fname, rtype), (_, ctype) in zip(rs[cname], cls._fields_):
+            rtype = rtype.strip()
+            if rtype in width:
+                assert width[rtype] == C.sizeof(ctype), (cname, fname)
+            elif rtype in rs or rtype in STRUCTS:           # nested struct by value
+                assert C.sizeof(ctype) == C.sizeof(STRUCTS[rtype]), (cname, fname)
+            else:                                            # raw pointer or Option<extern fn>: pointer sized
+                assert rtype.startswith("*") or rtype.endswith("_cb"), (cname, fname, rtype)
+                assert C.sizeof(ctype) == C.sizeof(C.c_void_p), (cname, fname)
+    # constants the shim relies on
+    consts = dict(re.findall(r"pub const (\w+): \w+ = (-?\d+);", txt))
+    hdr = open(os.path.join(ROOT, "include", "lbfgs_hip.h")).read() + open(os.path.join(ROOT, "include", "lbfgs_solver.h")).read()
+    for name, val in consts.items():
+        m = re.search(r"\b" + name + r"\s*=\s*(-?\d+)", hdr)
+        if m:
+            assert int(m.group(1)) == int(val), name

@@ -296,6 +296,24 @@ int main(int argc, char** argv) {
         sweep_copy<4, ~0u, ~0u, 2>(b, g1);
         return 0;
     }
+    if (argc > 2 && atoi(argv[2]) == -4) {  // do the three streams of the step kernel collide in DRAM banks? stagger their bases
+        const size_t pad = 64u << 20;
+        double *big_u, *big_v;
+        CK(hipMalloc(&big_u, bytes + pad));
+        CK(hipMalloc(&big_v, bytes + pad));
+        const size_t offs[] = {0, 256, 4096, 8192, 65536, 65536 + 4096, 1u << 20, (1u << 20) + 8192, (2u << 20) + 4096, (16u << 20) + 65536 + 4096};
+        printf("bases: q=%p u=%p v=%p\n", (void*)b.q, (void*)big_u, (void*)big_v);
+        for (size_t o : offs) {
+            Bufs c = b;
+            c.u = reinterpret_cast<double*>(reinterpret_cast<char*>(big_u) + o);
+            c.v = reinterpret_cast<double*>(reinterpret_cast<char*>(big_v) + 2 * o);
+            CK(hipMemcpy(c.u, h.data(), bytes, hipMemcpyHostToDevice));
+            CK(hipMemcpy(c.v, h.data(), bytes, hipMemcpyHostToDevice));
+            printf("u += %zu B, v += %zu B: ", o, 2 * o);
+            sweep_step<2, ~0u, ~0u, 1, 1>(c, {216});
+        }
+        return 0;
+    }
     if (argc > 2 && atoi(argv[2]) == -3) {  // two steps of the recursion as peek (3r) + pair (4r 1w) against 2 x (3r 1w)
         double* extra[4];
         for (auto& e : extra) { CK(hipMalloc(&e, bytes)); CK(hipMemcpy(e, h.data(), bytes, hipMemcpyHostToDevice)); }
