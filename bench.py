@@ -273,6 +273,30 @@ def measure(env, ctx, label, vector_free=False):
     return res
 
 
+def calibrate(ctx, reps=20):
+    """What this box's HBM delivers to the plainest kernels of the library: copy (1r 1w) and dot (2r), on vectors of
+    the bench's shard size.  SURVEY 8(d) asks for the achievable-copy figure beside the 8 TB/s spec peak."""
+    from rust_lbfgs_amd.math import DeviceVec
+
+    u, v = DeviceVec(ctx), DeviceVec(ctx)
+    try:
+        out = {}
+        for name, fn, passes in (("copy_1r1w_GBps", lambda: v.veccpy(u), 2), ("dot_2r_GBps", lambda: u.vecdot_slot(v, 250), 2)):
+            for _ in range(3):
+                fn()
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            ctx.sync()
+            dt = (time.perf_counter() - t0) / reps
+            out[name] = round(8.0 * passes * ctx.n_local / dt / 1e9, 1)
+        return out
+    finally:
+        u.free()
+        v.free()
+
+
 def main():
     a = parse()
     # stdout carries exactly ONE JSON line: RCCL, gloo and friends print banners to fd 1, so park it on stderr
@@ -296,6 +320,13 @@ def main():
             continue
         r = measure(env, ctx, label)
         if r is not None:
+            if r["roofline"].get("achieved"):
+                try:  # both denominators: the spec peak (frac) and what a plain copy achieves on this box
+                    cal = calibrate(ctx)
+                    r["roofline"]["calibration"] = cal
+                    r["roofline"]["frac_of_copy"] = r["roofline"]["achieved"] / cal["copy_1r1w_GBps"]
+                except Exception as e:  # noqa: BLE001
+                    print(f"[bench] calibration skipped: {e}", file=sys.stderr)
             results.append(r)
             if not a.no_vector_free and a.m <= 10:
                 # EXTENSION, reported beside the headline, never as `value`: the same iteration with the
