@@ -157,6 +157,23 @@ def make_context(env, kind):
                 ctx.check(ctx._L.lbfgs_hip_scalars_allreduce(ctx._h, 200, 3))
                 if list(ctx.scalars(200, 3)) != [tri * (it + 1), 1.0, -0.5 * tri]:
                     ok = 0.0
+        # ... and a reduction closed INSIDE a streaming kernel (p2p: by its last workgroup; rccl: on-stream after it):
+        # sum over ranks of n_local * (rank+1)^2, exact in f64 in any summation order
+        from rust_lbfgs_amd.dist import shard_range
+        from rust_lbfgs_amd.math import DeviceVec
+
+        u = DeviceVec(ctx)
+        try:
+            want = 0.0
+            for r in range(env.world):
+                lo, hi = shard_range(a.n, r, env.world)
+                want += float(hi - lo) * (r + 1) ** 2
+            for it in range(4):
+                u.fill(float(env.rank + 1))
+                if u.vecdot(u) != want:
+                    ok = 0.0
+        finally:
+            u.free()
     except Exception as e:  # noqa: BLE001
         print(f"[bench] rank {env.rank}: {kind} communicator unavailable: {e}", file=sys.stderr)
         ok = 0.0
@@ -274,14 +291,17 @@ def measure(env, ctx, label, vector_free=False):
 
 
 def calibrate(ctx, reps=20):
-    """What this box's HBM delivers to the plainest kernels of the library: copy (1r 1w) and dot (2r), on vectors of
-    the bench's shard size.  SURVEY 8(d) asks for the achievable-copy figure beside the 8 TB/s spec peak."""
+    """What this box's HBM delivers to the plainest kernels of the library: copy (1r 1w) and triad y += c*x (2r 1w), on
+    vectors of the bench's shard size.  SURVEY 8(d) asks for the achievable-copy figure beside the 8 TB/s spec peak.
+    No reductions here: nothing in this function is a collective, so ranks may run it independently."""
     from rust_lbfgs_amd.math import DeviceVec
 
     u, v = DeviceVec(ctx), DeviceVec(ctx)
     try:
         out = {}
-        for name, fn, passes in (("copy_1r1w_GBps", lambda: v.veccpy(u), 2), ("dot_2r_GBps", lambda: u.vecdot_slot(v, 250), 2)):
+        if ctx.n_local == 0:
+            return {"copy_1r1w_GBps": None, "triad_2r1w_GBps": None}
+        for name, fn, passes in (("copy_1r1w_GBps", lambda: v.veccpy(u), 2), ("triad_2r1w_GBps", lambda: v.vecadd(u, 1e-9), 3)):
             for _ in range(3):
                 fn()
             ctx.sync()
@@ -324,7 +344,8 @@ def main():
                 try:  # both denominators: the spec peak (frac) and what a plain copy achieves on this box
                     cal = calibrate(ctx)
                     r["roofline"]["calibration"] = cal
-                    r["roofline"]["frac_of_copy"] = r["roofline"]["achieved"] / cal["copy_1r1w_GBps"]
+                    if cal["copy_1r1w_GBps"]:
+                        r["roofline"]["frac_of_copy"] = r["roofline"]["achieved"] / cal["copy_1r1w_GBps"]
                 except Exception as e:  # noqa: BLE001
                     print(f"[bench] calibration skipped: {e}", file=sys.stderr)
             results.append(r)

@@ -89,3 +89,41 @@ def test_three_processes_one_gpu_with_an_empty_shard(kind, tmp_path, monkeypatch
         assert got[:3] == ref[:3]
         for a, b in zip(got[3:], ref[3:]):
             assert abs(a - b) <= 1e-9 * max(abs(b), 1e-6)
+
+
+@pytest.mark.parametrize("world,kind", [(1, "auto"), (3, "callback"), (2, "p2p")])
+def test_bench_contract_line(world, kind, tmp_path):
+    """bench.py end to end at a tiny size: exactly ONE JSON line on stdout with the contract's keys, also when a
+    rank holds an EMPTY shard (world 3, n = 1000) -- every rank must take the same collective decisions."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs the GPU")
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--gpus", str(world), "--steps", "6", "--warmup", "12", "--dim", "1000" if world > 1 else "200000",
+            "--cpu-n", "20000", "--device", "0"]
+    if world == 1:
+        cmd = [sys.executable, "bench.py"] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+               "127.0.0.1", "--master-port", str(29600 + world), "bench.py"] + args + ["--comm", kind, "--pg-backend", "gloo"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in j, key
+    assert j["n_gpus"] == world and j["steps"] == 6 and j["warmup"] == 12 and j["dtype"] == "f64"
+    assert j["vs_baseline"] is None and j["value"] > 0 and "workload" in j["config"]
+    r = j["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0
+    if world == 1:
+        c = j["cpu_baseline"]
+        assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
