@@ -331,17 +331,13 @@ __device__ __forceinline__ void do_pair(const Op& op, const typename Op::Coef& c
 //   2  grid-stride over SPAN*UNROLL*4 KiB super-chunks (each workgroup reads SPAN*UNROLL adjacent
 //      chunks, UNROLL at a time).
 // NTI / NTO are bit masks over the input / output streams: bit s set = stream s uses the `nt` hint.
-template <class Op, int UNR = UNROLL, unsigned NTI = 0, unsigned NTO = 0, int MAP = 0, int SPAN = 1>
-__global__ __launch_bounds__(BLOCK) void stream_kernel(const Op op, const uint64_t n, const uint64_t gofs,
-                                                        const RedCtl red) {
+// The sweep itself: this workgroup's share of the n elements, running sums into acc[].  Shared by the one-launch-
+// per-operator kernel below and by experiments that call it from other kernels (tools/tune_stream.hip).
+template <class Op, int UNR, unsigned NTI, unsigned NTO, int MAP, int SPAN>
+__device__ __forceinline__ void stream_body(const Op& op, const typename Op::Coef& cf, const uint64_t n,
+                                            const uint64_t gofs, double* acc) {
     constexpr int UNROLL = UNR;
-    constexpr int NIN = Op::NIN, NOUT = Op::NOUT, NRED = Op::NRED;
-    static_assert(NRED <= MAX_RED, "partials buffer overflow");
-    const typename Op::Coef cf = op.setup();
-    double acc[NRED ? NRED : 1];
-#pragma unroll
-    for (int k = 0; k < (NRED ? NRED : 1); ++k) acc[k] = 0.0;
-
+    constexpr int NIN = Op::NIN, NOUT = Op::NOUT;
     const uint64_t n2 = n >> 1;                           // 16-byte pairs
     const uint64_t nch = (n2 + BLOCK - 1) / BLOCK;        // chunks of BLOCK pairs (4 KiB per stream)
     const uint64_t tid = threadIdx.x;
@@ -411,6 +407,18 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const Op op, const uint64
             for (int s = 0; s < NOUT; ++s) op.out[s][e] = wa[s];
         }
     }
+}
+
+template <class Op, int UNR = UNROLL, unsigned NTI = 0, unsigned NTO = 0, int MAP = 0, int SPAN = 1>
+__global__ __launch_bounds__(BLOCK) void stream_kernel(const Op op, const uint64_t n, const uint64_t gofs,
+                                                        const RedCtl red) {
+    constexpr int NRED = Op::NRED;
+    static_assert(NRED <= MAX_RED, "partials buffer overflow");
+    const typename Op::Coef cf = op.setup();
+    double acc[NRED ? NRED : 1];
+#pragma unroll
+    for (int k = 0; k < (NRED ? NRED : 1); ++k) acc[k] = 0.0;
+    stream_body<Op, UNR, NTI, NTO, MAP, SPAN>(op, cf, n, gofs, acc);
     if constexpr (NRED > 0) grid_reduce<NRED>(reinterpret_cast<double(&)[NRED]>(acc), red);
 }
 

@@ -268,6 +268,89 @@ void sweep_peek_pair(const Bufs& b, const std::vector<int>& grids, double* extra
     }
 }
 
+// EXPERIMENT (not adopted, profiles/r01_tune_persistent_two_loop.log): grid-wide all-reduce for a persistent kernel.
+namespace lh {
+// ---- persistent kernels: a grid-wide sum that EVERY workgroup receives ---------------------------------------
+// For kernels that stay resident across dependent phases (the persistent two-loop): all workgroups must be
+// co-resident (cooperative launch).  Phase `step` (0, 1, 2, ... within one launch): each workgroup publishes its
+// partials, signals a monotonic arrival counter, waits until all G have signalled, then sums all partials itself in
+// the same fixed order as grid_reduce's last workgroup -- so the totals are bitwise those of the one-launch-per-step
+// path.  The partial buffers alternate with the parity of `step`: a workgroup can be at most one phase ahead of the
+// slowest one, which may still be reading the previous phase's buffer.  The release/acquire fences at agent scope
+// also order the streamed vector itself (a phase may read elements another workgroup wrote in the previous phase,
+// and L1 lines of this CU may be stale).  The spin is bounded by a wall-clock timeout that raises *err.
+constexpr int PERSIST_MAX_RED = 4;
+struct PersistCtl {
+    double* partials;              // [2][PERSIST_MAX_RED][MAX_GRID]
+    unsigned int* arrive;          // zero at launch
+    unsigned int* err;
+    unsigned long long timeout_ticks;
+};
+
+template <int NRED, bool FENCES = true>
+__device__ __forceinline__ void grid_allreduce(double (&acc)[NRED], const PersistCtl& pc, unsigned int step) {
+    static_assert(NRED <= PERSIST_MAX_RED, "persistent partial buffer");
+    __shared__ double lds[NRED][WAVES];
+    __shared__ double s_tot[NRED];
+    block_sum<NRED>(acc, lds);
+    const unsigned int G = gridDim.x;
+    double* buf = pc.partials + (size_t)(step & 1u) * PERSIST_MAX_RED * MAX_GRID;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NRED; ++k) store_agent(buf + (size_t)k * MAX_GRID + blockIdx.x, acc[k]);
+    }
+    if constexpr (FENCES) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this thread's stores (vector + partials) have left the CU
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(pc.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int target = G * (step + 1u);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(pc.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if ((unsigned long long)(wall_clock64() - t0) > pc.timeout_ticks) {
+                atomicExch(pc.err, 2u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    if constexpr (FENCES) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing cached in this CU predates the barrier
+    double tot[NRED];
+#pragma unroll
+    for (int k = 0; k < NRED; ++k) {
+        double t = 0.0;
+        for (unsigned int b = threadIdx.x; b < G; b += BLOCK) t += load_agent(buf + (size_t)k * MAX_GRID + b);
+        tot[k] = t;
+    }
+    block_sum<NRED>(tot, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NRED; ++k) s_tot[k] = tot[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NRED; ++k) acc[k] = s_tot[k];
+    __syncthreads();  // lds / s_tot are reused by the next phase
+}
+
+}  // namespace lh
+
+// EXPERIMENT: STEPS dependent two-loop steps inside ONE persistent launch (grid barrier + consumer-side sum per step)
+template <int UNR, unsigned NT, int MAP, bool FENCES>
+__global__ __launch_bounds__(BLOCK) void persist_probe(OpTwoLoopStep<false, false, 0> op, uint64_t n, PersistCtl pc, int steps,
+                                                        double* out) {
+    double tot[1] = {1e-12};
+    for (int s = 0; s < steps; ++s) {
+        TwoLoopCoef cf{tot[0] * 1e-30, 1.0};
+        double acc[1] = {0.0};
+        stream_body<decltype(op), UNR, NT, NT, MAP, 1>(op, cf, n, 0, acc);
+        grid_allreduce<1, FENCES>(acc, pc, (unsigned)s);
+        tot[0] = acc[0];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out = tot[0];
+}
+
 int main(int argc, char** argv) {
     Bufs b{};
     b.n = argc > 1 ? strtoull(argv[1], nullptr, 10) : 100000000ULL;
@@ -294,6 +377,52 @@ int main(int argc, char** argv) {
         printf("LH_STORE_POLICY=%d\n", LH_STORE_POLICY);
         sweep_step<2, ~0u, ~0u, 1, 1>(b, g1);
         sweep_copy<4, ~0u, ~0u, 2>(b, g1);
+        return 0;
+    }
+    if (argc > 2 && atoi(argv[2]) == -5) {  // persistent two-loop probe vs one launch per step
+        const int STEPS = 20;
+        OpTwoLoopStep<false, false, 0> op{};
+        op.in[0] = b.q; op.in[1] = b.u; op.in[2] = b.v; op.out[0] = b.q;
+        op.dot_in = b.board; op.ys_j = b.board + 1; op.alpha_j = b.board + 10; op.gamma_num = b.board; op.gamma_den = b.board + 1;
+        op.mode_b = 1;
+        PersistCtl pc{};
+        CK(hipMalloc(&pc.partials, 2 * PERSIST_MAX_RED * MAX_GRID * sizeof(double)));
+        CK(hipMalloc(&pc.arrive, 64));
+        CK(hipMalloc(&pc.err, 64));
+        CK(hipMemset(pc.err, 0, 64));
+        pc.timeout_ticks = 200000000ULL;  // 2 s
+        RedCtl red{};
+        red.partials = b.partials; red.ticket = b.ticket;
+        for (int k = 0; k < RED_PTRS; ++k) red.out[k] = b.board + 2 + k;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int grid : {216, 256}) {
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipEventRecord(e0, 0));
+                for (int i = 0; i < STEPS; ++i)
+                    hipLaunchKernelGGL((stream_kernel<decltype(op), 2, 0u, 0u, 1, 1>), dim3(grid), dim3(BLOCK), 0, 0, op, b.n, 0, red);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep == 2) printf("n=%llu grid=%d: %d launches           : %8.1f us per step\n", (unsigned long long)b.n, grid, STEPS, ms * 1000 / STEPS);
+            }
+            for (int fences = 0; fences < 2; ++fences)
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipMemsetAsync(pc.arrive, 0, 4, 0));
+                int steps = STEPS;
+                uint64_t n = b.n;
+                double* out = b.board + 40;
+                void* args[] = {&op, &n, &pc, &steps, &out};
+                CK(hipEventRecord(e0, 0));
+                if (fences) CK(hipLaunchCooperativeKernel((const void*)persist_probe<2, 0u, 1, true>, dim3(grid), dim3(BLOCK), args, 0, 0));
+                else CK(hipLaunchCooperativeKernel((const void*)persist_probe<2, 0u, 1, false>, dim3(grid), dim3(BLOCK), args, 0, 0));
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                unsigned err = 0; CK(hipMemcpy(&err, pc.err, 4, hipMemcpyDeviceToHost));
+                if (rep == 2) printf("n=%llu grid=%d: 1 persistent launch f=%d: %8.1f us per step (err=%u)\n", (unsigned long long)b.n, grid, fences, ms * 1000 / STEPS, err);
+            }
+        }
         return 0;
     }
     if (argc > 2 && atoi(argv[2]) == -4) {  // do the three streams of the step kernel collide in DRAM banks? stagger their bases
