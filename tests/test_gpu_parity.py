@@ -751,7 +751,7 @@ def test_random_configurations_match_oracle(seed):
                 stable = False
                 break
             scale = (max(abs(a[3]), 1e-6 * f0), max(a[4], 1e-300), max(a[5], 1e-6 * g0), abs(a[6]))
-            floor = max(floor, max(abs(u - v) / s for u, v, s in zip(a[3:], w[3:], scale)))
+            floor = max(floor, max((0.0 if (u != u and v != v) else abs(u - v) / s) for u, v, s in zip(a[3:], w[3:], scale)))
             if floor > 1e-8:  # the run has become chaotic for ANY summation order: stop comparing
                 stable = False
                 break
@@ -760,7 +760,9 @@ def test_random_configurations_match_oracle(seed):
             assert a[:3] == b[:3], (c, a, b)
             tol = max(1e-10, 20.0 * floor) * (50.0 if vf else 1.0)
             for u, v, s in zip(a[3:], b[3:], scale):
-                assert abs(u - v) <= tol * s, (c, i, a, b, floor)
+                # NaN is a legitimate value here: More-Thuente's cubic step has no guard under its sqrt (line.rs:629) and
+                # an exhausted search returns that step -- the product must produce the NaN too
+                assert (u != u and v != v) or abs(u - v) <= tol * s, (c, i, a, b, floor)
         if stable:
             assert ep == eo, (c, eo, ep)
             assert len(rp) == len(ro)

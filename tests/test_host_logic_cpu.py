@@ -313,5 +313,8 @@ def test_random_configurations_match_oracle_exactly(seed):
     ro, xo, eo = F.run_oracle(c)
     rp, xp, ep = F.run_product(R, objectives, c)
     assert eo == ep, (c, eo, ep)
-    assert ro == rp, c
-    assert np.array_equal(xo, xp), c
+    # bit for bit; NaN == NaN here (an exhausted More-Thuente search can return a NaN step: line.rs:629 has no guard)
+    assert len(ro) == len(rp), c
+    for a, b in zip(ro, rp):
+        assert np.array_equal(np.array(a, dtype=np.float64), np.array(b, dtype=np.float64), equal_nan=True), (c, a, b)
+    assert np.array_equal(xo, xp, equal_nan=True), c

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""One-off soak of the seeded random sweep on the HIP path with MANY seeds (the test suite runs seeds 0..59):
+    python tools/fuzz_soak.py 60 1500
+Prints one line per failing seed and a summary; exit code 1 if any seed fails."""
+import os
+import sys
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import tests.test_gpu_parity as T  # noqa: E402
+
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+bad = []
+for seed in range(lo, hi):
+    try:
+        T.test_random_configurations_match_oracle(seed)
+    except Exception:  # noqa: BLE001
+        bad.append(seed)
+        print("FAIL seed", seed, traceback.format_exc().splitlines()[-1][:600], flush=True)
+    if seed % 100 == 0:
+        print("... seed", seed, "failures so far", len(bad), flush=True)
+print("seeds", lo, "..", hi - 1, "failures:", bad)
+sys.exit(1 if bad else 0)
