@@ -33,6 +33,25 @@ static double dot_pairwise(const double* x, const double* y, size_t n) {
     return dot_pairwise(x, y, h) + dot_pairwise(x + h, y + h, n - h);
 }
 
+/* DIAGNOSTIC ONLY (dot mode 1): pairwise sum of a term array; used by every sum of the restatement that the
+ * reference forms sequentially -- vecdot, x1norm and the objectives' f -- so that mode 1 perturbs ALL of them. */
+static double sum_pairwise(const double* t, size_t n) {
+    if (n <= 32) {
+        double acc = 0.0;
+        for (size_t i = 0; i < n; ++i) acc += t[i];
+        return acc;
+    }
+    size_t h = n / 2;
+    return sum_pairwise(t, h) + sum_pairwise(t + h, n - h);
+}
+int oracle_dot_mode(void) { return g_dot_mode; }
+double oracle_sum_terms(const double* t, size_t n) {
+    if (g_dot_mode == 1) return sum_pairwise(t, n);
+    double acc = 0.0;
+    for (size_t i = 0; i < n; ++i) acc += t[i];
+    return acc;
+}
+
 /* math.rs:33-37  y += c*x */
 void oracle_vecadd(double* y, const double* x, double c, size_t n) {
     for (size_t i = 0; i < n; ++i) y[i] += c * x[i];
@@ -94,6 +113,15 @@ int oracle_owl_range(const oracle_param* p, size_t n, size_t* start, size_t* end
 
 /* orthantwise.rs:70-79: the multiply by c is inside the sum */
 double oracle_x1norm(double c, size_t start, size_t end, const double* x) {
+    if (g_dot_mode == 1 && end > start) {  /* diagnostic: the same terms, pairwise */
+        double* t = (double*)malloc((end - start) * sizeof(double));
+        if (t) {
+            for (size_t i = start; i < end; ++i) t[i - start] = c * fabs(x[i]);
+            double r = sum_pairwise(t, end - start);
+            free(t);
+            return r;
+        }
+    }
     double s = 0.0;
     for (size_t i = start; i < end; ++i) s += c * fabs(x[i]);
     return s;

@@ -108,8 +108,12 @@ typedef struct oracle_report {
 /* ---- math.rs:31-82 -------------------------------------------------------- */
 /* dot mode: 0 = sequential left-to-right (the reference, math.rs:41);
  * 1 = pairwise tree (diagnostic only: attributes GPU-vs-oracle differences to
- * summation order).  Process-global, default 0. */
+ * summation order).  Mode 1 reorders EVERY sum of the restatement: vecdot, x1norm and the f of the built-in
+ * objectives.  Process-global, default 0. */
 void oracle_set_dot_mode(int mode);
+int oracle_dot_mode(void);
+/* sum of a term array in the current mode (sequential = the reference; pairwise = diagnostic) */
+double oracle_sum_terms(const double* t, size_t n);
 void oracle_vecadd(double* y, const double* x, double c, size_t n);    /* y += c*x  */
 double oracle_vecdot(const double* x, const double* y, size_t n);      /* sum x*y   */
 void oracle_vecscale(double* y, double c, size_t n);                   /* y *= c    */

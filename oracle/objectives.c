@@ -17,20 +17,46 @@
 #include "lbfgs_oracle.h"
 
 #include <math.h>
+#include <stdlib.h>
+
+/* f = sum of per-element (per-pair) terms.  Mode 0 (the reference): running sum in index order, exactly as the cited
+ * loops.  Diagnostic mode 1: the same terms summed pairwise (oracle_sum_terms), so that the summation-order
+ * sensitivity estimate of the tests also perturbs f, not only the dot products. */
+typedef struct fsum {
+    double acc;
+    double* terms;
+    size_t k;
+} fsum;
+static void fsum_begin(fsum* s, size_t nterms) {
+    s->acc = 0.0;
+    s->k = 0;
+    s->terms = (oracle_dot_mode() == 1 && nterms) ? (double*)malloc(nterms * sizeof(double)) : NULL;
+}
+static inline void fsum_add(fsum* s, double t) {
+    if (s->terms) s->terms[s->k++] = t;
+    else s->acc += t;
+}
+static double fsum_end(fsum* s) {
+    if (!s->terms) return s->acc;
+    double r = oracle_sum_terms(s->terms, s->k);
+    free(s->terms);
+    return r;
+}
 
 /* src/lib.rs:79-94 */
 double oracle_obj_rosenbrock(void* user, const double* x, double* g, size_t n, int* failed) {
     (void)user;
     (void)failed;
-    double fx = 0.0;
+    fsum fx;
+    fsum_begin(&fx, n / 2);
     for (size_t i = 0; i + 1 < n; i += 2) {
         double t1 = 1.0 - x[i];
         double t2 = 10.0 * (x[i + 1] - x[i] * x[i]);
         g[i + 1] = 20.0 * t2;
         g[i] = -2.0 * (x[i] * g[i + 1] + t1);
-        fx += t1 * t1 + t2 * t2;
+        fsum_add(&fx, t1 * t1 + t2 * t2);
     }
-    return fx;
+    return fsum_end(&fx);
 }
 
 /* splitmix64 finaliser applied to a counter: state = seed + (i+1)*golden */
@@ -50,7 +76,8 @@ double oracle_hash_u01(uint64_t seed, uint64_t i) {
 double oracle_obj_quadratic(void* user, const double* x, double* g, size_t n, int* failed) {
     const oracle_hashed_obj* o = (const oracle_hashed_obj*)user;
     (void)failed;
-    double fx = 0.0;
+    fsum fx;
+    fsum_begin(&fx, n);
     for (size_t i = 0; i < n; ++i) {
         uint64_t gi = o->global_offset + i;
         double ua = oracle_hash_u01(o->seed_a, gi);
@@ -59,9 +86,9 @@ double oracle_obj_quadratic(void* user, const double* x, double* g, size_t n, in
         double b = 2.0 * ub - 1.0;
         double t = a * x[i];
         g[i] = t - b;
-        fx += x[i] * (0.5 * t - b);
+        fsum_add(&fx, x[i] * (0.5 * t - b));
     }
-    return fx;
+    return fsum_end(&fx);
 }
 
 /* f = sum_i log(1 + exp(-z_i)), z_i = w_i*x_i, w_i = t_i*a_i,
@@ -70,7 +97,8 @@ double oracle_obj_quadratic(void* user, const double* x, double* g, size_t n, in
 double oracle_obj_logistic(void* user, const double* x, double* g, size_t n, int* failed) {
     const oracle_hashed_obj* o = (const oracle_hashed_obj*)user;
     (void)failed;
-    double fx = 0.0;
+    fsum fx;
+    fsum_begin(&fx, n);
     for (size_t i = 0; i < n; ++i) {
         uint64_t gi = o->global_offset + i;
         double a = 0.5 + 1.5 * oracle_hash_u01(o->seed_a, gi);
@@ -86,9 +114,9 @@ double oracle_obj_logistic(void* user, const double* x, double* g, size_t n, int
             fi -= z;
         }
         g[i] = -w * sig;
-        fx += fi;
+        fsum_add(&fx, fi);
     }
-    return fx;
+    return fsum_end(&fx);
 }
 
 /* examples/lj.rs:20-64 with epsilon = sigma = 1, then gx.vecscale(-1.0) (:116) */
