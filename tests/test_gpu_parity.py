@@ -750,7 +750,7 @@ def test_random_configurations_match_oracle(seed):
             if a[:3] != w[:3]:
                 stable = False
                 break
-            scale = (max(abs(a[3]), 1e-6 * f0), max(a[4], 1e-300), max(a[5], 1e-6 * g0), abs(a[6]))
+            scale = (max(abs(a[3]), 1e-6 * f0), max(a[4], 1e-300), max(a[5], 1e-6 * g0), max(abs(a[6]), 1e-300))
             floor = max(floor, max((0.0 if (u != u and v != v) else abs(u - v) / s) for u, v, s in zip(a[3:], w[3:], scale)))
             if floor > 1e-8:  # the run has become chaotic for ANY summation order: stop comparing
                 stable = False
