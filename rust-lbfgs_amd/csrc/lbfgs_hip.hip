@@ -302,6 +302,7 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out,
             red.mirror.board = ctx->board;
             red.mirror.host_seq = reinterpret_cast<unsigned long long*>(ctx->mirror_dev + LBFGS_HIP_BOARD_SLOTS + 2);
             red.mirror.seq = ++ctx->mirror_seq;
+            red.mirror.host_err = reinterpret_cast<unsigned long long*>(ctx->mirror_dev + LBFGS_HIP_BOARD_SLOTS + 3);
             red.mirror.slots = LBFGS_HIP_BOARD_SLOTS + 2;
         }
     }
@@ -856,12 +857,11 @@ int lbfgs_hip_scalars_read(lbfgs_hip_ctx* ctx, int first, int count, double* hos
             }
             if (ok) {
                 memcpy(host, ctx->mirror + first, count * sizeof(double));
-                if (ctx->p2p_err) {  // a timed-out exchange must not go unnoticed on the fast path either
-                    unsigned int flag = 0;
-                    HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->p2p_err, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
-                    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                    if (flag) return fail(ctx, LBFGS_HIP_ERR_COMM, "P2P all-reduce timed out waiting for a peer");
-                }
+                // a timed-out in-kernel exchange is published next to the results (before the sequence word)
+                const volatile unsigned long long* perr =
+                    reinterpret_cast<volatile unsigned long long*>(ctx->mirror + LBFGS_HIP_BOARD_SLOTS + 3);
+                if (ctx->p2p_err && *perr)
+                    return fail(ctx, LBFGS_HIP_ERR_COMM, "P2P all-reduce timed out waiting for a peer");
                 return LBFGS_HIP_OK;
             }
         }

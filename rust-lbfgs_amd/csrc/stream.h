@@ -68,6 +68,7 @@ struct MirrorCtl {
     const double* board;            // the device board (to turn an output pointer into a slot index)
     unsigned long long* host_seq;   // device address of the host-mapped sequence word
     unsigned long long seq;         // this launch's sequence number
+    unsigned long long* host_err;   // device address of the host-mapped copy of the P2P timeout flag
     int slots;                      // mirrored slots
 };
 
@@ -226,6 +227,12 @@ __device__ __forceinline__ void grid_reduce(double (&acc)[NRED], const RedCtl& r
                     if (idx >= 0 && idx < red.mirror.slots)
                         __hip_atomic_store(reinterpret_cast<unsigned long long*>(red.mirror.host_board + idx),
                                            (unsigned long long)__double_as_longlong(tot[k]), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                if (red.p2p.world > 1 && red.mirror.host_err) {  // a timed-out exchange travels with the results
+                    const unsigned int e = __hip_atomic_load(red.p2p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (e)
+                        __hip_atomic_store(red.mirror.host_err, (unsigned long long)e, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_SYSTEM);
                 }
                 __hip_atomic_store(red.mirror.host_seq, red.mirror.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

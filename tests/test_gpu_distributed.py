@@ -127,3 +127,64 @@ def test_bench_contract_line(world, kind, tmp_path):
     if world == 1:
         c = j["cpu_baseline"]
         assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+
+
+TIMEOUT_WORKER = r'''
+import json, os, sys, time
+sys.path.insert(0, os.environ["LBFGS_ROOT"])
+import torch.distributed as dist
+import rust_lbfgs_amd as R
+from rust_lbfgs_amd import _ffi
+from rust_lbfgs_amd import dist as D
+from rust_lbfgs_amd.math import DeviceVec
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n = 100_000
+lo, hi = D.shard_range(n, rank, world)
+ctx = R.Context(n, device=0, shard=_ffi.Shard(rank, world, n, lo, hi - lo), comm=D.p2p_comm(0, timeout_s=0.3))
+u = DeviceVec(ctx)
+u.fill(1.0)
+out = dict(rank=rank)
+out["together"] = u.vecdot(u)                      # both ranks take part: n
+dist.barrier()
+if rank == 0:                                      # rank 1 stays away from the next two reductions
+    t0 = time.time()
+    for name, fn in (("in_kernel", lambda: u.vecdot(u)),
+                     ("standalone", lambda: (ctx.set_scalars(200, [1.0]), ctx.check(ctx._L.lbfgs_hip_scalars_allreduce(ctx._h, 200, 1)), ctx.scalars(200))[-1])):
+        try:
+            fn()
+            out[name] = "no error"
+        except R.LbfgsError as e:
+            out[name] = [e.code, str(e)]
+    out["seconds"] = time.time() - t0
+dist.barrier()
+u.free()
+ctx.close()
+json.dump(out, open(os.path.join(os.environ["LBFGS_OUT"], f"rank{rank}.json"), "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_p2p_exchange_times_out_instead_of_hanging(tmp_path):
+    """A peer that never arrives: the bounded spin gives up after p2p_timeout_s and the NEXT scalar read fails with
+    LBFGS_HIP_ERR_COMM -- through the host mirror (in-kernel exchange) and through the copy path alike."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs the GPU")
+    import subprocess
+    import sys
+
+    from tests.test_distributed_cpu import ROOT, _free_port
+
+    script = tmp_path / "worker.py"
+    script.write_text(TIMEOUT_WORKER)
+    env = dict(os.environ, LBFGS_ROOT=ROOT, LBFGS_OUT=str(tmp_path), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.load(open(tmp_path / "rank0.json"))
+    assert out["together"] == 100_000.0
+    assert out["in_kernel"][0] == _ffi.HIP_ERR_COMM and "timed out" in out["in_kernel"][1], out
+    assert out["standalone"][0] == _ffi.HIP_ERR_COMM, out
+    assert out["seconds"] < 30.0
