@@ -183,15 +183,8 @@ impl Lbfgs {
         E: FnMut(&[f64], &mut [f64]) -> Result<f64>,
         G: FnMut(&Progress) -> bool,
     {
-        let mut bridge = HostBridge { f: &mut eval_fn, err: None };
-        let ev = ffi::lbfgs_evaluator {
-            kind: ffi::LBFGS_EVAL_HOST,
-            fuse_line_eval: 0,
-            host: Some(host_trampoline::<E>),
-            device: None,
-            user: &mut bridge as *mut HostBridge<E> as *mut c_void,
-            builtin: no_objective(),
-        };
+        let mut bridge = HostBridge { f: &mut eval_fn, err: None }; // `&mut E` is itself FnMut
+        let ev = host_evaluator(&mut bridge);
         let r = self.run(x, &ev, prgr_fn);
         match (r, bridge.err.take()) {
             (Err(_), Some(user_err)) => Err(user_err), // the closure's own Err, as lbfgs.rs:454 propagates it
@@ -219,6 +212,22 @@ impl Lbfgs {
             builtin: obj,
         };
         self.run(x, &ev, prgr_fn)
+    }
+
+    /// src/lbfgs.rs:443-481, same signature: caller-driven stepping through `LbfgsState`.
+    pub fn build<'a, E>(self, x: &'a mut [f64], eval_fn: E) -> Result<LbfgsState<'a, E>>
+    where
+        E: FnMut(&[f64], &mut [f64]) -> Result<f64>,
+    {
+        let n = x.len();
+        let mut bridge = Box::new(HostBridge { f: eval_fn, err: None }); // boxed: the C side keeps its address
+        let ev = host_evaluator(&mut *bridge);
+        let ctx = Context::new(self.device, n)?;
+        let state = match State::build(&ctx, &self.param, x, &ev) {
+            Ok(s) => s,
+            Err(e) => return Err(bridge.err.take().unwrap_or(e)), // the closure's own Err (lbfgs.rs:454)
+        };
+        Ok(LbfgsState { state, ctx, bridge, x, gx: vec![0.0; n] })
     }
 
     fn run<G>(self, x: &mut [f64], ev: &ffi::lbfgs_evaluator, mut prgr_fn: G) -> Result<Report>
@@ -257,23 +266,84 @@ impl Lbfgs {
     }
 }
 
+/// LbfgsState (src/lbfgs.rs:425-439).  `x` is kept current after every `propagate`, as in the reference where the
+/// state holds `&mut x` (one download per iteration: this is the host-closure compatibility path).
+pub struct LbfgsState<'a, E>
+where
+    E: FnMut(&[f64], &mut [f64]) -> Result<f64>,
+{
+    state: State,   // dropped first ...
+    ctx: Context,   // ... then its context ...
+    bridge: Box<HostBridge<E>>, // ... then the closure the C side pointed at
+    x: &'a mut [f64],
+    gx: Vec<f64>,
+}
+
+impl<'a, E> LbfgsState<'a, E>
+where
+    E: FnMut(&[f64], &mut [f64]) -> Result<f64>,
+{
+    /// src/lbfgs.rs:489-494
+    pub fn is_converged(&self) -> bool {
+        self.state.is_converged().expect("backend failure in is_converged")
+    }
+
+    /// src/lbfgs.rs:497-499
+    pub fn report(&self) -> Report {
+        self.state.report().expect("backend failure in report")
+    }
+
+    /// src/lbfgs.rs:503-560
+    pub fn propagate(&mut self) -> Result<Progress> {
+        let p = match self.state.propagate() {
+            Ok(p) => p,
+            Err(e) => {
+                let _ = self.state.download(ffi::LBFGS_VEC_X, self.x);
+                return Err(self.bridge.err.take().unwrap_or(e));
+            }
+        };
+        self.state.download(ffi::LBFGS_VEC_X, self.x)?;
+        self.state.download(ffi::LBFGS_VEC_GX, &mut self.gx)?;
+        let _ = &self.ctx; // (kept alive by this struct)
+        Ok(Progress {
+            x: &*self.x, gx: &self.gx, fx: p.fx, xnorm: p.xnorm, gnorm: p.gnorm, step: p.step,
+            niter: p.niter as usize, neval: p.neval as usize, ncall: p.ncall as usize,
+        })
+    }
+}
+
 fn no_objective() -> ffi::lbfgs_hip_objective {
     ffi::lbfgs_hip_objective { kind: 0, _pad: 0, seed_a: 0, seed_b: 0, nbr_index: ptr::null(), max_nbr: 0, _pad2: 0, cutoff: 0.0 }
 }
 
 // ---- the host closure behind the C callback ----------------------------------------------------------
-struct HostBridge<'a, E> {
-    f: &'a mut E,
+struct HostBridge<F> {
+    f: F,
     err: Option<anyhow::Error>,
 }
 
-unsafe extern "C" fn host_trampoline<E>(user: *mut c_void, x: *const f64, g: *mut f64, n_local: u64, failed: *mut c_int) -> f64
+/// The evaluator record for a closure that lives in `bridge` (whose address must stay valid while the state lives).
+fn host_evaluator<F>(bridge: &mut HostBridge<F>) -> ffi::lbfgs_evaluator
 where
-    E: FnMut(&[f64], &mut [f64]) -> Result<f64>,
+    F: FnMut(&[f64], &mut [f64]) -> Result<f64>,
+{
+    ffi::lbfgs_evaluator {
+        kind: ffi::LBFGS_EVAL_HOST,
+        fuse_line_eval: 0,
+        host: Some(host_trampoline::<F>),
+        device: None,
+        user: bridge as *mut HostBridge<F> as *mut c_void,
+        builtin: no_objective(),
+    }
+}
+
+unsafe extern "C" fn host_trampoline<F>(user: *mut c_void, x: *const f64, g: *mut f64, n_local: u64, failed: *mut c_int) -> f64
+where
+    F: FnMut(&[f64], &mut [f64]) -> Result<f64>,
 {
     // never unwind across the FFI boundary: a panic in the closure is reported as a failed evaluation
     let outcome = catch_unwind(AssertUnwindSafe(|| {
-        let bridge = &mut *(user as *mut HostBridge<E>);
+        let bridge = &mut *(user as *mut HostBridge<F>);
         let xs = std::slice::from_raw_parts(x, n_local as usize);
         let gs = std::slice::from_raw_parts_mut(g, n_local as usize);
         match (bridge.f)(xs, gs) {
@@ -316,19 +386,20 @@ impl Drop for Context {
     }
 }
 
-struct State<'c> {
+/// Must be dropped BEFORE the `Context` it was built on (locals: declare the context first; fields: declare the
+/// state first -- Rust drops locals in reverse and fields in declaration order).
+struct State {
     raw: *mut ffi::lbfgs_state,
-    _ctx: &'c Context, // the state must not outlive its context
 }
 
-impl<'c> State<'c> {
-    fn build(ctx: &'c Context, param: &ffi::lbfgs_param, x0: &[f64], ev: &ffi::lbfgs_evaluator) -> Result<Self> {
+impl State {
+    fn build(ctx: &Context, param: &ffi::lbfgs_param, x0: &[f64], ev: &ffi::lbfgs_evaluator) -> Result<Self> {
         let mut raw = ptr::null_mut();
         let rc = unsafe { ffi::lbfgs_build(&mut raw, ctx.raw, param, x0.as_ptr(), ev) };
         if rc != ffi::LBFGS_HIP_OK {
             return Err(status_error(rc, cstr(unsafe { ffi::lbfgs_state_error(ptr::null()) })));
         }
-        Ok(State { raw, _ctx: ctx })
+        Ok(State { raw })
     }
     fn check(&self, rc: c_int) -> Result<()> {
         if rc == ffi::LBFGS_HIP_OK {
@@ -357,7 +428,7 @@ impl<'c> State<'c> {
     }
 }
 
-impl<'c> Drop for State<'c> {
+impl Drop for State {
     fn drop(&mut self) {
         unsafe { ffi::lbfgs_state_free(self.raw) }
     }
