@@ -118,11 +118,14 @@ struct lbfgs_hip_ctx {
     unsigned long long* p2p_mbox[P2P_MAX_WORLD] = {nullptr};  // [rank] -> that rank's mailbox (own entry = local)
     bool p2p_opened[P2P_MAX_WORLD] = {false};
     unsigned int p2p_epoch = 0;
-    unsigned int* p2p_err = nullptr;      // device flag: a spin timed out
+    unsigned int* p2p_err = nullptr;      // device error flag: 1 = a P2P spin timed out, 2 = a workgroup's partials never arrived
     unsigned long long p2p_timeout_ticks = 0;
     double* board = nullptr;         // LBFGS_HIP_BOARD_SLOTS doubles + 2 ping-pong dots
     double* partials = nullptr;      // MAX_RED * MAX_GRID
     unsigned int* ticket = nullptr;
+    unsigned long long* gran = nullptr;   // tagged partial granules [MAX_RED][MAX_GRID][2] (stream.h)
+    unsigned int red_epoch = 0;           // tag of the latest reducing launch (never 0)
+    bool handoff_ticket = false;          // LBFGS_HIP_HANDOFF=ticket: the arrival-counter form for every kernel (A/B, fallback)
     double* pinned = nullptr;        // host staging, LBFGS_HIP_BOARD_SLOTS doubles
     // host mirror of the board (stream.h MirrorCtl)
     double* mirror = nullptr;              // host-mapped: SLOTS+2 doubles, then the sequence word
@@ -210,6 +213,21 @@ struct ProfScope {
     }
 };
 
+// the cross-workgroup hand-off part of a RedCtl for the NEXT reducing launch
+int fill_handoff(lbfgs_hip_ctx* ctx, RedCtl& red) {
+    red.partials = ctx->partials;
+    red.ticket = ctx->ticket;
+    red.gran = ctx->gran;
+    red.err = ctx->p2p_err;
+    red.timeout_ticks = 1000000000ULL;  // 10 s of the 100 MHz wall clock
+    if (++ctx->red_epoch == 0u) {  // 2^32 launches: no granule of the buffer may still carry a tag that comes round again
+        HIP_TRY(ctx, hipMemsetAsync(ctx->gran, 0, (size_t)MAX_RED * MAX_GRID * 2 * sizeof(unsigned long long), ctx->stream));
+        ctx->red_epoch = 1u;
+    }
+    red.epoch = ctx->handoff_ticket ? 0u : ctx->red_epoch;
+    return LBFGS_HIP_OK;
+}
+
 // the P2P control block of the NEXT reduction (epochs advance identically on every rank)
 P2PCtl next_p2p(lbfgs_hip_ctx* ctx) {
     P2PCtl c{};
@@ -280,8 +298,10 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out,
     RedCtl red{};
     red.dup_ptr = dup_ptr;
     red.dup_k = dup_k;
-    red.partials = ctx->partials;
-    red.ticket = ctx->ticket;
+    if (Op::NRED > 0) {
+        const int rc_h = fill_handoff(ctx, red);
+        if (rc_h != LBFGS_HIP_OK) return rc_h;
+    }
     if constexpr (Op::NRED <= RED_PTRS) {
         for (int k = 0; k < Op::NRED; ++k) red.out[k] = red_out[k];
     } else {
@@ -417,8 +437,10 @@ int lj_eval(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, const lbfgs_hip_
     if (n % 3 != 0 || n / 3 > 0x7fffffffULL) return fail(ctx, LBFGS_HIP_ERR_ARG, "LJ needs n = 3*natoms");
     const uint32_t natoms = (uint32_t)(n / 3);
     RedCtl red{};
-    red.partials = ctx->partials;
-    red.ticket = ctx->ticket;
+    {
+        const int rc_h = fill_handoff(ctx, red);
+        if (rc_h != LBFGS_HIP_OK) return rc_h;
+    }
     red.out[0] = out;
     const long idx = out - ctx->board;
     if (idx >= 0 && idx < LBFGS_HIP_BOARD_SLOTS + 2) ctx->mirror_valid[idx] = false;
@@ -489,8 +511,10 @@ int two_loop_gram_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
     }
     {
         RedCtl red{};
-        red.partials = ctx->partials;
-        red.ticket = ctx->ticket;
+        {
+            const int rc_h = fill_handoff(ctx, red);
+            if (rc_h != LBFGS_HIP_OK) return rc_h;
+        }
         red.out_contig = h->gram_rows;
         if (ctx->comm_kind == LBFGS_HIP_COMM_P2P) red.p2p = next_p2p(ctx);
         const uint64_t n = ctx->shard.n_local;
@@ -637,12 +661,17 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     ctx->gram_grid = prop.multiProcessorCount;  // the 21-stream Gram rows pass peaks at one workgroup per CU
     if (const char* e = getenv("LBFGS_HIP_NT_THRESHOLD_MB")) ctx->nt_threshold_bytes = (size_t)atoll(e) << 20;
     if (const char* e = getenv("LBFGS_HIP_GRAM_GRID")) ctx->gram_grid = std::min(MAX_GRID, std::max(0, atoi(e)));
+    if (const char* e = getenv("LBFGS_HIP_HANDOFF")) ctx->handoff_ticket = strcmp(e, "ticket") == 0;
     if (const char* e = getenv("LBFGS_HIP_GRID")) ctx->grid_override = std::min(MAX_GRID, std::max(0, atoi(e)));
     CTX_TRY(hipMalloc(&ctx->board, (LBFGS_HIP_BOARD_SLOTS + 2) * sizeof(double)));
     CTX_TRY(hipMemsetAsync(ctx->board, 0, (LBFGS_HIP_BOARD_SLOTS + 2) * sizeof(double), ctx->stream));
     CTX_TRY(hipMalloc(&ctx->partials, (size_t)MAX_RED * MAX_GRID * sizeof(double)));
     CTX_TRY(hipMalloc(&ctx->ticket, 64));
     CTX_TRY(hipMemsetAsync(ctx->ticket, 0, 64, ctx->stream));
+    CTX_TRY(hipMalloc(&ctx->gran, (size_t)MAX_RED * MAX_GRID * 2 * sizeof(unsigned long long)));
+    CTX_TRY(hipMemsetAsync(ctx->gran, 0, (size_t)MAX_RED * MAX_GRID * 2 * sizeof(unsigned long long), ctx->stream));
+    CTX_TRY(hipMalloc(&ctx->p2p_err, 64));  // device error flag: 1 = a P2P peer never arrived, 2 = a partial never arrived
+    CTX_TRY(hipMemsetAsync(ctx->p2p_err, 0, 64, ctx->stream));
     CTX_TRY(hipHostMalloc(&ctx->pinned, (LBFGS_HIP_BOARD_SLOTS + 1) * sizeof(double), hipHostMallocDefault));
     if (!getenv("LBFGS_HIP_NO_MIRROR")) {
         void* hm = nullptr;
@@ -704,13 +733,6 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
             ctx->p2p_mbox[r] = (unsigned long long*)p;
             ctx->p2p_opened[r] = true;
         }
-        hipError_t e = hipMalloc(&ctx->p2p_err, 64);
-        if (e == hipSuccess) e = hipMemset(ctx->p2p_err, 0, 64);
-        if (e != hipSuccess) {
-            int rc = fail(nullptr, LBFGS_HIP_ERR_HIP, "P2P error flag: %s", hipGetErrorString(e));
-            lbfgs_hip_ctx_destroy(ctx);
-            return rc;
-        }
         const double tmo = comm->p2p_timeout_s > 0 ? comm->p2p_timeout_s : 5.0;
         ctx->p2p_timeout_ticks = (unsigned long long)(tmo * 1e8);  // wall_clock64 runs at 100 MHz
         ctx->comm_kind = LBFGS_HIP_COMM_P2P;
@@ -744,6 +766,7 @@ void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* ctx) {
     if (ctx->board) (void)hipFree(ctx->board);
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
+    if (ctx->gran) (void)hipFree(ctx->gran);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->mirror) (void)hipHostFree(ctx->mirror);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -837,6 +860,12 @@ int lbfgs_hip_vec_swap(lbfgs_hip_vec* a, lbfgs_hip_vec* b) {
 }
 
 // ==================================================================================== board
+static int device_error(lbfgs_hip_ctx* ctx, unsigned int flag) {
+    if (flag == 2u)
+        return fail(ctx, LBFGS_HIP_ERR_HIP, "a reduction timed out waiting for a workgroup's partial sums");
+    return fail(ctx, LBFGS_HIP_ERR_COMM, "P2P all-reduce timed out waiting for a peer");
+}
+
 int lbfgs_hip_scalars_read(lbfgs_hip_ctx* ctx, int first, int count, double* host) {
     if (!ctx || !host || !slot_ok(first, count)) return LBFGS_HIP_ERR_ARG;
     if (count == 0) return lbfgs_hip_sync(ctx);
@@ -860,8 +889,7 @@ int lbfgs_hip_scalars_read(lbfgs_hip_ctx* ctx, int first, int count, double* hos
                 // a timed-out in-kernel exchange is published next to the results (before the sequence word)
                 const volatile unsigned long long* perr =
                     reinterpret_cast<volatile unsigned long long*>(ctx->mirror + LBFGS_HIP_BOARD_SLOTS + 3);
-                if (ctx->p2p_err && *perr)
-                    return fail(ctx, LBFGS_HIP_ERR_COMM, "P2P all-reduce timed out waiting for a peer");
+                if (*perr) return device_error(ctx, (unsigned int)*perr);
                 return LBFGS_HIP_OK;
             }
         }
@@ -876,7 +904,7 @@ int lbfgs_hip_scalars_read(lbfgs_hip_ctx* ctx, int first, int count, double* hos
     if (ctx->p2p_err) {
         unsigned int flag;
         memcpy(&flag, ctx->pinned + LBFGS_HIP_BOARD_SLOTS, sizeof(flag));
-        if (flag) return fail(ctx, LBFGS_HIP_ERR_COMM, "P2P all-reduce timed out waiting for a peer");
+        if (flag) return device_error(ctx, flag);
     }
     return LBFGS_HIP_OK;
 }

@@ -121,22 +121,30 @@ struct OpTwoLoopPair {
 struct Bufs {
     double *q, *u, *v, *board, *partials;
     unsigned* ticket;
+    unsigned long long* gran;
+    unsigned* err;
     uint64_t n;
 };
+static unsigned g_epoch = 0;
+// the hand-off part of a RedCtl for the next launch (a fresh tag per launch, as the library does)
+static void handoff(RedCtl& red, const Bufs& b) {
+    red.partials = b.partials; red.ticket = b.ticket; red.gran = b.gran; red.err = b.err;
+    red.timeout_ticks = 200000000ULL;
+    red.epoch = ++g_epoch;
+}
 
 template <class Op, int UNR, unsigned NTL, unsigned NTS, int MAP, int SPAN = 1>
 float run(const Op& op, const Bufs& b, int grid, int reps, int* occ) {
     RedCtl red{};
-    red.partials = b.partials;
-    red.ticket = b.ticket;
     for (int k = 0; k < RED_PTRS; ++k) red.out[k] = b.board + 2 + k;
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, stream_kernel<Op, UNR, NTL, NTS, MAP, SPAN>, BLOCK, 0));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((stream_kernel<Op, UNR, NTL, NTS, MAP, SPAN>), dim3(grid), dim3(BLOCK), 0, 0, op, b.n, 0, red);
+    for (int i = 0; i < 3; ++i) { handoff(red, b); hipLaunchKernelGGL((stream_kernel<Op, UNR, NTL, NTS, MAP, SPAN>), dim3(grid), dim3(BLOCK), 0, 0, op, b.n, 0, red); }
     std::vector<float> ts;
     for (int r = 0; r < reps; ++r) {
+        handoff(red, b);
         CK(hipEventRecord(e0, 0));
         hipLaunchKernelGGL((stream_kernel<Op, UNR, NTL, NTS, MAP, SPAN>), dim3(grid), dim3(BLOCK), 0, 0, op, b.n, 0, red);
         CK(hipEventRecord(e1, 0));
@@ -362,6 +370,10 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&b.partials, (size_t)MAX_RED * MAX_GRID * sizeof(double)));
     CK(hipMalloc(&b.ticket, 64));
     CK(hipMemset(b.ticket, 0, 64));
+    CK(hipMalloc(&b.gran, (size_t)MAX_RED * MAX_GRID * 2 * sizeof(unsigned long long)));
+    CK(hipMemset(b.gran, 0, (size_t)MAX_RED * MAX_GRID * 2 * sizeof(unsigned long long)));
+    CK(hipMalloc(&b.err, 64));
+    CK(hipMemset(b.err, 0, 64));
     std::vector<double> h(b.n);
     for (size_t i = 0; i < b.n; ++i) h[i] = 1e-3 * (double)((i * 2654435761ULL) % 1000) - 0.5;
     CK(hipMemcpy(b.q, h.data(), bytes, hipMemcpyHostToDevice));
@@ -399,8 +411,10 @@ int main(int argc, char** argv) {
         for (int grid : {216, 256}) {
             for (int rep = 0; rep < 3; ++rep) {
                 CK(hipEventRecord(e0, 0));
-                for (int i = 0; i < STEPS; ++i)
+                for (int i = 0; i < STEPS; ++i) {
+                    handoff(red, b);
                     hipLaunchKernelGGL((stream_kernel<decltype(op), 2, 0u, 0u, 1, 1>), dim3(grid), dim3(BLOCK), 0, 0, op, b.n, 0, red);
+                }
                 CK(hipEventRecord(e1, 0));
                 CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -476,8 +490,10 @@ int main(int argc, char** argv) {
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0, 0));
-            for (int i = 0; i < 20; ++i)
+            for (int i = 0; i < 20; ++i) {
+                handoff(red, b);
                 hipLaunchKernelGGL((stream_kernel<decltype(op), 2, 0u, 0u, 1, 1>), dim3(216), dim3(BLOCK), 0, 0, op, b.n, 0, red);
+            }
             CK(hipEventRecord(e1, 0));
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
