@@ -18,9 +18,9 @@
 //     fits the 256 MiB Infinity Cache; below that, plain accesses let the cache
 //     keep the running vector between consecutive kernels;
 //   * reductions: f64 per-thread accumulators -> wave64 shuffle tree -> LDS ->
-//     one partial per workgroup -> the LAST workgroup to finish (agent-scope
-//     ticket) sums the partials in a FIXED order.  No float atomics, so results
-//     are bitwise reproducible for a given (n, grid).
+//     one partial per workgroup, published as tagged 8-byte granules -> the
+//     last-index workgroup polls them and sums in a FIXED order.  No float
+//     atomics, so results are bitwise reproducible for a given (n, grid).
 //
 // An operator (ops.h) only states: its input/output streams, how one element is
 // computed, and how many sums it accumulates.

@@ -897,3 +897,36 @@ def test_runs_with_and_without_deferred_trial_points_agree(kind, damping):
         for a, b_ in zip(u[3:], v[3:]):
             assert abs(a - b_) <= 1e-9 * max(abs(b_), 1e-12)
     assert np.max(np.abs(x1 - x2)) <= 1e-9 * np.max(np.abs(x2))
+
+
+def test_handoff_forms_are_bitwise_identical(monkeypatch):
+    """The tagged-granule hand-off (default) and the arrival-ticket hand-off (LBFGS_HIP_HANDOFF=ticket) add the same
+    partials in the same order: every sum, and therefore a whole run, is bit-identical between them."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("a property of the HIP kernels")
+    n = 300_007
+    a_h, b_h, c_h, d_h = rnd(n, 61), rnd(n, 62), rnd(n, 63), rnd(n, 64)
+    results = {}
+    for form in ("tagged", "ticket"):
+        monkeypatch.setenv("LBFGS_HIP_HANDOFF", form)
+        with R.Context(n) as ctx:
+            a, b, c, d = (DeviceVec(ctx, v) for v in (a_h, b_h, c_h, d_h))
+            out = [a.vecdot(b), a.vec2norm()]
+            H.norms_sq(a, b, 20)
+            out += list(ctx.scalars(20, 2))
+            hist = H.History(ctx, 2)
+            hist.update(0, a, b, c, d, 0.3, True, 30)          # 7 sums in one kernel
+            out += list(ctx.scalars(30, 7))
+            H.objective_line_probe(objectives.Quadratic(), a, b, 0.01, 40)
+            out += list(ctx.scalars(40, 2))
+            hist.free()
+            for v in (a, b, c, d):
+                v.free()
+        x, rows = np.zeros(20011), []
+        R.lbfgs().with_m(5).with_epsilon(0.0).with_max_iterations(30).minimize(
+            x, objectives.Quadratic(), lambda p: rows.append((p.niter, p.neval, p.ncall, p.fx, p.xnorm, p.gnorm, p.step)) and False)
+        results[form] = (out, rows, x)
+    (o1, r1, x1), (o2, r2, x2) = results["tagged"], results["ticket"]
+    assert o1 == o2
+    assert r1 == r2
+    assert np.array_equal(x1, x2)
