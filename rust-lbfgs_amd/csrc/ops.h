@@ -406,7 +406,8 @@ struct OpObjLineEval {  // take_line_step + evaluate + dg_unchecked (core.rs:155
 template <class Obj>
 struct OpObjLineProbe {
     static constexpr int NIN = 2, NOUT = 0, NRED = 2;
-    static constexpr int TUNE_GRID_X32 = 64;  // ALU-bound on the hashed objectives: 2 workgroups per CU (grid A/B)
+    static constexpr int TUNE_GRID_X32 = 96;  // ALU close behind HBM on the hashed objectives: 3 workgroups per CU
+                                              // (profiles/r01_tune_objective_kernels.log)
     const double* in[2];  // xp, d
     double* out[1];
     double step;
@@ -428,7 +429,8 @@ struct OpObjLineProbe {
 template <class Obj, bool DAMP>
 struct OpHistUpdateFromStep {
     static constexpr int NIN = 3, NOUT = 4, NRED = 7;
-    static constexpr int TUNE_GRID_X32 = 64;
+    // 3r 4w: fine grid-stride map, 2 chunks in flight, one workgroup per CU (profiles/r01_tune_objective_kernels.log)
+    static constexpr int TUNE_MAP = 1, TUNE_UNROLL = 2, TUNE_GRID_X32 = 32;
     const double* in[3];  // xp, d, gp
     double* out[4];       // x, g, s, y
     double t;             // the accepted trial step

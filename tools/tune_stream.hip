@@ -221,6 +221,23 @@ void sweep_lineeval(const Bufs& b, const std::vector<int>& grids, double* extra[
 }
 
 template <int UNR, unsigned NTL, unsigned NTS, int MAP, int SPAN = 1>
+void sweep_update_from_step(const Bufs& b, const std::vector<int>& grids, double* extra[4]) {
+    OpHistUpdateFromStep<ObjQuadratic, false> op{};
+    op.in[0] = b.q; op.in[1] = b.u; op.in[2] = b.v;
+    op.out[0] = extra[0]; op.out[1] = extra[1]; op.out[2] = extra[2]; op.out[3] = extra[3];
+    op.t = 1e-3; op.neg_step = 0.0; op.obj = {0x5EED0001ULL, 0x5EED0002ULL};
+    OpObjLineProbe<ObjQuadratic> pr{};
+    pr.in[0] = b.q; pr.in[1] = b.u; pr.step = 1e-3; pr.obj = {0x5EED0001ULL, 0x5EED0002ULL};
+    for (int g : grids) {
+        int occ = 0;
+        float ms = run<decltype(op), UNR, NTL, NTS, MAP, SPAN>(op, b, g, 9, &occ);
+        float ms2 = run<decltype(pr), UNR, NTL, NTS, MAP, SPAN>(pr, b, g, 9, &occ);
+        printf("upd3r4w_s%d map=%d unroll=%d grid=%5d (%.2f/CU) : %8.3f ms %7.1f GB/s | probe2r : %8.3f ms %7.1f GB/s\n", SPAN, MAP, UNR, g,
+               g / 256.0, ms, 56.0 * b.n / ms / 1e6, ms2, 16.0 * b.n / ms2 / 1e6);
+    }
+}
+
+template <int UNR, unsigned NTL, unsigned NTS, int MAP, int SPAN = 1>
 void sweep_combine(const Bufs& b, const std::vector<int>& grids, double** vecs) {
     OpGramCombine<10> op{};
     for (int j = 0; j < 21; ++j) op.in[j] = vecs[j];
@@ -389,6 +406,19 @@ int main(int argc, char** argv) {
         printf("LH_STORE_POLICY=%d\n", LH_STORE_POLICY);
         sweep_step<2, ~0u, ~0u, 1, 1>(b, g1);
         sweep_copy<4, ~0u, ~0u, 2>(b, g1);
+        return 0;
+    }
+    if (argc > 2 && atoi(argv[2]) == -7) {  // the two kernels that carry the hashed objective: map / unroll / grid
+        double* extra[4];
+        for (auto& e : extra) CK(hipMalloc(&e, bytes));
+        std::vector<int> g1 = {216, 256, 384, 512, 768, 1024};
+        constexpr unsigned ALL = ~0u;
+        sweep_update_from_step<4, ALL, ALL, 2, 1>(b, g1, extra);
+        sweep_update_from_step<2, ALL, ALL, 2, 1>(b, g1, extra);
+        sweep_update_from_step<2, ALL, ALL, 1, 1>(b, g1, extra);
+        sweep_update_from_step<1, ALL, ALL, 1, 1>(b, g1, extra);
+        sweep_update_from_step<4, ALL, ALL, 1, 1>(b, g1, extra);
+        sweep_update_from_step<2, ALL, ALL, 2, 2>(b, g1, extra);
         return 0;
     }
     if (argc > 2 && atoi(argv[2]) == -5) {  // persistent two-loop probe vs one launch per step
