@@ -429,8 +429,9 @@ struct OpObjLineProbe {
 template <class Obj, bool DAMP>
 struct OpHistUpdateFromStep {
     static constexpr int NIN = 3, NOUT = 4, NRED = 7;
-    // 3r 4w: fine grid-stride map, 2 chunks in flight, one workgroup per CU (profiles/r01_tune_objective_kernels.log)
-    static constexpr int TUNE_MAP = 1, TUNE_UNROLL = 2, TUNE_GRID_X32 = 32;
+    // default map / unroll, 2 workgroups per CU.  (The stand-alone sweep profiles/r01_tune_objective_kernels.log prefers
+    // map 1 / unroll 2 / 1 per CU; inside bench.py that setting measured 1082 us against 925 us: not taken.)
+    static constexpr int TUNE_GRID_X32 = 64;
     const double* in[3];  // xp, d, gp
     double* out[4];       // x, g, s, y
     double t;             // the accepted trial step
