@@ -125,6 +125,7 @@ struct lbfgs_hip_ctx {
     unsigned int* ticket = nullptr;
     unsigned long long* gran = nullptr;   // tagged partial granules [MAX_RED][MAX_GRID][2] (stream.h)
     unsigned int red_epoch = 0;           // tag of the latest reducing launch (never 0)
+    int grid_class[16] = {0};             // LBFGS_HIP_GRID_K<class>=N: grid override per kernel class (in-situ tuning)
     bool handoff_ticket = false;          // LBFGS_HIP_HANDOFF=ticket: the arrival-counter form for every kernel (A/B, fallback)
     double* pinned = nullptr;        // host staging, LBFGS_HIP_BOARD_SLOTS doubles
     // host mirror of the board (stream.h MirrorCtl)
@@ -327,7 +328,8 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out,
         }
     }
     constexpr int MAP = tuning<Op>::MAP, UNR = tuning<Op>::UNR;
-    const int grid = grid_for(ctx, tuning<Op>::GRID_X32);
+    const int grid = (kclass >= 0 && kclass < 16 && ctx->grid_class[kclass] > 0)
+                         ? std::min(MAX_GRID, ctx->grid_class[kclass]) : grid_for(ctx, tuning<Op>::GRID_X32);
     // streaming (`nt`) hints once the running vector cannot stay in the 256 MiB Infinity Cache next to the others
     const bool streaming = n * sizeof(double) >= ctx->nt_threshold_bytes;
     {
@@ -661,6 +663,11 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     ctx->gram_grid = prop.multiProcessorCount;  // the 21-stream Gram rows pass peaks at one workgroup per CU
     if (const char* e = getenv("LBFGS_HIP_NT_THRESHOLD_MB")) ctx->nt_threshold_bytes = (size_t)atoll(e) << 20;
     if (const char* e = getenv("LBFGS_HIP_GRAM_GRID")) ctx->gram_grid = std::min(MAX_GRID, std::max(0, atoi(e)));
+    for (int k = 0; k < LBFGS_HIP_K_CLASSES && k < 16; ++k) {
+        char name[32];
+        snprintf(name, sizeof(name), "LBFGS_HIP_GRID_K%d", k);
+        if (const char* e = getenv(name)) ctx->grid_class[k] = std::max(0, atoi(e));
+    }
     if (const char* e = getenv("LBFGS_HIP_HANDOFF")) ctx->handoff_ticket = strcmp(e, "ticket") == 0;
     if (const char* e = getenv("LBFGS_HIP_GRID")) ctx->grid_override = std::min(MAX_GRID, std::max(0, atoi(e)));
     CTX_TRY(hipMalloc(&ctx->board, (LBFGS_HIP_BOARD_SLOTS + 2) * sizeof(double)));
