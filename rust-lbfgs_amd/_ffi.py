@@ -269,8 +269,9 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
-    hip = os.path.join(HERE, "liblbfgs_hip.so")
-    solver = os.path.join(HERE, "liblbfgs_solver.so")
+    libdir = os.environ.get("LBFGS_HIP_LIB_DIR", HERE)  # prebuilt libraries elsewhere (deployment, A/B builds)
+    hip = os.path.join(libdir, "liblbfgs_hip.so")
+    solver = os.path.join(libdir, "liblbfgs_solver.so")
     for p in (hip, solver):
         if not os.path.exists(p):
             raise ImportError(

@@ -177,11 +177,17 @@ struct OpTwoLoopFirst {
 struct TwoLoopCoef {
     double c, gamma;
 };
+#ifndef LH_STEP_MAP      // overridable for in-situ A/B builds (tools/build_variants.sh); the defaults are the measured best
+#define LH_STEP_MAP 1
+#endif
+#ifndef LH_STEP_UNROLL
+#define LH_STEP_UNROLL 2
+#endif
 template <bool NEG_SRC, bool SCALE, int VMODE>
 struct OpTwoLoopStep {
     static constexpr int NIN = (VMODE == 1) ? 2 : 3, NOUT = 1, NRED = (VMODE == 2) ? 2 : (VMODE == 3 ? 4 : 1);
     // measured best for the 3r+1w shape on MI355X: fine grid-stride, 2 chunks in flight per stream
-    static constexpr int TUNE_MAP = (VMODE == 1) ? DEFAULT_MAP : 1, TUNE_UNROLL = (VMODE == 1) ? UNROLL : 2;  // 3r+1w shapes
+    static constexpr int TUNE_MAP = (VMODE == 1) ? DEFAULT_MAP : LH_STEP_MAP, TUNE_UNROLL = (VMODE == 1) ? UNROLL : LH_STEP_UNROLL;  // 3r+1w shapes
     const double* in[3];  // src, u, v (VMODE 2: g)
     double* out[1];       // dst (= d)
     const double* dot_in; // previous reduction (global sum)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Build A/B variants of the HIP library with other compile-time traits for the dominant kernel, for in-situ comparison:
+#   bash tools/build_variants.sh "1:1 1:2 1:3 1:4 2:2 2:4"      (MAP:UNROLL of OpTwoLoopStep)
+# then e.g.  LBFGS_HIP_LIB_DIR=tools/bin/variants/m1u3 python bench.py ...
+set -e
+root=$(cd "$(dirname "$0")/.." && pwd)
+for v in $1; do
+  m=${v%%:*}; u=${v##*:}
+  d=$root/tools/bin/variants/m${m}u${u}
+  mkdir -p "$d"
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -DLH_STEP_MAP=$m -DLH_STEP_UNROLL=$u \
+      -I"$root/include" "$root/rust-lbfgs_amd/csrc/lbfgs_hip.hip" -o "$d/liblbfgs_hip.so" -ldl 2>/dev/null
+  g++ -O2 -ffp-contract=off -fPIC -shared -std=c++17 -I"$root/include" "$root/rust-lbfgs_amd/csrc/host/solver.cpp" -o "$d/liblbfgs_solver.so" \
+      -L"$d" -llbfgs_hip -Wl,-rpath,'$ORIGIN'
+  echo "built $d"
+done
