@@ -291,6 +291,12 @@ int allreduce(lbfgs_hip_ctx* ctx, double* const* ptrs, int count) {
     return LBFGS_HIP_OK;
 }
 
+#ifndef LH_NT_IN   // cache-hint masks of the streaming instantiation (bit s = stream s uses `nt`); A/B builds override them
+#define LH_NT_IN ~0u
+#endif
+#ifndef LH_NT_OUT
+#define LH_NT_OUT ~0u
+#endif
 // ---- launch one operator ---------------------------------------------------------------------
 template <class Op>
 int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out, double* dup_ptr = nullptr,
@@ -335,7 +341,7 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out,
     {
         ProfScope ps(ctx, kclass);
         if (streaming)
-            hipLaunchKernelGGL((stream_kernel<Op, UNR, ~0u, ~0u, MAP>), dim3(grid), dim3(BLOCK), 0, ctx->stream,
+            hipLaunchKernelGGL((stream_kernel<Op, UNR, LH_NT_IN, LH_NT_OUT, MAP>), dim3(grid), dim3(BLOCK), 0, ctx->stream,
                                op, n, ctx->shard.offset, red);
         else
             hipLaunchKernelGGL((stream_kernel<Op, UNR, 0u, 0u, MAP>), dim3(grid), dim3(BLOCK), 0, ctx->stream,

@@ -30,7 +30,10 @@
 
 namespace lh {
 
-constexpr int BLOCK = 256;          // 4 wave64 per workgroup
+#ifndef LH_BLOCK         // overridable for in-situ A/B builds (tools/build_variants.sh)
+#define LH_BLOCK 256
+#endif
+constexpr int BLOCK = LH_BLOCK;     // 4 wave64 per workgroup
 constexpr int WAVES = BLOCK / 64;
 constexpr int UNROLL = 4;           // default: independent 16-B loads per stream per thread
 constexpr int DEFAULT_MAP = 2;      // default address map (see stream_kernel)

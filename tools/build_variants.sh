@@ -4,11 +4,18 @@
 # then e.g.  LBFGS_HIP_LIB_DIR=tools/bin/variants/m1u3 python bench.py ...
 set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
+# A second form names the variant and passes raw -D flags:  bash tools/build_variants.sh "b512=-DLH_BLOCK=512 nti=-DLH_NT_OUT=0u"
 for v in $1; do
-  m=${v%%:*}; u=${v##*:}
-  d=$root/tools/bin/variants/m${m}u${u}
+  if [[ $v == *=* ]]; then
+    name=${v%%=*}; flags=${v#*=}
+    d=$root/tools/bin/variants/$name
+  else
+    m=${v%%:*}; u=${v##*:}
+    d=$root/tools/bin/variants/m${m}u${u}
+    flags="-DLH_STEP_MAP=$m -DLH_STEP_UNROLL=$u"
+  fi
   mkdir -p "$d"
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -DLH_STEP_MAP=$m -DLH_STEP_UNROLL=$u \
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 $flags \
       -I"$root/include" "$root/rust-lbfgs_amd/csrc/lbfgs_hip.hip" -o "$d/liblbfgs_hip.so" -ldl 2>/dev/null
   g++ -O2 -ffp-contract=off -fPIC -shared -std=c++17 -I"$root/include" "$root/rust-lbfgs_amd/csrc/host/solver.cpp" -o "$d/liblbfgs_solver.so" \
       -L"$d" -llbfgs_hip -Wl,-rpath,'$ORIGIN'
