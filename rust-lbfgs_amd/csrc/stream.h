@@ -423,39 +423,50 @@ __device__ __forceinline__ void stream_body(const Op& op, const typename Op::Coe
     };
     auto chunk_end = [&]() -> uint64_t { return MAP == 0 ? c1 : nch; };
 
-    for (uint64_t t = 0; t < trips; ++t) {
+    auto full_trip = [&](uint64_t t) -> bool {  // UNROLL whole chunks: no bounds checks needed
         const uint64_t last = chunk_of(t, UNROLL - 1);
-        if (last < chunk_end() && (last + 1) * BLOCK <= n2) {
-            // fast path: UNROLL full chunks, all loads issued before the first use
-            d2 v[UNROLL][NIN ? NIN : 1];
+        return last < chunk_end() && (last + 1) * BLOCK <= n2;
+    };
+    auto load_trip = [&](uint64_t t, d2 (&v)[UNROLL][NIN ? NIN : 1]) {  // all loads of a trip, issued back to back
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const uint64_t p = chunk_of(t, u) * BLOCK + tid;
+        for (int u = 0; u < UNROLL; ++u) {
+            const uint64_t p = chunk_of(t, u) * BLOCK + tid;
 #pragma unroll
-                for (int s = 0; s < NIN; ++s) v[u][s] = ld_masked<NTI>(op.in[s], p, s);
-            }
+            for (int s = 0; s < NIN; ++s) v[u][s] = ld_masked<NTI>(op.in[s], p, s);
+        }
+    };
+    auto work_trip = [&](uint64_t t, d2 (&v)[UNROLL][NIN ? NIN : 1]) {
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const uint64_t p = chunk_of(t, u) * BLOCK + tid;
-                d2 w[NOUT ? NOUT : 1];
-                do_pair<Op>(op, cf, v[u], w, acc, gofs + 2 * p);
+        for (int u = 0; u < UNROLL; ++u) {
+            const uint64_t p = chunk_of(t, u) * BLOCK + tid;
+            d2 w[NOUT ? NOUT : 1];
+            do_pair<Op>(op, cf, v[u], w, acc, gofs + 2 * p);
+#pragma unroll
+            for (int s = 0; s < NOUT; ++s) st_masked<NTO>(op.out[s], p, w[s], s);
+        }
+    };
+    auto ragged_trip = [&](uint64_t t) {  // chunk by chunk, pair by pair
+        for (int u = 0; u < UNROLL; ++u) {
+            const uint64_t c = chunk_of(t, u);
+            const uint64_t p = c * BLOCK + tid;
+            if (c < chunk_end() && p < n2) {
+                d2 v[NIN ? NIN : 1], w[NOUT ? NOUT : 1];
+#pragma unroll
+                for (int s = 0; s < NIN; ++s) v[s] = ld_masked<NTI>(op.in[s], p, s);
+                do_pair<Op>(op, cf, v, w, acc, gofs + 2 * p);
 #pragma unroll
                 for (int s = 0; s < NOUT; ++s) st_masked<NTO>(op.out[s], p, w[s], s);
             }
+        }
+    };
+    for (uint64_t t = 0; t < trips; ++t) {
+        if (full_trip(t)) {
+            // fast path: UNROLL full chunks, all loads issued before the first use
+            d2 v[UNROLL][NIN ? NIN : 1];
+            load_trip(t, v);
+            work_trip(t, v);
         } else {
-            // ragged end: chunk by chunk, pair by pair
-            for (int u = 0; u < UNROLL; ++u) {
-                const uint64_t c = chunk_of(t, u);
-                const uint64_t p = c * BLOCK + tid;
-                if (c < chunk_end() && p < n2) {
-                    d2 v[NIN ? NIN : 1], w[NOUT ? NOUT : 1];
-#pragma unroll
-                    for (int s = 0; s < NIN; ++s) v[s] = ld_masked<NTI>(op.in[s], p, s);
-                    do_pair<Op>(op, cf, v, w, acc, gofs + 2 * p);
-#pragma unroll
-                    for (int s = 0; s < NOUT; ++s) st_masked<NTO>(op.out[s], p, w[s], s);
-                }
-            }
+            ragged_trip(t);
         }
     }
     // odd n: the last element, scalar (never taken by PAIRWISE ops: their n is even)

@@ -7,7 +7,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 # A second form names the variant and passes raw -D flags:  bash tools/build_variants.sh "b512=-DLH_BLOCK=512 nti=-DLH_NT_OUT=0u"
 for v in $1; do
   if [[ $v == *=* ]]; then
-    name=${v%%=*}; flags=${v#*=}
+    name=${v%%=*}; flags=${v#*=}; flags=${flags//,/ }   # commas separate several -D flags
     d=$root/tools/bin/variants/$name
   else
     m=${v%%:*}; u=${v##*:}
