@@ -257,6 +257,10 @@ typedef struct lbfgs_hip_objective {
     uint32_t _pad2;
     double cutoff;
 } lbfgs_hip_objective;
+/* page-locked host staging memory (hipHostMalloc): the host-closure bridge keeps x and g in such buffers so that the two
+ * PCIe transfers per evaluation run at DMA speed instead of through pageable memory */
+int lbfgs_hip_host_buffer_create(lbfgs_hip_ctx* ctx, uint64_t bytes, void** out);
+void lbfgs_hip_host_buffer_destroy(lbfgs_hip_ctx* ctx, void* buf);
 /* raw device buffers for objective data (neighbour tables ...): allocate + upload; free */
 int lbfgs_hip_device_buffer_create(lbfgs_hip_ctx* ctx, const void* host, uint64_t bytes, void** out);
 void lbfgs_hip_device_buffer_destroy(lbfgs_hip_ctx* ctx, void* buf);

@@ -104,6 +104,7 @@ lbfgs_hip_objective_eval lbfgs_hip_objective_line_eval lbfgs_hip_objective_owlqn
 lbfgs_hip_objective_is_elementwise lbfgs_hip_objective_line_probe lbfgs_hip_history_update_from_step
 lbfgs_hip_device_buffer_create
 lbfgs_hip_device_buffer_destroy
+lbfgs_hip_host_buffer_create lbfgs_hip_host_buffer_destroy
 lbfgs_hip_prof_enable lbfgs_hip_prof_reset lbfgs_hip_prof_read
 """.split()
 
@@ -178,6 +179,8 @@ def declare(L):
         "lbfgs_hip_history_update_from_step": (i, [vp, i, C.POINTER(Objective), vp, vp, vp, dbl, vp, vp, dbl, i, i]),
         "lbfgs_hip_objective_owlqn_line_eval": (i, [C.POINTER(Objective), vp, vp, vp, dbl, vp, vp, vp, dbl, u64, u64, i]),
         "lbfgs_hip_device_buffer_create": (i, [vp, vp, u64, C.POINTER(vp)]),
+        "lbfgs_hip_host_buffer_create": (i, [vp, u64, C.POINTER(vp)]),
+        "lbfgs_hip_host_buffer_destroy": (None, [vp, vp]),
         "lbfgs_hip_device_buffer_destroy": (None, [vp, vp]),
         "lbfgs_hip_prof_enable": (i, [vp, i]),
         "lbfgs_hip_prof_reset": (i, [vp]),

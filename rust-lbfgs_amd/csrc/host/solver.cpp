@@ -174,7 +174,7 @@ struct lbfgs_state {
     double xnorm2 = 0.0, gnorm2 = 0.0;  // squared norms at the current point
     bool norms_valid = false;
     bool evaluated = false;              // core.rs:48
-    std::vector<double> host_x, host_g;  // staging for the host closure
+    double *host_x = nullptr, *host_g = nullptr;  // page-locked staging for the host closure (n_local doubles each)
     // LbfgsState (lbfgs.rs:425-439)
     lbfgs_hip_history* hist = nullptr;
     int end = 0;
@@ -240,11 +240,16 @@ int call_user_evaluate(lbfgs_state* st) {
     int failed = 0;
     double f;
     if (st->eval.kind == LBFGS_EVAL_HOST) {
-        st->host_x.resize(nl);
-        st->host_g.resize(nl);
-        TRYB(st, lbfgs_hip_vec_download(st->x, st->host_x.data(), nl));
-        f = st->eval.host(st->eval.user, st->host_x.data(), st->host_g.data(), nl, &failed);
-        if (!failed) TRYB(st, lbfgs_hip_vec_upload(st->gx, st->host_g.data(), nl));
+        if (!st->host_x) {  // pinned, so the two transfers per evaluation run at DMA speed
+            void *a = nullptr, *b = nullptr;
+            TRYB(st, lbfgs_hip_host_buffer_create(st->ctx, nl * sizeof(double), &a));
+            st->host_x = static_cast<double*>(a);
+            TRYB(st, lbfgs_hip_host_buffer_create(st->ctx, nl * sizeof(double), &b));
+            st->host_g = static_cast<double*>(b);
+        }
+        TRYB(st, lbfgs_hip_vec_download(st->x, st->host_x, nl));
+        f = st->eval.host(st->eval.user, st->host_x, st->host_g, nl, &failed);
+        if (!failed) TRYB(st, lbfgs_hip_vec_upload(st->gx, st->host_g, nl));
     } else {
         TRYB(st, lbfgs_hip_sync(st->ctx));
         f = st->eval.device(st->eval.user, lbfgs_hip_vec_ptr(st->x), lbfgs_hip_vec_ptr(st->gx), nl,
@@ -596,6 +601,8 @@ static std::string g_build_error;
 void lbfgs_state_free(lbfgs_state* st) {
     if (!st) return;
     lbfgs_hip_history_destroy(st->hist);
+    lbfgs_hip_host_buffer_destroy(st->ctx, st->host_x);
+    lbfgs_hip_host_buffer_destroy(st->ctx, st->host_g);
     lbfgs_hip_vec* vs[] = {st->x, st->gx, st->xp, st->gp, st->pg, st->wp, st->d};
     for (auto* v : vs) lbfgs_hip_vec_free(v);
     delete st;

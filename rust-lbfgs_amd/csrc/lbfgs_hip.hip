@@ -1366,6 +1366,23 @@ int lbfgs_hip_constrain_direction(lbfgs_hip_vec* d, const lbfgs_hip_vec* pg, uin
 
 // ==================================================================================== objectives
 
+int lbfgs_hip_host_buffer_create(lbfgs_hip_ctx* ctx, uint64_t bytes, void** out) {
+    if (!ctx || !out) return LBFGS_HIP_ERR_ARG;
+    *out = nullptr;
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 256, hipHostMallocDefault);
+    if (e != hipSuccess)
+        return fail(ctx, LBFGS_HIP_ERR_NOMEM, "hipHostMalloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
+    *out = p;
+    return LBFGS_HIP_OK;
+}
+
+void lbfgs_hip_host_buffer_destroy(lbfgs_hip_ctx* ctx, void* buf) {
+    if (!buf) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipHostFree(buf);
+}
+
 int lbfgs_hip_device_buffer_create(lbfgs_hip_ctx* ctx, const void* host, uint64_t bytes, void** out) {
     if (!ctx || !out || (!host && bytes)) return LBFGS_HIP_ERR_ARG;
     *out = nullptr;

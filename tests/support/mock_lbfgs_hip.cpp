@@ -331,6 +331,11 @@ static int eval_obj(const lbfgs_hip_objective* obj, lbfgs_hip_ctx* c, const doub
     }
     return LBFGS_HIP_OK;
 }
+int lbfgs_hip_host_buffer_create(lbfgs_hip_ctx*, uint64_t bytes, void** out) {
+    *out = malloc(bytes ? bytes : 1);
+    return *out ? LBFGS_HIP_OK : LBFGS_HIP_ERR_NOMEM;
+}
+void lbfgs_hip_host_buffer_destroy(lbfgs_hip_ctx*, void* buf) { free(buf); }
 int lbfgs_hip_device_buffer_create(lbfgs_hip_ctx*, const void* host, uint64_t bytes, void** out) {
     *out = malloc(bytes ? bytes : 1);
     if (bytes) memcpy(*out, host, bytes);
