@@ -10,7 +10,6 @@ import ctypes as C
 
 import numpy as np
 
-from . import _ffi
 from .api import BuiltinObjective, Context, _dp
 from .math import DeviceVec
 

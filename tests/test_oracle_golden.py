@@ -7,7 +7,6 @@ import json
 import os
 
 import numpy as np
-import pytest
 
 from oracle import oracle as O
 from tests import problems as P
