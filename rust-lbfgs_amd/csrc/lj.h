@@ -35,9 +35,17 @@ __global__ __launch_bounds__(BLOCK) void lj_allpairs_kernel(const double* __rest
         for (uint32_t t = threadIdx.x; t < 3 * cnt; t += BLOCK) tile[t] = x[3 * (size_t)base + t];
         __syncthreads();
         if (live) {
-            for (uint32_t j = 0; j < cnt; ++j) {
-                if (base + j == i) continue;
-                lj_pair(xi - tile[3 * j], yi - tile[3 * j + 1], zi - tile[3 * j + 2], e, fx, fy, fz);
+            if (base != blockIdx.x * BLOCK) {
+                // a tile that cannot contain atom i: no self test, so the loop unrolls and four independent
+                // division chains keep the f64 pipe busy at one wave per SIMD
+#pragma unroll 4
+                for (uint32_t j = 0; j < cnt; ++j)
+                    lj_pair(xi - tile[3 * j], yi - tile[3 * j + 1], zi - tile[3 * j + 2], e, fx, fy, fz);
+            } else {
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    if (base + j == i) continue;
+                    lj_pair(xi - tile[3 * j], yi - tile[3 * j + 1], zi - tile[3 * j + 2], e, fx, fy, fz);
+                }
             }
         }
     }
