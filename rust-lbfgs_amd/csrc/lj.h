@@ -62,14 +62,22 @@ __global__ __launch_bounds__(BLOCK) void lj_neighbors_kernel(const double* __res
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < natoms; i += gridDim.x * BLOCK) {
         const double xi = x[3 * (size_t)i], yi = x[3 * (size_t)i + 1], zi = x[3 * (size_t)i + 2];
         double fx = 0.0, fy = 0.0, fz = 0.0;
+        // Branch-free and unrolled: the gathers of four neighbours are in flight together.  An empty slot (-1) or a pair
+        // beyond the cutoff is evaluated at a harmless r^2 = 1 and adds a selected 0.0, so the sums are those of the
+        // branching loop.
+#pragma unroll 4
         for (uint32_t k = 0; k < max_nbr; ++k) {
             const int32_t j = nbr[(size_t)k * natoms + i];  // coalesced across lanes
-            if (j < 0) continue;
-            const double dx = xi - x[3 * (size_t)j], dy = yi - x[3 * (size_t)j + 1], dz = zi - x[3 * (size_t)j + 2];
-            if (dx * dx + dy * dy + dz * dz < rc2) {
-                lj_pair(dx, dy, dz, e, fx, fy, fz);
-                e -= eshift;
-            }
+            const size_t jj = (j < 0) ? (size_t)i : (size_t)j;
+            const double dx = xi - x[3 * jj], dy = yi - x[3 * jj + 1], dz = zi - x[3 * jj + 2];
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            const bool on = (j >= 0) && (r2 < rc2);
+            const double inv2 = 1.0 / (on ? r2 : 1.0);
+            const double s6 = inv2 * inv2 * inv2;
+            e += on ? 4.0 * (s6 * s6 - s6) : 0.0;                     // pair_energy   lj.rs:22-25
+            const double c = 24.0 * (s6 - 2.0 * (s6 * s6)) * inv2;   // pair_gradient/r  lj.rs:28-32, :57-58
+            fx += on ? c * dx : 0.0; fy += on ? c * dy : 0.0; fz += on ? c * dz : 0.0;  // selects: a NaN neighbour stays out
+            e -= on ? eshift : 0.0;
         }
         g[3 * (size_t)i] = fx; g[3 * (size_t)i + 1] = fy; g[3 * (size_t)i + 2] = fz;
     }
