@@ -123,6 +123,8 @@ struct lbfgs_hip_ctx {
     double* board = nullptr;         // LBFGS_HIP_BOARD_SLOTS doubles + 2 ping-pong dots
     double* partials = nullptr;      // MAX_RED * MAX_GRID
     unsigned int* ticket = nullptr;
+    double* lj_scratch = nullptr;         // all-pairs LJ: per-j-range force slices (allocated on demand)
+    size_t lj_scratch_bytes = 0;
     unsigned long long* gran = nullptr;   // tagged partial granules [MAX_RED][MAX_GRID][2] (stream.h)
     unsigned int red_epoch = 0;           // tag of the latest reducing launch (never 0)
     int grid_class[16] = {0};             // LBFGS_HIP_GRID_K<class>=N: grid override per kernel class (in-situ tuning)
@@ -455,9 +457,32 @@ int lj_eval(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, const lbfgs_hip_
     {
         ProfScope ps(ctx, LBFGS_HIP_K_EVAL);
         if (obj->kind == LBFGS_HIP_OBJ_LJ_ALLPAIRS) {
-            const uint32_t grid = (natoms + BLOCK - 1) / BLOCK;
-            if (grid > MAX_GRID) return fail(ctx, LBFGS_HIP_ERR_ARG, "all-pairs LJ supports up to %d atoms", MAX_GRID * BLOCK);
-            hipLaunchKernelGGL(lj_allpairs_kernel, dim3(grid ? grid : 1), dim3(BLOCK), 0, ctx->stream, x->p, g->p, natoms, red);
+            const uint32_t tiles = std::max(1u, (natoms + BLOCK - 1) / BLOCK);
+            if (tiles > (uint32_t)MAX_GRID) return fail(ctx, LBFGS_HIP_ERR_ARG, "all-pairs LJ supports up to %d atoms", MAX_GRID * BLOCK);
+            // about six workgroups per CU: enough waves per SIMD to hide the division chains, and a short tail
+            uint32_t S = (uint32_t)std::lround(6.0 * ctx->cu_count / tiles);
+            S = std::min({std::max(S, 1u), 16u, tiles, (uint32_t)MAX_GRID / tiles});
+            const uint32_t jspan = ((natoms + S - 1) / S + BLOCK - 1) / BLOCK * BLOCK;
+            S = (natoms + jspan - 1) / jspan;  // ranges that actually hold atoms
+            double* out_f = g->p;
+            if (S > 1) {
+                const size_t need = (size_t)S * n * sizeof(double);
+                if (need > ctx->lj_scratch_bytes) {
+                    if (ctx->lj_scratch) HIP_TRY(ctx, hipFree(ctx->lj_scratch));
+                    ctx->lj_scratch = nullptr;
+                    ctx->lj_scratch_bytes = 0;
+                    hipError_t e = hipMalloc(&ctx->lj_scratch, need);
+                    if (e != hipSuccess) return fail(ctx, LBFGS_HIP_ERR_NOMEM, "LJ force slices: %s", hipGetErrorString(e));
+                    ctx->lj_scratch_bytes = need;
+                }
+                out_f = ctx->lj_scratch;
+            }
+            hipLaunchKernelGGL(lj_allpairs_kernel, dim3(tiles * S), dim3(BLOCK), 0, ctx->stream, x->p, out_f, natoms, tiles,
+                               jspan, red);
+            if (S > 1) {
+                const uint32_t cg = (uint32_t)std::min<uint64_t>((n + BLOCK - 1) / BLOCK, 1024);
+                hipLaunchKernelGGL(lj_combine_kernel, dim3(cg), dim3(BLOCK), 0, ctx->stream, ctx->lj_scratch, g->p, n, S);
+            }
         } else {
             if (!obj->nbr_index || obj->max_nbr == 0 || !(obj->cutoff > 0.0))
                 return fail(ctx, LBFGS_HIP_ERR_ARG, "LJ_NEIGHBORS needs a neighbour table and a cutoff");
@@ -780,6 +805,7 @@ void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* ctx) {
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     if (ctx->gran) (void)hipFree(ctx->gran);
+    if (ctx->lj_scratch) (void)hipFree(ctx->lj_scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->mirror) (void)hipHostFree(ctx->mirror);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
