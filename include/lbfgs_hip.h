@@ -82,7 +82,8 @@ typedef struct lbfgs_hip_comm {
     const void* rccl_unique_id;  /* 128 bytes from lbfgs_hip_rccl_unique_id() on rank 0, shared out of band */
     lbfgs_hip_allreduce_cb callback;
     void* callback_user;
-    void* p2p_mailbox;           /* P2P: this rank's mailbox from lbfgs_hip_p2p_mailbox_create (owned by the ctx afterwards) */
+    void* p2p_mailbox;           /* P2P: this rank's mailbox from lbfgs_hip_p2p_mailbox_create (lbfgs_hip_ctx_create takes
+                                    ownership whether it succeeds or not: on failure it frees the mailbox itself) */
     const void* p2p_handles;     /* P2P: world x 64-byte IPC handles in rank order, gathered out of band */
     double p2p_timeout_s;        /* P2P: bound on every spin (0 = 5 s); a timeout fails the next scalars_read */
 } lbfgs_hip_comm;
@@ -97,7 +98,7 @@ int lbfgs_hip_rccl_unique_id(void* out128);
 /* P2P step 1 (before ctx_create): allocate this rank's mailbox in uncached device memory and export
  * its 64-byte IPC handle; the host framework all-gathers the handles into lbfgs_hip_comm.p2p_handles. */
 int lbfgs_hip_p2p_mailbox_create(int device, void** mailbox_out, void* ipc_handle64_out);
-void lbfgs_hip_p2p_mailbox_destroy(int device, void* mailbox); /* only if ctx_create was never given it */
+void lbfgs_hip_p2p_mailbox_destroy(int device, void* mailbox); /* only for a mailbox never handed to lbfgs_hip_ctx_create */
 /* shard == NULL => single rank holding n elements.  comm == NULL => NONE.
  * stream == NULL => the context creates its own non-blocking stream. */
 int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfgs_hip_shard* shard,
@@ -143,6 +144,11 @@ int lbfgs_hip_vecncpy(lbfgs_hip_vec* y, const lbfgs_hip_vec* x);                
 int lbfgs_hip_vecdiff(lbfgs_hip_vec* z, const lbfgs_hip_vec* x, const lbfgs_hip_vec* y); /* math.rs:66 */
 /* math.rs:73-81: the board receives the SQUARED norm (dot(x,x)); sqrt / 1.0/sqrt are host scalar ops */
 int lbfgs_hip_vec2norm_sq(const lbfgs_hip_vec* x, int out_slot);
+/* math.rs:73-76 vec2norm = sqrt(vecdot(x, x)) and math.rs:79-81 vec2norminv = 1.0 / vec2norm: the 1:1 forms of the
+ * trait methods.  The (global, all-reduced) dot(x,x) is left in board[scratch_slot]; *out receives the norm resp.
+ * its reciprocal (one stream synchronisation, like every host-returning reduction). */
+int lbfgs_hip_vec2norm(const lbfgs_hip_vec* x, int scratch_slot, double* out);
+int lbfgs_hip_vec2norminv(const lbfgs_hip_vec* x, int scratch_slot, double* out);
 
 /* ------------------------------------------------------------------------- */
 /* fused hot-path operators                                                    */

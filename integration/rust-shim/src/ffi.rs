@@ -165,6 +165,8 @@ extern "C" {
     pub fn lbfgs_hip_vecncpy(y: *mut lbfgs_hip_vec, x: *const lbfgs_hip_vec) -> c_int;
     pub fn lbfgs_hip_vecdiff(z: *mut lbfgs_hip_vec, x: *const lbfgs_hip_vec, y: *const lbfgs_hip_vec) -> c_int;
     pub fn lbfgs_hip_vec2norm_sq(x: *const lbfgs_hip_vec, out_slot: c_int) -> c_int;
+    pub fn lbfgs_hip_vec2norm(x: *const lbfgs_hip_vec, scratch_slot: c_int, out: *mut f64) -> c_int;
+    pub fn lbfgs_hip_vec2norminv(x: *const lbfgs_hip_vec, scratch_slot: c_int, out: *mut f64) -> c_int;
     // ---- fused hot path ------------------------------------------------------------------------
     pub fn lbfgs_hip_line_step(x: *mut lbfgs_hip_vec, xp: *const lbfgs_hip_vec, d: *const lbfgs_hip_vec, step: f64,
                                wp: *const lbfgs_hip_vec, start: u64, end: u64) -> c_int;

@@ -94,7 +94,7 @@ lbfgs_hip_vec_alloc lbfgs_hip_vec_free lbfgs_hip_vec_upload lbfgs_hip_vec_downlo
 lbfgs_hip_vec_ptr lbfgs_hip_vec_swap
 lbfgs_hip_scalars_read lbfgs_hip_scalars_write lbfgs_hip_scalars_ptr lbfgs_hip_scalars_allreduce
 lbfgs_hip_vecadd lbfgs_hip_vecadd_dev lbfgs_hip_vecdot lbfgs_hip_vecscale lbfgs_hip_veccpy lbfgs_hip_vecncpy
-lbfgs_hip_vecdiff lbfgs_hip_vec2norm_sq
+lbfgs_hip_vecdiff lbfgs_hip_vec2norm_sq lbfgs_hip_vec2norm lbfgs_hip_vec2norminv
 lbfgs_hip_line_step lbfgs_hip_norms_sq
 lbfgs_hip_history_create lbfgs_hip_history_destroy lbfgs_hip_history_s lbfgs_hip_history_y
 lbfgs_hip_history_scalars_read lbfgs_hip_history_scalars_write lbfgs_hip_history_update lbfgs_hip_history_damp
@@ -154,6 +154,8 @@ def declare(L):
         "lbfgs_hip_vecncpy": (i, [vp, vp]),
         "lbfgs_hip_vecdiff": (i, [vp, vp, vp]),
         "lbfgs_hip_vec2norm_sq": (i, [vp, i]),
+        "lbfgs_hip_vec2norm": (i, [vp, i, dp]),
+        "lbfgs_hip_vec2norminv": (i, [vp, i, dp]),
         "lbfgs_hip_line_step": (i, [vp, vp, vp, dbl, vp, u64, u64]),
         "lbfgs_hip_norms_sq": (i, [vp, vp, i]),
         "lbfgs_hip_history_create": (i, [vp, i, C.POINTER(vp)]),

@@ -238,23 +238,34 @@ int call_user_evaluate(lbfgs_state* st) {
     if (st->eval.kind == LBFGS_EVAL_BUILTIN)
         return backend(st, lbfgs_hip_objective_eval(&st->eval.builtin, st->x, st->gx, S_F));
     int failed = 0;
-    double f;
+    double f = 0.0;
+    // A rank-local backend failure (staging buffers, transfers, stream) must not leave the peers alone in the
+    // collective below: it is folded into `failed`, this rank still takes part, and the stored error is
+    // returned afterwards.
+    int local_rc = LBFGS_OK;
+    std::string local_err;
+    auto local = [&](int rc) {
+        if (local_rc == LBFGS_OK && backend(st, rc) != LBFGS_OK) {
+            local_rc = rc;
+            local_err = st->err;
+        }
+        return local_rc == LBFGS_OK;
+    };
     if (st->eval.kind == LBFGS_EVAL_HOST) {
         if (!st->host_x) {  // pinned, so the two transfers per evaluation run at DMA speed
             void *a = nullptr, *b = nullptr;
-            TRYB(st, lbfgs_hip_host_buffer_create(st->ctx, nl * sizeof(double), &a));
-            st->host_x = static_cast<double*>(a);
-            TRYB(st, lbfgs_hip_host_buffer_create(st->ctx, nl * sizeof(double), &b));
-            st->host_g = static_cast<double*>(b);
+            if (local(lbfgs_hip_host_buffer_create(st->ctx, nl * sizeof(double), &a))) st->host_x = static_cast<double*>(a);
+            if (local(lbfgs_hip_host_buffer_create(st->ctx, nl * sizeof(double), &b))) st->host_g = static_cast<double*>(b);
         }
-        TRYB(st, lbfgs_hip_vec_download(st->x, st->host_x, nl));
-        f = st->eval.host(st->eval.user, st->host_x, st->host_g, nl, &failed);
-        if (!failed) TRYB(st, lbfgs_hip_vec_upload(st->gx, st->host_g, nl));
-    } else {
-        TRYB(st, lbfgs_hip_sync(st->ctx));
+        if (local(lbfgs_hip_vec_download(st->x, st->host_x, nl))) {
+            f = st->eval.host(st->eval.user, st->host_x, st->host_g, nl, &failed);
+            if (!failed) local(lbfgs_hip_vec_upload(st->gx, st->host_g, nl));
+        }
+    } else if (local(lbfgs_hip_sync(st->ctx))) {
         f = st->eval.device(st->eval.user, lbfgs_hip_vec_ptr(st->x), lbfgs_hip_vec_ptr(st->gx), nl,
                             lbfgs_hip_stream(st->ctx), &failed);
     }
+    if (local_rc != LBFGS_OK) failed = 1;
     if (multi) {  // partial f per shard; a failure on any rank fails all
         double v[2] = {failed ? 0.0 : f, failed ? 1.0 : 0.0};
         TRYB(st, lbfgs_hip_scalars_write(st->ctx, S_F, 1, &v[0]));
@@ -263,9 +274,11 @@ int call_user_evaluate(lbfgs_state* st) {
         TRYB(st, lbfgs_hip_scalars_allreduce(st->ctx, S_FAILED, 1));
         double nf = 0.0;
         TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_FAILED, 1, &nf));
+        if (local_rc != LBFGS_OK) return fail(st, local_rc, local_err);
         if (nf != 0.0) return fail(st, LBFGS_ERR_EVALUATE, "evaluate failed");
         return LBFGS_OK;
     }
+    if (local_rc != LBFGS_OK) return fail(st, local_rc, local_err);
     if (failed) return fail(st, LBFGS_ERR_EVALUATE, "evaluate failed");
     return backend(st, lbfgs_hip_scalars_write(st->ctx, S_F, 1, &f));
 }
@@ -779,7 +792,19 @@ int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
     st->norms_valid = false;
 
     uint64_t ncall = 0;
-    TRY(line_search_find(st, st->step, &ncall, true));  // :517-521
+    {
+        const int rc_ls = line_search_find(st, st->step, &ncall, true);  // :517-521
+        if (rc_ls != LBFGS_OK) {
+            // a hard error (negative step, gradient-only + More-Thuente, backend / communicator failure): the
+            // reference's save_state COPIES (core.rs:207-210), so its x still is the point the search started from.
+            // Undo the buffer exchange so that VEC_X names that point again (minimize() hands it back to the caller).
+            (void)lbfgs_hip_vec_swap(st->x, st->xp);
+            (void)lbfgs_hip_vec_swap(st->gx, st->gp);
+            st->norms_valid = false;
+            st->point_deferred = false;
+            return rc_ls;
+        }
+    }
     st->ncall = ncall;
     const double step_ls = st->step;
 
@@ -835,7 +860,8 @@ int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
                                          S_UPD + 2, S_DNORM2, st->owlqn() ? -1 : S_UPD + 6, &new_end));
     if (st->owlqn() && !projected)  // :554, orthantwise.rs:140-161 (after dnorm, as in the reference)
         TRYB(st, lbfgs_hip_constrain_direction(st->d, st->pg, st->owl_start, st->owl_end, S_DNORM2C));
-    TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_UPD, S_END_BLOCK - S_UPD, u));
+    // plain L-BFGS never writes S_DNORM2C..: asking for them would force the copy path of scalars_read every iteration
+    TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_UPD, (st->owlqn() ? S_END_BLOCK : S_DNORM2C) - S_UPD, u));
     if (!early) TRY(check_update());
     st->end = new_end;
     if (!st->owlqn()) {

@@ -647,19 +647,34 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
                          const lbfgs_hip_comm* comm, void* stream) {
     if (!out) return fail(nullptr, LBFGS_HIP_ERR_ARG, "null out");
     *out = nullptr;
+    // A P2P mailbox handed in through `comm` belongs to this call from here on, whether it succeeds or not
+    // (lbfgs_hip.h): until the context owns it, every failure path frees it.
+    void* const mbox_in = (comm && comm->kind == LBFGS_HIP_COMM_P2P) ? comm->p2p_mailbox : nullptr;
+    auto drop_mbox = [&]() {
+        if (mbox_in) lbfgs_hip_p2p_mailbox_destroy(device, mbox_in);
+    };
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        drop_mbox();
         return fail(nullptr, LBFGS_HIP_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
-    if (device < 0 || device >= ndev) return fail(nullptr, LBFGS_HIP_ERR_ARG, "device %d out of range (%d)", device, ndev);
+    }
+    if (device < 0 || device >= ndev) {
+        drop_mbox();
+        return fail(nullptr, LBFGS_HIP_ERR_ARG, "device %d out of range (%d)", device, ndev);
+    }
 
     lbfgs_hip_ctx* ctx = new (std::nothrow) lbfgs_hip_ctx();
-    if (!ctx) return fail(nullptr, LBFGS_HIP_ERR_NOMEM, "out of host memory");
+    if (!ctx) {
+        drop_mbox();
+        return fail(nullptr, LBFGS_HIP_ERR_NOMEM, "out of host memory");
+    }
     ctx->device = device;
     if (shard) {
         ctx->shard = *shard;
         if (shard->world < 1 || shard->rank < 0 || shard->rank >= shard->world ||
             shard->offset + shard->n_local > shard->n_global) {
             delete ctx;
+            drop_mbox();
             return fail(nullptr, LBFGS_HIP_ERR_ARG, "inconsistent shard");
         }
     } else {
@@ -668,6 +683,14 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
         ctx->shard.n_global = n;
         ctx->shard.offset = 0;
         ctx->shard.n_local = n;
+    }
+    if (mbox_in) {
+        if (ctx->shard.rank >= P2P_MAX_WORLD) {
+            delete ctx;
+            drop_mbox();
+            return fail(nullptr, LBFGS_HIP_ERR_ARG, "P2P communicator supports world <= %d", P2P_MAX_WORLD);
+        }
+        ctx->p2p_mbox[ctx->shard.rank] = (unsigned long long*)mbox_in;  // lbfgs_hip_ctx_destroy frees it from now on
     }
 #define CTX_TRY(call)                                                                              \
     do {                                                                                           \
@@ -756,8 +779,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
             return fail(nullptr, LBFGS_HIP_ERR_ARG, "P2P communicator needs a mailbox, %d handles and world <= %d", W,
                         P2P_MAX_WORLD);
         }
-        ctx->p2p_mbox[me] = (unsigned long long*)comm->p2p_mailbox;
-        for (int r = 0; r < W; ++r) {
+        for (int r = 0; r < W; ++r) {  // (p2p_mbox[me] was taken over at the top)
             if (r == me) continue;
             hipIpcMemHandle_t hdl;
             memcpy(&hdl, (const char*)comm->p2p_handles + (size_t)r * HIP_IPC_HANDLE_SIZE, sizeof(hdl));
@@ -1035,6 +1057,24 @@ int lbfgs_hip_vec2norm_sq(const lbfgs_hip_vec* x, int out_slot) {
     op.in[0] = x->p;
     double* outs[1] = {x->ctx->board + out_slot};
     return launch(x->ctx, LBFGS_HIP_K_BLAS1, op, outs);
+}
+
+int lbfgs_hip_vec2norm(const lbfgs_hip_vec* x, int scratch_slot, double* out) {  // math.rs:73-76
+    if (!x || !out || !slot_ok(scratch_slot, 1)) return LBFGS_HIP_ERR_ARG;
+    int rc = lbfgs_hip_vec2norm_sq(x, scratch_slot);
+    if (rc != LBFGS_HIP_OK) return rc;
+    double sq = 0.0;
+    if ((rc = lbfgs_hip_scalars_read(x->ctx, scratch_slot, 1, &sq)) != LBFGS_HIP_OK) return rc;
+    *out = std::sqrt(sq);
+    return LBFGS_HIP_OK;
+}
+
+int lbfgs_hip_vec2norminv(const lbfgs_hip_vec* x, int scratch_slot, double* out) {  // math.rs:79-81
+    double nrm = 0.0;
+    const int rc = lbfgs_hip_vec2norm(x, scratch_slot, &nrm);
+    if (rc != LBFGS_HIP_OK) return rc;
+    *out = 1.0 / nrm;
+    return LBFGS_HIP_OK;
 }
 
 // ==================================================================================== fused ops

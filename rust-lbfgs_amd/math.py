@@ -9,7 +9,6 @@ stream synchronisation each); `*_slot` variants leave the result on the device b
 from __future__ import annotations
 
 import ctypes as C
-import math as _math
 
 import numpy as np
 
@@ -89,9 +88,12 @@ class DeviceVec:
 
     def vec2norm(self) -> float:
         """||x||  (math.rs:73-76): sqrt of the device dot"""
-        self.ctx.check(self._L.lbfgs_hip_vec2norm_sq(self._h, _SCRATCH_SLOT))
-        return _math.sqrt(float(self.ctx.scalars(_SCRATCH_SLOT)[0]))
+        out = C.c_double()
+        self.ctx.check(self._L.lbfgs_hip_vec2norm(self._h, _SCRATCH_SLOT, C.byref(out)))
+        return out.value
 
     def vec2norminv(self) -> float:
         """1/||x||  (math.rs:79-81)"""
-        return 1.0 / self.vec2norm()
+        out = C.c_double()
+        self.ctx.check(self._L.lbfgs_hip_vec2norminv(self._h, _SCRATCH_SLOT, C.byref(out)))
+        return out.value

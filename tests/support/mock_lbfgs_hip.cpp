@@ -141,6 +141,17 @@ int lbfgs_hip_veccpy(lbfgs_hip_vec* y, const lbfgs_hip_vec* x) { oracle_veccpy(y
 int lbfgs_hip_vecncpy(lbfgs_hip_vec* y, const lbfgs_hip_vec* x) { oracle_vecncpy(y->p->data(), x->p->data(), nl(y->ctx)); return 0; }
 int lbfgs_hip_vecdiff(lbfgs_hip_vec* z, const lbfgs_hip_vec* x, const lbfgs_hip_vec* y) { oracle_vecdiff(z->p->data(), x->p->data(), y->p->data(), nl(z->ctx)); return 0; }
 int lbfgs_hip_vec2norm_sq(const lbfgs_hip_vec* x, int s) { return gdot(x->ctx, x->p->data(), x->p->data(), x->ctx->board + s); }
+int lbfgs_hip_vec2norm(const lbfgs_hip_vec* x, int s, double* out) {
+    int rc = lbfgs_hip_vec2norm_sq(x, s);
+    if (rc == 0) *out = std::sqrt(x->ctx->board[s]);
+    return rc;
+}
+int lbfgs_hip_vec2norminv(const lbfgs_hip_vec* x, int s, double* out) {
+    double v = 0.0;
+    int rc = lbfgs_hip_vec2norm(x, s, &v);
+    if (rc == 0) *out = 1.0 / v;
+    return rc;
+}
 
 int lbfgs_hip_line_step(lbfgs_hip_vec* x, const lbfgs_hip_vec* xp, const lbfgs_hip_vec* d, double step,
                         const lbfgs_hip_vec* wp, uint64_t start, uint64_t end) {

@@ -215,6 +215,23 @@ def test_error_paths():
     with pytest.raises(R.LbfgsError) as e:
         b.minimize(P.rosenbrock_x0(), R.default_evaluate())
     assert e.value.code == _ffi.ERR_GRADONLY_MT
+    # ... and a hard line-search error leaves x at the point the search started from (the reference's save_state
+    # copies, core.rs:207-210; the product exchanges buffers and has to undo that before returning)
+    for x0 in (np.array([1.0, 2.0, 5.0, -4.0]), P.rosenbrock_x0()):
+        xp_, xo_ = x0.copy(), x0.copy()
+        with pytest.raises(R.LbfgsError) as e:
+            R.lbfgs().with_gradient_only().with_linesearch_algorithm("MoreThuente").minimize(xp_, R.default_evaluate())
+        with pytest.raises(O.OracleError) as eo:
+            O.lbfgs().with_gradient_only().with_linesearch_algorithm("MoreThuente").minimize(xo_, O.rosenbrock())
+        assert e.value.code == eo.value.code == _ffi.ERR_GRADONLY_MT
+        assert np.array_equal(xp_, x0) and np.array_equal(xo_, x0)
+    x = P.rosenbrock_x0()
+    with R.lbfgs().with_gradient_only().with_linesearch_algorithm("MoreThuente").build(x, R.default_evaluate()) as sp:
+        sp.propagate()
+        gx0 = sp.download("gx")
+        with pytest.raises(R.LbfgsError):
+            sp.propagate()
+        assert np.array_equal(sp.download("x"), x) and np.array_equal(sp.download("gx"), gx0)
     # orthantwise start >= end panics (orthantwise.rs:64)
     with pytest.raises(R.LbfgsPanic):
         R.lbfgs().with_orthantwise(1.0, 100, 100).minimize(P.rosenbrock_x0(), R.default_evaluate())
