@@ -9,22 +9,43 @@ A "step" is ONE L-BFGS iteration (LbfgsState::propagate, reference src/lbfgs.rs:
 synthetic diagonal quadratic of BASELINE.json config 4: n = 1e8, m = 10, More-Thuente, f64, the
 crate's default parameters, everything resident in HBM (device objective, no PCIe in the timed
 region).  One step = the line search (per trial one pass over xp and d that returns f and g.d), the
-history update (which also forms the accepted x and g) and the fused two-loop recursion.  With N > 1 the n-vector is sharded contiguously over the
-ranks (total work fixed => "strong" scaling) and every reduction is closed by an all-reduce of its
-f64 scalars: RCCL ncclAllReduce on the compute stream, or the direct xGMI mailbox exchange ("p2p").
-With --comm auto (default) both are measured -- RCCL first, then p2p if its start-up self-test
-passes on every rank -- and the faster one is reported as `value`; both are listed in `config`.
+history update (which also forms the accepted x and g) and the fused two-loop recursion.  With N > 1
+the n-vector is sharded contiguously over the ranks (total work fixed => "strong" scaling) and every
+reduction is closed by an all-reduce of its f64 scalars.
+
+Process structure.  N = 1 runs in this process.  N > 1 never measures in the process the user (or
+torch.distributed.run) started: that process is a SUPERVISOR that touches no GPU and runs one fresh
+child job per communicator ("leg"), each under a wall-clock timeout:
+  * `python bench.py --gpus N` (no RANK in the environment): per leg one
+    `python -m torch.distributed.run --nproc-per-node N bench.py --_rank-mode --comm <leg>` child;
+  * launched by torch.distributed.run (RANK set): every rank is a supervisor (gloo group, CPU only);
+    rank 0 picks a fresh rendezvous port per leg and each rank starts ITS child
+    `python bench.py --_rank-mode --comm <leg>` with the same RANK / LOCAL_RANK / WORLD_SIZE.
+Legs, in this order: "p2p" (direct xGMI mailbox exchange inside the reducing kernels -- the path the
+multi-process tests cover), then "rccl" (ncclAllReduce on the compute stream); "callback" (host-staged
+all-reduce through gloo) only if neither produced a result.  A leg that fails or hangs is reported in
+`config.legs`; the run prints ONE JSON line with the best leg as `value` and exits 0 if any leg
+succeeded.
+
+Timing.  W warm-up steps (plus whatever fills the history: bound = m before anything is timed), then
+EXACTLY K steps between barrier + synchronize on both sides, max over ranks.  That K-step region is
+repeated --repeats times, each time from a freshly built state brought to the same iteration, so
+every repeat times the same K iterations; `value` / `ms_per_step` are the MEDIAN repeat, all repeats
+are listed in `config.repeats_iters_per_sec`.
 
 The JSON line carries, besides the contract fields:
   roofline      the dominant kernel (two-loop step  q += c*u ; out = v.q,  3 reads + 1 write of
                 an n-vector = 32 bytes/element algorithmic) timed with HIP events on the launch
                 stream over the timed region, against the 8 TB/s HBM peak;
-  cpu_baseline  the CPU oracle (reference operation order, 1 thread) on a bounded sample of the
-                same workload, rank 0, N = 1 only.
+  cpu_baseline  the CPU oracle (reference operation order, 1 thread) on the metric's own
+                configuration (n = 1e8, m = 10: 3 iterations after m+2 warm-up, ~22 GB of host memory) when
+                the host has the memory, with the sampled-and-scaled figure beside it; rank 0, N = 1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,41 +55,75 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--dim", dest="n", type=int, default=100_000_000, help="n, the number of variables")
     ap.add_argument("--hist", dest="m", type=int, default=10, help="m, the number of L-BFGS corrections")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="how many times the K-step timed region is measured (median reported)")
     ap.add_argument("--no-prof", action="store_true", help="do not time kernels with HIP events in the timed region")
     ap.add_argument("--prof-every", type=int, default=5,
                     help="time kernels with HIP events on every k-th step of the timed region only: an event pair per "
                          "kernel costs ~1.5 us of stream time, 11 %% of an iteration at 100 MB shards when always on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=20_000_000, help="sample size of the CPU baseline (~10 s on one core)")
+    ap.add_argument("--cpu-n", type=int, default=20_000_000, help="sample size of the sampled CPU baseline (~10 s on one core)")
+    ap.add_argument("--no-cpu-full", action="store_true",
+                    help="skip the CPU baseline at the metric's own n (needs (2m+7)*8n bytes of host memory, ~50 s)")
     ap.add_argument("--grid", type=int, default=0, help="workgroups per launch (0 = library default)")
     ap.add_argument("--comm", default="auto", choices=["auto", "rccl", "p2p", "callback"],
-                    help="N>1: how scalars are all-reduced (auto = measure RCCL, then p2p if its self-test passes)")
-    ap.add_argument("--pg-backend", default="nccl", help="torch.distributed backend used for rendezvous/barriers")
+                    help="N>1: how scalars are all-reduced (auto = p2p, then rccl; callback if both fail)")
+    ap.add_argument("--pg-backend", default="auto",
+                    help="torch.distributed backend of a rank process, used for rendezvous, barriers and the max over "
+                         "ranks (auto = nccl for the rccl leg, gloo otherwise)")
+    ap.add_argument("--leg-timeout", type=float, default=420.0, help="N>1: wall-clock bound on one communicator leg (s)")
     ap.add_argument("--no-vector-free", action="store_true",
                     help="skip the extra measurement of the vector-free (Gram) two-loop extension")
     ap.add_argument("--line-eval", type=int, default=2, choices=[0, 1, 2],
                     help="lbfgs_evaluator.fuse_line_eval: 2 = trials write no vectors (default), 1 = every trial writes x and g, "
                          "0 = separate passes")
     ap.add_argument("--device", type=int, default=-1, help="force a device index (testing: several ranks on one GPU)")
-    return ap.parse_args()
+    ap.add_argument("--_rank-mode", dest="rank_mode", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(n_sample, m, n_full):
-    """The oracle (C restatement of the reference's sequential arithmetic) on one host core."""
+# ======================================================================================== CPU baseline
+def host_info():
+    model, cores = "unknown", os.cpu_count() or 0
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    avail = None
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable"):
+                avail = int(ln.split()[1]) * 1024
+                break
+    except OSError:
+        pass
+    usable = cores
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    return model, cores, usable, avail
+
+
+def oracle_ips(n, m, timed):
+    """iterations/sec of the oracle (C restatement of the reference's sequential arithmetic) on one host core."""
     import numpy as np
 
     from oracle import oracle as O
 
-    x = np.zeros(n_sample)
+    x = np.zeros(n)
     st = O.lbfgs().with_m(m).with_epsilon(0.0).build(x, O.quadratic())
-    warm, timed = m + 2, 6
+    warm = m + 2  # the history is full (bound = m) from iteration m+2 on
     for _ in range(warm):
         st.propagate()
     t0 = time.perf_counter()
@@ -76,41 +131,68 @@ def cpu_baseline(n_sample, m, n_full):
         st.propagate()
     dt = time.perf_counter() - t0
     st.close()
-    ips_sample = timed / dt
-    return {
-        "value": ips_sample * n_sample / n_full,
-        "unit": "iters/sec",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"oracle (gcc -O2 -ffp-contract=off, sequential sums) on the same quadratic at n={n_sample}, m={m}: "
-                  f"{timed} iterations after {warm} warm-up = {ips_sample:.3f} iters/sec, scaled by n_sample/n "
-                  f"(every pass is O(n)) to n={n_full}",
+    return timed / dt, warm
+
+
+def cpu_baseline(a):
+    model, cores, usable, avail = host_info()
+    ips_s, warm_s = oracle_ips(a.cpu_n, a.m, 6)
+    scaled = ips_s * a.cpu_n / a.n
+    out = {
+        "value": scaled, "unit": "iters/sec", "cores": 1, "kind": "port",
+        "host_cpu": model, "host_cores_total": cores, "host_cores_usable": usable,
+        "sampled_and_scaled": {"value": scaled, "n_sample": a.cpu_n, "iters_per_sec_at_n_sample": ips_s,
+                               "timed_iterations": 6, "warmup_iterations": warm_s},
+        "sample": f"oracle (gcc -O2 -ffp-contract=off, sequential sums, 1 thread) on the same quadratic at n={a.cpu_n}, m={a.m}: "
+                  f"6 iterations after {warm_s} warm-up = {ips_s:.3f} iters/sec, scaled by n_sample/n (every pass is O(n)) "
+                  f"to n={a.n}",
     }
+    need = (2 * a.m + 9) * 8 * a.n  # 2m history + 7 problem vectors (+ the caller's x and slack)
+    if a.no_cpu_full or a.n <= a.cpu_n:
+        return out
+    if avail is None or avail < need * 1.25:
+        out["full_size"] = f"skipped: needs {need / 1e9:.1f} GB of host memory, {0 if avail is None else avail / 1e9:.1f} GB available"
+        return out
+    try:
+        ips_f, warm_f = oracle_ips(a.n, a.m, 3)
+    except Exception as e:  # noqa: BLE001  (MemoryError included)
+        out["full_size"] = f"failed: {e!r}"
+        return out
+    out["value"] = ips_f
+    out["full_size"] = {"value": ips_f, "n": a.n, "timed_iterations": 3, "warmup_iterations": warm_f}
+    out["sample"] = (f"oracle (gcc -O2 -ffp-contract=off, sequential sums, 1 thread) on the metric's own configuration n={a.n}, "
+                     f"m={a.m}: 3 iterations after {warm_f} warm-up = {ips_f:.4f} iters/sec (sampled at n={a.cpu_n} and scaled: "
+                     f"{scaled:.4f})")
+    return out
 
 
+# ======================================================================================== one rank
 class Env:
     """rank / world / torch.distributed plumbing (only rendezvous, barriers and a max over ranks)."""
 
-    def __init__(self, a):
+    def __init__(self, a, comm):
         self.a = a
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dev = self.local_rank if a.device < 0 else a.device
         self.dist = self.torch = None
-        if self.world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU
+        self.backend = a.pg_backend
+        if self.backend == "auto":
+            self.backend = "nccl" if comm == "rccl" else "gloo"
+        if self.world > 1 or "RANK" in os.environ:  # one rank per GPU
             import torch
             import torch.distributed as dist
 
             self.torch, self.dist = torch, dist
             torch.cuda.set_device(self.dev)
-            if a.pg_backend == "nccl":
+            if self.backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.dev))
             else:
-                dist.init_process_group(a.pg_backend)
+                dist.init_process_group(self.backend)
 
     def _tensor(self, v):
-        return self.torch.tensor([v], dtype=self.torch.float64, device="cuda" if self.a.pg_backend == "nccl" else "cpu")
+        return self.torch.tensor([v], dtype=self.torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
 
     def barrier(self, ctx=None):
         if ctx is not None:
@@ -149,14 +231,14 @@ def make_context(env, kind):
     ok, ctx = 1.0, None
     try:
         ctx = sharded_context(a.n, device=env.dev, kind=kind)
-        if kind == "p2p":  # known-answer reductions through the real code path before trusting it
-            tri = env.world * (env.world + 1) / 2.0
-            for it in range(16):
-                ctx.set_scalars(200, [float((env.rank + 1) * (it + 1)), float(env.rank == it % env.world),
-                                      -0.5 * (env.rank + 1)])
-                ctx.check(ctx._L.lbfgs_hip_scalars_allreduce(ctx._h, 200, 3))
-                if list(ctx.scalars(200, 3)) != [tri * (it + 1), 1.0, -0.5 * tri]:
-                    ok = 0.0
+        # known-answer reductions through the real code path before trusting it
+        tri = env.world * (env.world + 1) / 2.0
+        for it in range(16):
+            ctx.set_scalars(200, [float((env.rank + 1) * (it + 1)), float(env.rank == it % env.world),
+                                  -0.5 * (env.rank + 1)])
+            ctx.check(ctx._L.lbfgs_hip_scalars_allreduce(ctx._h, 200, 3))
+            if list(ctx.scalars(200, 3)) != [tri * (it + 1), 1.0, -0.5 * tri]:
+                ok = 0.0
         # ... and a reduction closed INSIDE a streaming kernel (p2p: by its last workgroup; rccl: on-stream after it):
         # sum over ranks of n_local * (rank+1)^2, exact in f64 in any summation order
         from rust_lbfgs_amd.dist import shard_range
@@ -184,9 +266,10 @@ def make_context(env, kind):
     return ctx, kind
 
 
-def measure(env, ctx, label, vector_free=False):
-    """W warm-up steps, then exactly K timed steps between barriers; max over ranks.  Every rank executes the
-    same barriers even if its own run failed, so a failure can never leave a peer waiting."""
+def measure(env, ctx, label, vector_free=False, repeats=1):
+    """`repeats` times: a fresh state, W warm-up steps (history full), then exactly K timed steps between barriers;
+    max over ranks.  Every rank executes the same barriers and collectives even if its own run failed, so a failure
+    can never leave a peer waiting."""
     import numpy as np
 
     import rust_lbfgs_amd as R
@@ -200,9 +283,13 @@ def measure(env, ctx, label, vector_free=False):
         builder = builder.with_vector_free(True)
     x0 = np.zeros(ctx.n_local)
     hold = {"state": None, "restarts": 0}
-    ok = 1.0
-    ncalls = 0
     prefill = max(0, a.m + 2 - a.warmup)  # history must be full (bound = m) before anything is timed
+
+    def fresh():
+        if hold["state"] is not None:
+            hold["state"].close()
+            hold["state"] = None
+        hold["state"] = builder.build(x0, objectives.Quadratic(fuse_line_eval=a.line_eval), ctx=ctx)
 
     def step():
         try:
@@ -211,37 +298,42 @@ def measure(env, ctx, label, vector_free=False):
             if e.code <= -100:
                 raise  # backend / communicator failure
             # converged to rounding error (the line search cannot make progress): start over
-            hold["state"].close()
-            hold["state"] = builder.build(x0, objectives.Quadratic(fuse_line_eval=a.line_eval), ctx=ctx)
+            fresh()
             hold["restarts"] += 1
             return hold["state"].propagate()
 
-    try:
-        hold["state"] = builder.build(x0, objectives.Quadratic(fuse_line_eval=a.line_eval), ctx=ctx)
-        for _ in range(prefill + a.warmup):
-            step()
-        if not a.no_prof:
-            ctx.prof_enable(True)
-            ctx.prof_reset()
-            ctx.prof_enable(False)
-    except R.LbfgsError as e:
-        print(f"[bench] rank {env.rank}: {label} failed in warm-up: {e}", file=sys.stderr)
-        ok = 0.0
-    env.barrier(ctx)
-    t0 = time.perf_counter()
-    try:
-        if ok:
-            for i in range(a.steps):
-                if not a.no_prof:
-                    ctx.prof_enable(i % max(1, a.prof_every) == 0)
-                ncalls += step().ncall
-    except R.LbfgsError as e:
-        print(f"[bench] rank {env.rank}: {label} failed in the timed region: {e}", file=sys.stderr)
-        ok = 0.0
-    env.barrier(ctx)
-    dt = time.perf_counter() - t0
-    dt = env.reduce(dt, "MAX")
-    ok = env.reduce(ok, "MIN")
+    ok = 1.0
+    dts, ncalls = [], 0
+    for rep in range(max(1, repeats)):
+        try:
+            if ok:
+                fresh()
+                for _ in range(prefill + a.warmup):
+                    step()
+                if not a.no_prof and rep == 0:
+                    ctx.prof_enable(True)
+                    ctx.prof_reset()
+                    ctx.prof_enable(False)
+        except R.LbfgsError as e:
+            print(f"[bench] rank {env.rank}: {label} failed in warm-up: {e}", file=sys.stderr)
+            ok = 0.0
+        env.barrier(ctx)
+        t0 = time.perf_counter()
+        try:
+            if ok:
+                for i in range(a.steps):
+                    if not a.no_prof:
+                        ctx.prof_enable(i % max(1, a.prof_every) == 0)
+                    ncalls += step().ncall
+        except R.LbfgsError as e:
+            print(f"[bench] rank {env.rank}: {label} failed in the timed region: {e}", file=sys.stderr)
+            ok = 0.0
+        env.barrier(ctx)
+        dt = time.perf_counter() - t0
+        dts.append(env.reduce(dt, "MAX"))
+        ok = env.reduce(ok, "MIN")
+        if ok != 1.0:
+            break
     res = None
     if ok == 1.0:
         ctx.prof_enable(False)
@@ -258,30 +350,36 @@ def measure(env, ctx, label, vector_free=False):
                 ach = 32.0 * n_local / (avg_ms * 1e-3) / 1e9  # 3 reads + 1 write of f64 per element
                 roof.update(achieved=ach, frac=ach / HBM_PEAK_GBPS, kernel="stream_kernel<OpTwoLoopStep<*,false,0>>",
                             launches=ns, avg_ms=avg_ms, bytes_per_launch=32 * n_local)
-                # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be collected from inside)
+                # HBM bytes per launch: rocprofv3 PMC counters cannot be collected from inside this process; the
+                # figure is taken from the committed counter passes of THIS command (tools/profile_round.sh) when
+                # they were made at this shard size, and the record names them -- otherwise the field stays null
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
                     if pm["n_local"] == n_local:
                         roof["traffic"] = pm["traffic_bytes_per_launch"] / 1e9
-                        roof["traffic_unit"] = "GB per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_bench_n1e8_m10.md)"
+                        roof["traffic_unit"] = "GB per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)"
+                        roof["traffic_source"] = pm.get("_source")
                 except Exception:  # noqa: BLE001
                     pass
             if nt:
                 t_tl = ms_all / nt
                 # 8*b passes of 8 bytes is the fused minimum that respects the dot->axpy dependency;
-                # the first numerator s.(-g) now comes out of the history-update kernel, so the exact recursion
+                # the first numerator s.(-g) comes out of the history-update kernel, so the exact recursion
                 # is charged 8*b - 2 passes (it actually moves 8*b - 1: the last step re-reads g for the next g.d)
                 passes = (4 * a.m + 3) if vector_free else (8 * a.m - 2)
                 gbps = 8.0 * passes * n_local / (t_tl * 1e-3) / 1e9
                 roof.update(two_loop={"ms": t_tl, "algorithmic_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS,
                                       "bytes": 8 * passes * n_local, "passes": passes, "calls": nt,
                                       "note": "per GPU: this rank's shard, incl. the all-reduces inside the recursion"})
-            sampled = max(nt, 1)  # steps whose kernels were timed (every --prof-every-th step of the timed region)
+            sampled = max(nt, 1)  # steps whose kernels were timed (every --prof-every-th step of the timed regions)
             roof["per_iteration_ms"] = {
                 "two_loop": ms_all / sampled, "history_update": ms_upd / sampled, "line_eval": ms_eval / sampled,
                 "allreduce": ms_comm / sampled, "allreduce_launches": nc / sampled, "sampled_steps": nt}
-        res = dict(label=label, value=a.steps / dt, ms_per_step=dt / a.steps * 1e3, roofline=roof, n_local=n_local,
-                   prefill=prefill, trials=ncalls / max(a.steps, 1), restarts=hold["restarts"])
+        srt = sorted(dts)
+        med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+        res = dict(label=label, value=a.steps / med, ms_per_step=med / a.steps * 1e3, roofline=roof, n_local=n_local,
+                   prefill=prefill, trials=ncalls / max(a.steps * len(dts), 1), restarts=hold["restarts"],
+                   repeats=[round(a.steps / d, 3) for d in dts], best=a.steps / srt[0], timed_s=sum(dts))
     if hold["state"] is not None:
         try:
             hold["state"].close()
@@ -317,28 +415,59 @@ def calibrate(ctx, reps=20):
         v.free()
 
 
-def main():
-    a = parse()
+def compose(a, world, results, ext, legs=None):
+    """The one JSON line: the best communicator as `value`, everything measured in `config`."""
+    best = max(results, key=lambda r: r["value"])
+    cfg = {"workload": f"hashed diagonal quadratic (cond 1e3), n={a.n}, m={a.m}, MoreThuente, crate defaults, "
+                       f"x/g/s/y sharded contiguously over {world} GPU(s)",
+           "n": a.n, "m": a.m, "n_local_rank0": best["n_local"], "prefill_iters": best["prefill"],
+           "line_search_trials_per_step": best["trials"], "restarts": best["restarts"],
+           "repeats": len(best["repeats"]), "repeats_iters_per_sec": best["repeats"],
+           "best_repeat_iters_per_sec": round(best["best"], 3), "timed_seconds": round(best["timed_s"], 3),
+           "value_is": "median over the repeats of K steps / (max over ranks of the K-step wall time)",
+           "allreduce": best["label"],
+           "allreduce_measured_iters_per_sec": {r["label"]: round(r["value"], 3) for r in results},
+           "extension_vector_free_two_loop": ext}
+    if legs is not None:
+        cfg["legs"] = legs
+    return {
+        "metric": "L-BFGS iters/sec (two-loop HBM GB/s in roofline) at n=1e8, m=10",
+        "value": best["value"],
+        "unit": "iters/sec",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": best["ms_per_step"],
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": cfg,
+        "roofline": best["roofline"],
+    }
+
+
+def worker_main(a):
+    """One rank: measures ONE communicator (N = 1: none) and, on rank 0, prints the line."""
     # stdout carries exactly ONE JSON line: RCCL, gloo and friends print banners to fd 1, so park it on stderr
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    env = Env(a)
-    if env.world != a.gpus:
-        if env.world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        a.gpus = env.world
+    comm = a.comm
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env > 1 and comm == "auto":
+        comm = "p2p"
+    env = Env(a, comm)
+    a.gpus = env.world
 
     import rust_lbfgs_amd  # noqa: F401  (fails loudly if the HIP extension is not built)
 
-    kinds = ["rccl", "p2p"] if (env.world > 1 and a.comm == "auto") else [a.comm if env.world > 1 else "none"]
     results, ext = [], {}
-    for kind in kinds:
-        ctx, label = make_context(env, kind)
-        if ctx is None:
-            continue
-        r = measure(env, ctx, label)
+    ctx, label = make_context(env, comm if env.world > 1 else "none")
+    if ctx is not None:
+        r = measure(env, ctx, label, repeats=a.repeats)
         if r is not None:
             if r["roofline"].get("achieved"):
                 try:  # both denominators: the spec peak (frac) and what a plain copy achieves on this box
@@ -352,46 +481,196 @@ def main():
             if not a.no_vector_free and a.m <= 10:
                 # EXTENSION, reported beside the headline, never as `value`: the same iteration with the
                 # two-loop carried out in Gram-coefficient space (4m+3 passes, 2 all-reduces)
-                rv = measure(env, ctx, label + "+vector_free", vector_free=True)
+                rv = measure(env, ctx, label + "+vector_free", vector_free=True, repeats=min(a.repeats, 3))
                 if rv is not None:
                     tl = rv["roofline"].get("two_loop", {})
                     ext[label] = {"iters_per_sec": round(rv["value"], 3), "two_loop_ms": tl.get("ms"),
-                                  "two_loop_passes": 4 * a.m + 3}
+                                  "two_loop_passes": 4 * a.m + 3, "repeats_iters_per_sec": rv["repeats"]}
         ctx.close()
 
     out = None
+    rc = 0
     if env.rank == 0:
         if not results:
-            sys.exit("bench.py: no communicator produced a result")
-        best = max(results, key=lambda r: r["value"])
-        out = {
-            "metric": "L-BFGS iters/sec (two-loop HBM GB/s in roofline) at n=1e8, m=10",
-            "value": best["value"],
-            "unit": "iters/sec",
-            "n_gpus": env.world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": best["ms_per_step"],
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"hashed diagonal quadratic (cond 1e3), n={a.n}, m={a.m}, MoreThuente, crate defaults, "
-                                   f"x/g/s/y sharded contiguously over {env.world} GPU(s)",
-                       "n": a.n, "m": a.m, "n_local_rank0": best["n_local"], "prefill_iters": best["prefill"],
-                       "line_search_trials_per_step": best["trials"], "restarts": best["restarts"],
-                       "allreduce": best["label"],
-                       "allreduce_measured_iters_per_sec": {r["label"]: round(r["value"], 3) for r in results},
-                       "extension_vector_free_two_loop": ext},
-            "roofline": best["roofline"],
-        }
-        if env.world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.m, a.n)
+            print("bench.py: the communicator produced no result", file=sys.stderr)
+            rc = 3
+        else:
+            out = compose(a, env.world, results, ext)
+            if env.world == 1 and not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(a)
     env.finish()
     if out is not None:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    return rc
+
+
+# ======================================================================================== supervisor (N > 1)
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def passthrough(a, leg):
+    args = ["--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup), "--dim", str(a.n), "--hist",
+            str(a.m), "--repeats", str(a.repeats), "--prof-every", str(a.prof_every), "--line-eval", str(a.line_eval),
+            "--pg-backend", a.pg_backend, "--comm", leg, "--no-cpu-baseline", "--_rank-mode"]
+    if a.no_prof:
+        args.append("--no-prof")
+    if a.no_vector_free:
+        args.append("--no-vector-free")
+    if a.grid:
+        args += ["--grid", str(a.grid)]
+    if a.device >= 0:
+        args += ["--device", str(a.device)]
+    return args
+
+
+def run_child(cmd, env, timeout):
+    """-> (status, stdout).  The child gets its own process group, so a hung leg is killed with all its descendants
+    (torch.distributed.run's workers included); never a re-exec of this process."""
+    import signal
+
+    p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=None, text=True, start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=timeout)
+        return ("ok" if p.returncode == 0 else f"exit code {p.returncode}"), out
+    except subprocess.TimeoutExpired:
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(p.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                p.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        try:
+            out, _ = p.communicate(timeout=5)
+        except Exception:  # noqa: BLE001
+            out = ""
+        return f"timed out after {timeout:.0f} s (killed)", out or ""
+
+
+def last_json(text):
+    for ln in reversed((text or "").splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{"):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                continue
+    return None
+
+
+def supervisor_main(a):
+    """N > 1.  This process never touches a GPU: it runs one child job per communicator leg under a timeout."""
+    # stdout carries exactly ONE JSON line (gloo prints connection banners to fd 1): park it on stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    under_launcher = "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ["WORLD_SIZE"]) if under_launcher else a.gpus
+    a.gpus = world
+    dist = None
+    if under_launcher:  # the ranks' supervisors coordinate over gloo (CPU only)
+        import datetime
+
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=a.leg_timeout + 120))
+    base_env = dict(os.environ)
+    base_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
+    base_env.setdefault("GLOO_SOCKET_IFNAME", "lo")         # one node: never depend on the hostname resolving
+    legs = ["p2p", "rccl"] if a.comm == "auto" else [a.comm]
+    if os.environ.get("LBFGS_BENCH_LEGS"):  # testing: e.g. "hang,p2p" (a leg that never returns)
+        legs = os.environ["LBFGS_BENCH_LEGS"].split(",")
+    report, lines = {}, []
+    tried_callback = False
+    i = 0
+    while i < len(legs):
+        leg = legs[i]
+        i += 1
+        t0 = time.perf_counter()
+        if leg == "hang":  # test hook: a child that never prints and never exits
+            cmd_tail, child = None, [sys.executable, "-c", "import time; time.sleep(100000)"]
+        else:
+            # (LBFGS_BENCH_WORKER: the CPU suite runs the rank processes on the test double of the C-ABI)
+            cmd_tail = [os.environ.get("LBFGS_BENCH_WORKER") or os.path.join(ROOT, "bench.py")] + passthrough(a, leg)
+            child = None
+        if under_launcher:
+            port = [free_port() if rank == 0 else 0]
+            dist.broadcast_object_list(port, src=0)
+            env = dict(base_env, MASTER_PORT=str(port[0]))
+            for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
+                      "TORCHELASTIC_USE_AGENT_STORE"):
+                env.pop(k, None)  # the child does its own env:// rendezvous on the fresh port
+            cmd = child or [sys.executable] + cmd_tail
+        else:
+            env = base_env
+            cmd = child or [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                            "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + cmd_tail
+        status, out = run_child(cmd, env, a.leg_timeout)
+        if under_launcher:  # a leg counts only if every rank's child ended well
+            all_status = [None] * world
+            dist.all_gather_object(all_status, status)
+            bad = [f"rank {r}: {s}" for r, s in enumerate(all_status) if s != "ok"]
+            if bad:
+                status = "; ".join(bad)
+        j = last_json(out) if (rank == 0 and status == "ok") else None
+        if rank == 0:
+            if status == "ok" and j is None:
+                status = "no JSON line"
+            report[leg] = {"status": status, "seconds": round(time.perf_counter() - t0, 1),
+                           "iters_per_sec": round(j["value"], 3) if j else None}
+            if j:
+                lines.append((leg, j))
+            print(f"[bench] leg {leg}: {report[leg]}", file=sys.stderr)
+        if i == len(legs) and a.comm == "auto" and not tried_callback:
+            # last resort: the host-staged all-reduce through gloo, only if nothing has produced a result
+            have = [len(lines)]
+            if under_launcher:
+                dist.broadcast_object_list(have, src=0)
+            if have[0] == 0:
+                legs.append("callback")
+            tried_callback = True
+    rc = 0
+    if rank == 0:
+        if not lines:
+            print("bench.py: no communicator leg produced a result: " + json.dumps(report), file=sys.stderr)
+            rc = 1
+        else:
+            leg, best = max(lines, key=lambda t: t[1]["value"])
+            best["config"]["legs"] = report
+            best["config"]["allreduce_measured_iters_per_sec"] = {lg: round(j["value"], 3) for lg, j in lines}
+            ext = {}
+            for lg, j in lines:
+                ext.update(j["config"].get("extension_vector_free_two_loop") or {})
+            best["config"]["extension_vector_free_two_loop"] = ext
+            best["config"]["launch"] = ("torch.distributed.run ranks as supervisors, one child rank each per leg"
+                                        if under_launcher else "self-launched: one torch.distributed.run child per leg")
+            os.write(real_stdout, (json.dumps(best) + "\n").encode())
+    if dist is not None:
+        ok = [rc]
+        dist.broadcast_object_list(ok, src=0)
+        rc = ok[0]
+        dist.barrier()
+        dist.destroy_process_group()
+    return rc
+
+
+def main():
+    a = parse()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.rank_mode or (a.gpus <= 1 and world_env <= 1):
+        return worker_main(a)
+    return supervisor_main(a)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

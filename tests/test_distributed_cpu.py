@@ -222,3 +222,52 @@ def test_three_ranks_uneven_shards(tmp_path):
             assert abs(a - b) <= 1e-9 * max(abs(b), 1e-6)
     x = np.concatenate([np.array(o["x"]) for o in outs])
     assert np.max(np.abs(x - ref_x)) <= 1e-9 * max(np.max(np.abs(ref_x)), 1e-12)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# bench.py's N > 1 supervisor: rank processes run on the test double (tests/support/bench_on_mock.py)
+# ------------------------------------------------------------------------------------------------------------
+def _run_bench(extra_args, launcher, legs=None, timeout=300):
+    env = dict(os.environ, LBFGS_BENCH_WORKER=os.path.join(ROOT, "tests", "support", "bench_on_mock.py"),
+               OMP_NUM_THREADS="1")
+    if legs:
+        env["LBFGS_BENCH_LEGS"] = legs
+    args = ["--gpus", "2", "--steps", "4", "--warmup", "12", "--dim", "3000", "--hist", "5", "--repeats", "2",
+            "--no-vector-free"] + extra_args
+    if launcher:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("launcher", [False, True], ids=["plain_python", "torch_distributed_run"])
+def test_bench_supervisor_two_ranks(launcher):
+    """`python bench.py --gpus 2` and the torch.distributed.run form both end in exactly ONE JSON line."""
+    p = _run_bench(["--comm", "callback"], launcher)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["warmup"] == 12 and j["value"] > 0 and j["scaling"] == "strong"
+    assert j["config"]["legs"]["callback"]["status"] == "ok" and j["config"]["allreduce"] == "callback"
+    assert j["config"]["repeats"] == 2 and len(j["config"]["repeats_iters_per_sec"]) == 2
+    assert j["config"]["n_local_rank0"] == 1536  # shard_range(3000, 0, 2)
+
+
+@pytest.mark.parametrize("launcher", [False, True], ids=["plain_python", "torch_distributed_run"])
+def test_bench_supervisor_survives_a_hung_and_a_failed_leg(launcher):
+    """A leg that never returns is killed at --leg-timeout, a leg whose communicator does not exist (the test double has
+    no RCCL) fails, and the run still prints the line of the leg that worked and exits 0."""
+    p = _run_bench(["--leg-timeout", "15"], launcher, legs="hang,rccl,callback")
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    legs = json.loads(lines[0])["config"]["legs"]
+    assert "timed out" in legs["hang"]["status"] and legs["rccl"]["status"] != "ok" and legs["callback"]["status"] == "ok"
+
+
+def test_bench_supervisor_reports_failure_when_no_leg_works():
+    p = _run_bench(["--leg-timeout", "60", "--comm", "rccl"], False)  # the test double has no RCCL; no fallback when a leg is forced
+    assert p.returncode != 0 and not p.stdout.strip()

@@ -91,10 +91,14 @@ def test_three_processes_one_gpu_with_an_empty_shard(kind, tmp_path, monkeypatch
             assert abs(a - b) <= 1e-9 * max(abs(b), 1e-6)
 
 
-@pytest.mark.parametrize("world,kind", [(1, "auto"), (3, "callback"), (2, "p2p")])
-def test_bench_contract_line(world, kind, tmp_path):
+@pytest.mark.parametrize("world,launch,kind", [(1, "plain", "auto"), (2, "plain", "auto"), (3, "torchrun", "callback"),
+                                               (2, "torchrun", "p2p")])
+def test_bench_contract_line(world, launch, kind, tmp_path):
     """bench.py end to end at a tiny size: exactly ONE JSON line on stdout with the contract's keys, also when a
-    rank holds an EMPTY shard (world 3, n = 1000) -- every rank must take the same collective decisions."""
+    rank holds an EMPTY shard (world 3, n = 1000) -- every rank must take the same collective decisions.  N > 1 is
+    started BOTH ways: plain `python bench.py --gpus 2` (the supervisor launches its own ranks; on this one-GPU box
+    the p2p leg works and the rccl leg fails -- two ranks on one device -- and the line still comes) and through
+    torch.distributed.run (every rank a supervisor)."""
     if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
         pytest.skip("needs the GPU")
     import json
@@ -103,14 +107,14 @@ def test_bench_contract_line(world, kind, tmp_path):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     args = ["--gpus", str(world), "--steps", "6", "--warmup", "12", "--dim", "1000" if world > 1 else "200000",
-            "--cpu-n", "20000", "--device", "0"]
-    if world == 1:
-        cmd = [sys.executable, "bench.py"] + args
+            "--cpu-n", "20000", "--device", "0", "--repeats", "3", "--leg-timeout", "150"]
+    if launch == "plain":
+        cmd = [sys.executable, "bench.py"] + args + ["--comm", kind]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
                "127.0.0.1", "--master-port", str(29600 + world), "bench.py"] + args + ["--comm", kind, "--pg-backend", "gloo"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=240)
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=500)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout
@@ -120,6 +124,7 @@ def test_bench_contract_line(world, kind, tmp_path):
         assert key in j, key
     assert j["n_gpus"] == world and j["steps"] == 6 and j["warmup"] == 12 and j["dtype"] == "f64"
     assert j["vs_baseline"] is None and j["value"] > 0 and "workload" in j["config"]
+    assert len(j["config"]["repeats_iters_per_sec"]) == 3
     r = j["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
@@ -127,6 +132,32 @@ def test_bench_contract_line(world, kind, tmp_path):
     if world == 1:
         c = j["cpu_baseline"]
         assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+        assert c["host_cores_total"] >= 1 and c["host_cpu"]
+    else:
+        legs = j["config"]["legs"]
+        assert any(v["status"] == "ok" for v in legs.values()), legs
+        if launch == "plain":
+            assert legs["p2p"]["status"] == "ok" and "rccl" in legs, legs
+
+
+def test_bench_survives_a_hung_leg(tmp_path):
+    """`python bench.py --gpus 2` with a first leg that never returns: killed at --leg-timeout, the p2p leg still
+    produces the line, exit code 0."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs the GPU")
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "12", "--dim", "1000", "--device", "0",
+           "--repeats", "2", "--leg-timeout", "60", "--no-vector-free"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LBFGS_BENCH_LEGS="hang,p2p")
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=400)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    legs = json.loads(lines[0])["config"]["legs"]
+    assert "timed out" in legs["hang"]["status"] and legs["p2p"]["status"] == "ok"
 
 
 TIMEOUT_WORKER = r'''
