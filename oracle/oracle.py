@@ -17,7 +17,9 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liblbfgs_oracle.so")
+# LBFGS_SANITIZE=1 (tests/test_sanitizers_cpu.py): the -fsanitize=address,undefined build of the same sources
+_LIB_NAME = "liblbfgs_oracle_asan.so" if os.environ.get("LBFGS_SANITIZE") == "1" else "liblbfgs_oracle.so"
+_LIB_PATH = os.path.join(_HERE, _LIB_NAME)
 
 LS_MORETHUENTE, LS_BT_ARMIJO, LS_BT_STRONGWOLFE, LS_BT_WOLFE = 0, 1, 2, 3
 
@@ -48,7 +50,7 @@ def build(force: bool = False) -> str:
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
     )
     if stale:
-        subprocess.run(["make", "-C", _HERE, "-B", "liblbfgs_oracle.so"], check=True, capture_output=True)
+        subprocess.run(["make", "-C", _HERE, "-B", _LIB_NAME], check=True, capture_output=True)
     return _LIB_PATH
 
 

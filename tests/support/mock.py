@@ -11,7 +11,9 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-LIB = os.path.join(HERE, "liblbfgs_solver_mock.so")
+# LBFGS_SANITIZE=1 (tests/test_sanitizers_cpu.py): everything below compiled with -fsanitize=address,undefined
+SANITIZE = os.environ.get("LBFGS_SANITIZE") == "1"
+LIB = os.path.join(HERE, "liblbfgs_solver_mock_asan.so" if SANITIZE else "liblbfgs_solver_mock.so")
 SRCS = [
     os.path.join(ROOT, "rust-lbfgs_amd", "csrc", "host", "solver.cpp"),
     os.path.join(HERE, "mock_lbfgs_hip.cpp"),
@@ -27,8 +29,10 @@ def build(force=False):
         return LIB
     objs = []
     flags = ["-O2", "-ffp-contract=off", "-fPIC", "-Wall"]
+    if SANITIZE:
+        flags = ["-O1", "-g", "-ffp-contract=off", "-fPIC", "-Wall", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
     for s in C_SRCS:
-        o = os.path.join(HERE, os.path.basename(s) + ".o")
+        o = os.path.join(HERE, os.path.basename(s) + (".asan.o" if SANITIZE else ".o"))
         subprocess.run(["gcc", "-std=c11", *flags, "-c", s, "-o", o], check=True, capture_output=True)
         objs.append(o)
     r = subprocess.run(["g++", "-std=c++17", *flags, "-shared", *SRCS, *objs, "-o", LIB, "-lm", "-Wl,-Bsymbolic"],
