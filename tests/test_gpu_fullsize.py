@@ -110,3 +110,73 @@ def test_streaming_hint_kernels_equal_plain_kernels(monkeypatch):
                 v.free()
     for a, b in zip(out["plain"], out["nt"]):
         assert np.array_equal(a, b)
+
+
+def test_owlqn_properties_at_config3_size():
+    """BASELINE.json config 3 at its own size (OWL-QN, L1 logistic, n = 1e7, m = 6, c = 0.5), through size-independent
+    properties on the device:
+      (a) the fused trial kernel (projected line step + evaluate + x1norm + pseudo-gradient + g.d in one pass,
+          line.rs:740-743 over core.rs:155-164,119-126) == the unfused sequence of the four primitives: x, g, pg
+          BITWISE, the five sums to 1e-12;
+      (b) two_loop_owlqn (orthant projection folded into the last step) == two_loop + constrain_direction
+          (orthantwise.rs:140-161): d bitwise, ||d||^2 and pg.d to 1e-12;
+      (c) bitwise determinism of both;
+      (d) coordinates whose |g| <= c at x = 0 stay exactly 0 (the reason config 3 exercises the projection)."""
+    n, m, c = int(os.environ.get("LBFGS_TEST_CONFIG3_N", 10_000_000)), 6, 0.5
+    q = objectives.Logistic()
+    with R.Context(n) as ctx:
+        hist = H.History(ctx, m)
+        xp, gp, pg, wp, d, tmp = (DeviceVec(ctx) for _ in range(6))
+        x1, g1, pg1, x2, g2, pg2 = (DeviceVec(ctx) for _ in range(6))
+        close = lambda a, b: abs(a - b) <= 1e-12 * max(abs(a), abs(b), 1e-300)
+        same = lambda u, v: (tmp.vecdiff(u, v), tmp.vec2norm())[1] == 0.0
+
+        def trial_pair(t):
+            H.objective_owlqn_line_eval(q, x1, xp, d, t, wp, g1, pg1, c, 0, n, 20)
+            fused = ctx.scalars(20, 5)                      # f, g.d, c*sum|x|, ||pg||^2, ||x||^2
+            H.line_step(x2, xp, d, t, wp, 0, n)
+            H.objective_eval(q, x2, g2, 30)
+            H.owlqn_post_eval(x2, g2, pg2, c, 0, n, 32)     # c*sum|x|, ||pg||^2, ||x||^2
+            g2.vecdot_slot(d, 31)
+            unfused = ctx.scalars(30, 5)
+            assert same(x1, x2) and same(g1, g2) and same(pg1, pg2)
+            for a, b in zip(fused, unfused):
+                assert close(a, b), (fused, unfused)
+            H.objective_owlqn_line_eval(q, x1, xp, d, t, wp, g1, pg1, c, 0, n, 20)  # (c) determinism
+            assert np.array_equal(ctx.scalars(20, 5), fused) and same(x1, x2) and same(pg1, pg2)
+            return fused
+
+        # round 1 from x = 0 (every coordinate takes the x == 0 branch of orthantwise.rs:95-110)
+        xp.fill(0.0)
+        H.objective_eval(q, xp, gp, 0)
+        H.owlqn_post_eval(xp, gp, pg, c, 0, n, 2)
+        H.orthant_select(wp, xp, pg)
+        d.vecncpy(pg)
+        s1 = trial_pair(0.75)
+        zeros = n - int(np.count_nonzero(x1.to_numpy()))
+        assert 0.3 * n < zeros < 0.37 * n                   # a_i <= 1 <=> |g_i(0)| <= c: a third of the coordinates
+        # round 2 from that point (mixed zero / non-zero coordinates: both branches, and real sign flips)
+        xp.veccpy(x1); gp.veccpy(g1); pg.veccpy(pg1)
+        H.orthant_select(wp, xp, pg)
+        d.vecncpy(pg)
+        s2 = trial_pair(1.0)
+        assert s2[0] + s2[2] < s1[0] + s1[2] < n * np.log(2.0)  # the objective f + c|x|_1 went down twice
+        # (b) the two forms of the OWL-QN two-loop
+        _fill_history(ctx, hist, tmp)
+        ys3 = hist.y(3).vecdot(hist.s(3))
+        ctx.set_scalars(7, [ys3, hist.y(3).vecdot(hist.y(3))])
+        ne1 = hist.two_loop_owlqn(x1, pg, 23, 3, 0, n, 7, 8, 13)
+        a = ctx.scalars(13, 4)                              # ||d||^2, pg.d before; ||d||^2, pg.d after the projection
+        ne2 = hist.two_loop(x2, pg, 23, 3, 7, 8, 40)
+        b_pre = ctx.scalars(40, 2)
+        H.constrain_direction(x2, pg, 0, n, 42)
+        b_post = ctx.scalars(42, 2)
+        assert ne1 == ne2 == 4 and same(x1, x2)
+        for u, v in zip(a, list(b_pre) + list(b_post)):
+            assert close(u, v), (a, b_pre, b_post)
+        assert a[2] > 0 and a[3] < 0                        # a descent direction survives the projection
+        hist.two_loop_owlqn(g1, pg, 23, 3, 0, n, 7, 8, 13)
+        assert same(g1, x1) and np.array_equal(ctx.scalars(13, 4), a)
+        hist.free()
+        for v in (xp, gp, pg, wp, d, tmp, x1, g1, pg1, x2, g2, pg2):
+            v.free()

@@ -1,8 +1,9 @@
 #!/bin/bash
 # The round's judged profile of `python bench.py` (n=1e8, m=10, one MI355X).  Run on the GPU box from the repo root:
 #     bash tools/profile_round.sh r01
-# Writes gpurun_out/prof_<tag>/{bench.json, stats/, pmc_fetch/, pmc_write/, summary.md}; copy summary.md, bench.json and
-# the kernel_stats csv into profiles/.  PMC counters are collected in their own passes, with --kernel-trace only.
+# Writes gpurun_out/prof_<tag>/{bench.json, kernel_stats.csv, pmc_*_counter_collection.csv, pmc_traffic.json, summary.md}:
+# copy them into profiles/ (pmc_traffic.json as profiles/pmc_traffic.json: bench.py's roofline.traffic reads it and names
+# the raw CSVs it was derived from).  PMC counters are collected in their own passes, with --kernel-trace only.
 set -e
 tag=${1:-r01}
 root=$(pwd)
@@ -13,8 +14,11 @@ python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --steps 30 --warmup 12 --no-cpu-baseline --no-vector-free > "$out/stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 4 --warmup 12 --no-cpu-baseline --no-prof --no-vector-free > "$out/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 4 --warmup 12 --no-cpu-baseline --no-prof --no-vector-free > "$out/pmc_write.log" 2>&1
-python3 tools/summarize_profile.py "$out/stats" "$out/pmc_fetch" "$out/pmc_write" 100000000 "$out/summary.md" > /dev/null
+python3 tools/summarize_profile.py "$out/stats" "$out/pmc_fetch" "$out/pmc_write" 100000000 "$out/summary.md" "$tag" > /dev/null
 cp "$out"/stats/*/*_kernel_stats.csv "$out/kernel_stats.csv"
+# the RAW counter rows behind roofline.traffic (one row per dispatch; a few hundred KB) are kept and committed
+cat "$out"/pmc_fetch/*/*_counter_collection.csv > "$out/pmc_fetch_counter_collection.csv"
+cat "$out"/pmc_write/*/*_counter_collection.csv > "$out/pmc_write_counter_collection.csv"
 # keep only the small artefacts (the traces are hundreds of MB)
 rm -rf "$out/stats" "$out/pmc_fetch" "$out/pmc_write"
 cat "$out/summary.md"; cut -c1-200 "$out/bench.json"

@@ -56,6 +56,7 @@ def pmc(dirname, counter):
 
 def main():
     stats_dir, fdir, wdir, n_local, out = sys.argv[1:6]
+    tag = sys.argv[6] if len(sys.argv) > 6 else "rXX"
     n_local = int(n_local)
     fetch = pmc(fdir, "FETCH_SIZE")
     write = pmc(wdir, "WRITE_SIZE")
@@ -86,6 +87,20 @@ def main():
                      f"{gbps / 80:.1f} | - | - | - |")
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
+    # the dominant kernel's measured HBM bytes per launch, for bench.py's roofline.traffic
+    import json
+    import os
+
+    dom = [k for k in fetch if re.search(r"OpTwoLoopStep<false, false, 0", k)]
+    if dom and dom[0] in write:
+        rd, wr = fetch[dom[0]] * 1024 * 2, write[dom[0]] * 1024
+        json.dump({"_source": f"profiles/{tag}_pmc_fetch_counter_collection.csv + profiles/{tag}_pmc_write_counter_collection.csv "
+                              "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python3 bench.py`, averaged over the "
+                              "dispatches of the kernel; FETCH_SIZE x2: gfx950 correction of MI355X_MICROARCH.md section HBM; KiB)",
+                   "kernel": "stream_kernel<OpTwoLoopStep<*,false,0>>", "n_local": n_local,
+                   "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
+                   "traffic_bytes_per_launch": round(rd + wr)},
+                  open(os.path.join(os.path.dirname(out), "pmc_traffic.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
