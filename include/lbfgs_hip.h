@@ -249,8 +249,13 @@ enum {
     LBFGS_HIP_OBJ_LOGISTIC = 2,   /* hashed separable logistic  (config 3, with OWL-QN)      */
     LBFGS_HIP_OBJ_ROSENBROCK = 3, /* src/lib.rs:79-94 default_evaluate (pairs must not straddle shards) */
     LBFGS_HIP_OBJ_LJ_ALLPAIRS = 4,  /* examples/lj.rs:20-64,113-118: exact all-pairs Lennard-Jones, x = 3*natoms; one rank */
-    LBFGS_HIP_OBJ_LJ_NEIGHBORS = 5  /* the same pair terms over a fixed neighbour table with a cutoff (shifted by v(rc)):
-                                       the substitute evaluator for BASELINE config 5 at 1e6 atoms; one rank */
+    LBFGS_HIP_OBJ_LJ_NEIGHBORS = 5, /* the same pair terms over a fixed, caller-built neighbour table with a cutoff
+                                       (shifted by v(rc)); the table is never rebuilt: valid only while it stays complete */
+    LBFGS_HIP_OBJ_LJ_CELLS = 6      /* E = sum_{i<j, r<rc} [v(r) - v(rc)] through a neighbour (Verlet) list that the LIBRARY
+                                       builds on the device from a cell list (radius cutoff + skin) and rebuilds whenever an
+                                       atom has moved more than skin/2 since the last build -- detected inside the
+                                       evaluation kernel, followed by rebuild + re-evaluation, so every result is the exact
+                                       cutoff sum at x: the evaluator of BASELINE config 5 at 1e6 atoms; one rank */
 };
 typedef struct lbfgs_hip_objective {
     int32_t kind;
@@ -259,10 +264,15 @@ typedef struct lbfgs_hip_objective {
     /* LJ_NEIGHBORS: ELL table int32[max_nbr][natoms] in DEVICE memory (column-major, -1 = empty), from
      * lbfgs_hip_device_buffer_create; cutoff rc */
     const void* nbr_index;
-    uint32_t max_nbr;
+    uint32_t max_nbr;   /* LJ_NEIGHBORS: rows of the table.  LJ_CELLS: capacity of an atom's list (rounded up to a multiple
+                           of 4; 0 = 128); an atom with more neighbours within cutoff + skin fails the evaluation */
     uint32_t _pad2;
     double cutoff;
+    double skin;        /* LJ_CELLS: list radius = cutoff + skin (> 0) */
 } lbfgs_hip_objective;
+/* LJ_CELLS bookkeeping of this context: list builds so far, evaluations (re-evaluations after a rebuild included),
+ * and the longest neighbour list of the latest build */
+int lbfgs_hip_lj_cells_stats(lbfgs_hip_ctx* ctx, uint64_t* rebuilds, uint64_t* evaluations, uint32_t* longest_list);
 /* page-locked host staging memory (hipHostMalloc): the host-closure bridge keeps x and g in such buffers so that the two
  * PCIe transfers per evaluation run at DMA speed instead of through pageable memory */
 int lbfgs_hip_host_buffer_create(lbfgs_hip_ctx* ctx, uint64_t bytes, void** out);

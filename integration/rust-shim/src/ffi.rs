@@ -72,6 +72,7 @@ pub struct lbfgs_hip_objective {
     pub max_nbr: u32,
     pub _pad2: u32,
     pub cutoff: f64,
+    pub skin: f64,
 }
 
 #[repr(C)]

@@ -202,6 +202,15 @@ typedef struct oracle_lj_nbr {
     double cutoff;
 } oracle_lj_nbr;
 double oracle_obj_lj_neighbors(void* user, const double* x, double* g, size_t n, int* failed);
+/* the truncated-and-shifted pair potential of the substitute evaluator with NO stored list:
+ *   E = sum_{i<j, r<rc} [v(r) - v(rc)],  g = dE/dx,
+ * found through a cell list that is rebuilt at EVERY call (cells of side >= rc), so the result depends on x alone.
+ * This is the rule the device's rebuildable Verlet list (LBFGS_HIP_OBJ_LJ_CELLS: cutoff + skin, rebuilt when an atom
+ * has moved more than skin/2) must reproduce at every point, whatever its rebuild history. */
+typedef struct oracle_lj_cells {
+    double cutoff;
+} oracle_lj_cells;
+double oracle_obj_lj_cells(void* user, const double* x, double* g, size_t n, int* failed);
 
 #ifdef __cplusplus
 }

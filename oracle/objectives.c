@@ -181,3 +181,97 @@ double oracle_obj_lj_neighbors(void* user, const double* x, double* g, size_t n,
     }
     return energy;
 }
+
+/* Cutoff + shift rule with a cell list rebuilt at every call (no Verlet skin: nothing is carried between calls).
+ * Per atom i the pair terms are accumulated over the 27 surrounding cells; every pair is seen from both ends, as in
+ * oracle_obj_lj_neighbors.  A non-finite coordinate makes the call fail (the closure's Err). */
+double oracle_obj_lj_cells(void* user, const double* x, double* g, size_t n, int* failed) {
+    const oracle_lj_cells* o = (const oracle_lj_cells*)user;
+    const size_t na = n / 3;
+    const double rc = o->cutoff, rc2 = rc * rc;
+    const double i6 = 1.0 / (rc2 * rc2 * rc2);
+    const double eshift = 4.0 * (i6 * i6 - i6);
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = 0; i < na; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const double v = x[3 * i + k];
+            if (!(v - v == 0.0)) { /* NaN or inf */
+                if (failed) *failed = 1;
+                return 0.0;
+            }
+            if (v < lo[k]) lo[k] = v;
+            if (v > hi[k]) hi[k] = v;
+        }
+    if (na == 0) return 0.0;
+    /* cells of side >= rc; at most ~2*na cells */
+    double side = rc;
+    size_t dim[3];
+    for (;;) {
+        double total = 1.0;
+        for (int k = 0; k < 3; ++k) {
+            dim[k] = (size_t)floor((hi[k] - lo[k]) / side) + 1;
+            total *= (double)dim[k];
+        }
+        if (total <= 2.0 * (double)na + 64.0) break;
+        side *= 1.26;
+    }
+    const size_t ncell = dim[0] * dim[1] * dim[2];
+    size_t* start = (size_t*)calloc(ncell + 1, sizeof(size_t));
+    size_t* cell = (size_t*)malloc(na * sizeof(size_t));
+    size_t* order = (size_t*)malloc(na * sizeof(size_t));
+    if (!start || !cell || !order) {
+        free(start); free(cell); free(order);
+        if (failed) *failed = 1;
+        return 0.0;
+    }
+    for (size_t i = 0; i < na; ++i) {
+        size_t c[3];
+        for (int k = 0; k < 3; ++k) {
+            c[k] = (size_t)floor((x[3 * i + k] - lo[k]) / side);
+            if (c[k] >= dim[k]) c[k] = dim[k] - 1;
+        }
+        cell[i] = (c[2] * dim[1] + c[1]) * dim[0] + c[0];
+        start[cell[i] + 1] += 1;
+    }
+    for (size_t c = 0; c < ncell; ++c) start[c + 1] += start[c];
+    {   /* counting sort, stable: atoms of a cell in ascending index order */
+        size_t* cur = (size_t*)malloc(ncell * sizeof(size_t));
+        if (!cur) { free(start); free(cell); free(order); if (failed) *failed = 1; return 0.0; }
+        for (size_t c = 0; c < ncell; ++c) cur[c] = start[c];
+        for (size_t i = 0; i < na; ++i) order[cur[cell[i]]++] = i;
+        free(cur);
+    }
+    double energy = 0.0;
+    for (size_t i = 0; i < na; ++i) {
+        const size_t cx = cell[i] % dim[0], cy = (cell[i] / dim[0]) % dim[1], cz = cell[i] / (dim[0] * dim[1]);
+        double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const long long ax = (long long)cx + dx, ay = (long long)cy + dy, az = (long long)cz + dz;
+                    if (ax < 0 || ay < 0 || az < 0 || ax >= (long long)dim[0] || ay >= (long long)dim[1] ||
+                        az >= (long long)dim[2])
+                        continue;
+                    const size_t c = ((size_t)az * dim[1] + (size_t)ay) * dim[0] + (size_t)ax;
+                    for (size_t t = start[c]; t < start[c + 1]; ++t) {
+                        const size_t j = order[t];
+                        if (j == i) continue;
+                        const double ddx = x[3 * i] - x[3 * j], ddy = x[3 * i + 1] - x[3 * j + 1],
+                                     ddz = x[3 * i + 2] - x[3 * j + 2];
+                        const double r2 = ddx * ddx + ddy * ddy + ddz * ddz;
+                        if (r2 < rc2) {
+                            const double inv2 = 1.0 / r2;
+                            const double s6 = inv2 * inv2 * inv2;
+                            e += 4.0 * (s6 * s6 - s6);                             /* pair_energy  lj.rs:22-25 */
+                            const double cc = 24.0 * (s6 - 2.0 * (s6 * s6)) * inv2; /* pair_gradient / r  lj.rs:28-32 */
+                            fx += cc * ddx; fy += cc * ddy; fz += cc * ddz;
+                            e -= eshift;
+                        }
+                    }
+                }
+        g[3 * i] = fx; g[3 * i + 1] = fy; g[3 * i + 2] = fz;
+        energy += 0.5 * e;
+    }
+    free(start); free(cell); free(order);
+    return energy;
+}

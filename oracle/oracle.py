@@ -267,6 +267,15 @@ def lj_neighbors(nbr_index, cutoff):
     return b
 
 
+class LjCells(C.Structure):
+    _fields_ = [("cutoff", C.c_double)]
+
+
+def lj_cells(cutoff):
+    """E = sum_{i<j, r<rc} [v(r) - v(rc)] through a cell list rebuilt at every call (a function of x alone)."""
+    return Builtin("oracle_obj_lj_cells", LjCells(float(cutoff)))
+
+
 def _resolve_eval(evaluate):
     """Return (callable pointer as c_void_p, user pointer, keepalive)."""
     L = lib()

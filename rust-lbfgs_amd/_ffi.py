@@ -23,7 +23,7 @@ HIP_ERR_ARG, HIP_ERR_HIP, HIP_ERR_COMM, HIP_ERR_NOMEM, HIP_ERR_NO_DEVICE = -101,
 LS_MORETHUENTE, LS_BT_ARMIJO, LS_BT_STRONGWOLFE, LS_BT_WOLFE = 0, 1, 2, 3
 EVAL_HOST, EVAL_DEVICE, EVAL_BUILTIN = 0, 1, 2
 COMM_NONE, COMM_RCCL, COMM_CALLBACK, COMM_P2P = 0, 1, 2, 3
-OBJ_QUADRATIC, OBJ_LOGISTIC, OBJ_ROSENBROCK, OBJ_LJ_ALLPAIRS, OBJ_LJ_NEIGHBORS = 1, 2, 3, 4, 5
+OBJ_QUADRATIC, OBJ_LOGISTIC, OBJ_ROSENBROCK, OBJ_LJ_ALLPAIRS, OBJ_LJ_NEIGHBORS, OBJ_LJ_CELLS = 1, 2, 3, 4, 5, 6
 (K_TWOLOOP_STEP, K_TWOLOOP_EDGE, K_UPDATE, K_LINE, K_EVAL, K_OWLQN, K_BLAS1, K_COMM, K_TWOLOOP_ALL) = range(9)
 VEC_X, VEC_GX, VEC_XP, VEC_GP, VEC_PG, VEC_WP, VEC_D = range(7)
 VEC_S0, VEC_Y0 = 100, 200
@@ -45,7 +45,8 @@ class Comm(C.Structure):
 
 class Objective(C.Structure):
     _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("seed_a", C.c_uint64), ("seed_b", C.c_uint64),
-                ("nbr_index", C.c_void_p), ("max_nbr", C.c_uint32), ("_pad2", C.c_uint32), ("cutoff", C.c_double)]
+                ("nbr_index", C.c_void_p), ("max_nbr", C.c_uint32), ("_pad2", C.c_uint32), ("cutoff", C.c_double),
+                ("skin", C.c_double)]
 
 
 class Param(C.Structure):
@@ -102,6 +103,7 @@ lbfgs_hip_two_loop lbfgs_hip_two_loop_from lbfgs_hip_two_loop_owlqn lbfgs_hip_tw
 lbfgs_hip_owlqn_post_eval lbfgs_hip_orthant_select lbfgs_hip_constrain_direction
 lbfgs_hip_objective_eval lbfgs_hip_objective_line_eval lbfgs_hip_objective_owlqn_line_eval
 lbfgs_hip_objective_is_elementwise lbfgs_hip_objective_line_probe lbfgs_hip_history_update_from_step
+lbfgs_hip_lj_cells_stats
 lbfgs_hip_device_buffer_create
 lbfgs_hip_device_buffer_destroy
 lbfgs_hip_host_buffer_create lbfgs_hip_host_buffer_destroy
@@ -177,6 +179,7 @@ def declare(L):
         "lbfgs_hip_objective_eval": (i, [C.POINTER(Objective), vp, vp, i]),
         "lbfgs_hip_objective_line_eval": (i, [C.POINTER(Objective), vp, vp, vp, dbl, vp, i]),
         "lbfgs_hip_objective_is_elementwise": (i, [C.POINTER(Objective)]),
+        "lbfgs_hip_lj_cells_stats": (i, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_uint32)]),
         "lbfgs_hip_objective_line_probe": (i, [C.POINTER(Objective), vp, vp, dbl, i]),
         "lbfgs_hip_history_update_from_step": (i, [vp, i, C.POINTER(Objective), vp, vp, vp, dbl, vp, vp, dbl, i, i]),
         "lbfgs_hip_objective_owlqn_line_eval": (i, [C.POINTER(Objective), vp, vp, vp, dbl, vp, vp, vp, dbl, u64, u64, i]),

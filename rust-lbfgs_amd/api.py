@@ -110,6 +110,12 @@ class Context:
     def sync(self):
         self.check(self._L.lbfgs_hip_sync(self._h))
 
+    def lj_cells_stats(self):
+        """LJ_CELLS bookkeeping: (list builds, evaluations incl. re-evaluations, longest list of the latest build)."""
+        r, e, m = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        self.check(self._L.lbfgs_hip_lj_cells_stats(self._h, C.byref(r), C.byref(e), C.byref(m)))
+        return r.value, e.value, m.value
+
     def set_grid(self, blocks):
         self.check(self._L.lbfgs_hip_set_grid(self._h, blocks))
 
@@ -181,10 +187,13 @@ class BuiltinObjective:
     fuse_line_eval: int = 1    # 0 / 1 / 2, see lbfgs_solver.h (bools accepted)
     nbr_index: object = None   # LJ_NEIGHBORS: int32 [max_nbr, natoms] host table (-1 = empty), uploaded per context
     cutoff: float = 0.0
+    skin: float = 0.0          # LJ_CELLS: list radius = cutoff + skin
+    max_nbr: int = 0           # LJ_CELLS: capacity of an atom's neighbour list (0 = the library's default, 128)
 
     def c_struct(self, ctx):
         """lbfgs_hip_objective for `ctx` (uploads the neighbour table once per context and keeps it alive)."""
-        o = _ffi.Objective(self.kind, 0, self.seed_a, self.seed_b, None, 0, 0, float(self.cutoff))
+        o = _ffi.Objective(self.kind, 0, self.seed_a, self.seed_b, None, int(self.max_nbr), 0, float(self.cutoff),
+                           float(self.skin))
         if self.nbr_index is not None:
             cache = ctx.__dict__.setdefault("_objective_tables", {})  # one upload per (context, objective)
             if id(self) not in cache:

@@ -105,6 +105,31 @@ struct ProfClass {
     double ms = 0.0;
 };
 
+// LJ_CELLS (lj.h): device buffers and bookkeeping of the rebuildable neighbour list of ONE context
+struct LjCells {
+    uint32_t natoms = 0, max_nbr = 0;
+    double cutoff = 0.0, skin = 0.0;
+    size_t ncap = 0;                 // cells the count / start / cursor arrays can hold
+    int32_t *nbr = nullptr, *cnt = nullptr, *cell_of = nullptr, *sorted = nullptr, *counts = nullptr, *starts = nullptr,
+            *cursor = nullptr;
+    double* xref = nullptr;          // positions at build time
+    double* bbox_part = nullptr;     // [LJ_BBOX_GRID][6]
+    unsigned int* overflow = nullptr;
+    double* host = nullptr;          // host-mapped: [0] = atoms outside their skin/2 sphere (written by the evaluation kernel)
+    double* host_dev = nullptr;
+    bool built = false;
+    uint64_t rebuilds = 0, evals = 0;
+    uint32_t longest = 0;
+    void release() {
+        void* ptrs[] = {nbr, cnt, cell_of, sorted, counts, starts, cursor, xref, bbox_part, overflow};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        if (host) (void)hipHostFree(host);
+        *this = LjCells();
+    }
+};
+constexpr int LJ_BBOX_GRID = 256;
+
 struct lbfgs_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -125,6 +150,7 @@ struct lbfgs_hip_ctx {
     unsigned int* ticket = nullptr;
     double* lj_scratch = nullptr;         // all-pairs LJ: per-j-range force slices (allocated on demand)
     size_t lj_scratch_bytes = 0;
+    struct LjCells* lj_cells = nullptr;   // LJ_CELLS: the rebuildable neighbour structure (allocated on demand)
     unsigned long long* gran = nullptr;   // tagged partial granules [MAX_RED][MAX_GRID][2] (stream.h)
     unsigned int red_epoch = 0;           // tag of the latest reducing launch (never 0)
     int grid_class[16] = {0};             // LBFGS_HIP_GRID_K<class>=N: grid override per kernel class (in-situ tuning)
@@ -440,20 +466,168 @@ int two_loop_step(lbfgs_hip_history* h, const double* src, const double* u, cons
 }  // namespace
 
 namespace {
+// ---- LJ_CELLS: (re)build the Verlet list of ctx->lj_cells from the positions x (lj.h) --------------------------------
+int lj_cells_prepare(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, uint32_t natoms) {
+    if (!(obj->cutoff > 0.0) || !(obj->skin > 0.0))
+        return fail(ctx, LBFGS_HIP_ERR_ARG, "LJ_CELLS needs cutoff > 0 and skin > 0");
+    uint32_t max_nbr = obj->max_nbr ? obj->max_nbr : 128u;
+    max_nbr = (max_nbr + 3u) & ~3u;
+    if (!ctx->lj_cells) ctx->lj_cells = new (std::nothrow) LjCells();
+    LjCells* lc = ctx->lj_cells;
+    if (!lc) return fail(ctx, LBFGS_HIP_ERR_NOMEM, "out of host memory");
+    if (lc->natoms == natoms && lc->max_nbr == max_nbr && lc->cutoff == obj->cutoff && lc->skin == obj->skin) return LBFGS_HIP_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t keep_rebuilds = lc->rebuilds, keep_evals = lc->evals;
+    lc->release();
+    lc->rebuilds = keep_rebuilds; lc->evals = keep_evals;
+    lc->natoms = natoms; lc->max_nbr = max_nbr; lc->cutoff = obj->cutoff; lc->skin = obj->skin;
+    lc->ncap = 2 * (size_t)natoms + 64;
+#define LJ_ALLOC(ptr, bytes)                                                                                     \
+    do {                                                                                                         \
+        hipError_t e_ = hipMalloc(&(ptr), (bytes));                                                              \
+        if (e_ != hipSuccess) {                                                                                  \
+            lc->release();                                                                                       \
+            return fail(ctx, LBFGS_HIP_ERR_NOMEM, "LJ_CELLS buffers (%zu bytes): %s", (size_t)(bytes), hipGetErrorString(e_)); \
+        }                                                                                                        \
+    } while (0)
+    const size_t na = natoms ? natoms : 1;
+    LJ_ALLOC(lc->nbr, (size_t)max_nbr * na * sizeof(int32_t));
+    LJ_ALLOC(lc->cnt, na * sizeof(int32_t));
+    LJ_ALLOC(lc->cell_of, na * sizeof(int32_t));
+    LJ_ALLOC(lc->sorted, na * sizeof(int32_t));
+    LJ_ALLOC(lc->counts, (lc->ncap + 1) * sizeof(int32_t));
+    LJ_ALLOC(lc->starts, (lc->ncap + 1) * sizeof(int32_t));
+    LJ_ALLOC(lc->cursor, (lc->ncap + 1) * sizeof(int32_t));
+    LJ_ALLOC(lc->xref, 3 * na * sizeof(double));
+    LJ_ALLOC(lc->bbox_part, (size_t)LJ_BBOX_GRID * 6 * sizeof(double));
+    LJ_ALLOC(lc->overflow, 64);
+#undef LJ_ALLOC
+    void* hm = nullptr;
+    if (hipHostMalloc(&hm, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        lc->release();
+        return fail(ctx, LBFGS_HIP_ERR_NOMEM, "LJ_CELLS host word");
+    }
+    memset(hm, 0, 64);
+    void* dv = nullptr;
+    if (hipHostGetDevicePointer(&dv, hm, 0) != hipSuccess) {
+        (void)hipHostFree(hm);
+        lc->release();
+        return fail(ctx, LBFGS_HIP_ERR_HIP, "LJ_CELLS host word: no device pointer");
+    }
+    lc->host = (double*)hm;
+    lc->host_dev = (double*)dv;
+    return LBFGS_HIP_OK;
+}
+
+int lj_cells_rebuild(lbfgs_hip_ctx* ctx, const double* x) {
+    LjCells* lc = ctx->lj_cells;
+    const uint32_t natoms = lc->natoms;
+    const double rl = lc->cutoff + lc->skin;
+    // 1. bounding box (per-workgroup partials, reduced here: a rebuild synchronises anyway)
+    const int bgrid = (int)std::min<uint32_t>(LJ_BBOX_GRID, std::max(1u, (natoms + BLOCK - 1) / BLOCK));
+    hipLaunchKernelGGL(lj_bbox_kernel, dim3(bgrid), dim3(BLOCK), 0, ctx->stream, x, natoms, lc->bbox_part);
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<double> part((size_t)bgrid * 6);
+    HIP_TRY(ctx, hipMemcpyAsync(part.data(), lc->bbox_part, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int b = 0; b < bgrid; ++b)
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::fmin(lo[k], part[(size_t)b * 6 + k]);
+            hi[k] = std::fmax(hi[k], part[(size_t)b * 6 + 3 + k]);
+        }
+    for (int k = 0; k < 3; ++k)
+        if (!std::isfinite(lo[k]) || !std::isfinite(hi[k]))
+            return fail(ctx, LBFGS_HIP_ERR_ARG, "LJ_CELLS: a coordinate is not finite");
+    // 2. cells of side >= rl, as many as fit the arrays
+    LjGrid gr{};
+    double side = rl;
+    for (;;) {
+        double dims[3], total = 1.0;
+        for (int k = 0; k < 3; ++k) {
+            dims[k] = std::floor((hi[k] - lo[k]) / side) + 1.0;
+            total *= dims[k];
+        }
+        if (total <= (double)lc->ncap && dims[0] < 2.0e9 && dims[1] < 2.0e9 && dims[2] < 2.0e9) {
+            gr.nx = (int)dims[0]; gr.ny = (int)dims[1]; gr.nz = (int)dims[2];
+            break;
+        }
+        side *= 1.26;  // 2x the cell volume
+    }
+    gr.ox = lo[0]; gr.oy = lo[1]; gr.oz = lo[2];
+    gr.inv_side = 1.0 / side;
+    const uint32_t ncells = (uint32_t)gr.nx * (uint32_t)gr.ny * (uint32_t)gr.nz;
+    // 3. count -> scan -> fill -> sort -> list
+    const int agrid = (int)std::min<uint32_t>(4096u, std::max(1u, (natoms + BLOCK - 1) / BLOCK));
+    const int cgrid = (int)std::min<uint32_t>(4096u, std::max(1u, (ncells + BLOCK - 1) / BLOCK));
+    HIP_TRY(ctx, hipMemsetAsync(lc->counts, 0, ((size_t)ncells + 1) * sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(lc->overflow, 0, sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(lj_cells_count_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, x, natoms, gr, lc->cell_of, lc->counts);
+    hipLaunchKernelGGL(lj_cells_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, lc->counts, ncells, lc->starts, lc->cursor);
+    hipLaunchKernelGGL(lj_cells_fill_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, lc->cell_of, natoms, lc->cursor, lc->sorted);
+    hipLaunchKernelGGL(lj_cells_sort_kernel, dim3(cgrid), dim3(BLOCK), 0, ctx->stream, lc->starts, ncells, lc->sorted);
+    hipLaunchKernelGGL(lj_cells_build_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, x, natoms, gr, lc->cell_of, lc->starts,
+                       lc->sorted, rl * rl, lc->max_nbr, lc->nbr, lc->cnt, lc->xref, lc->overflow);
+    HIP_TRY(ctx, hipGetLastError());
+    unsigned int over = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&over, lc->overflow, sizeof(over), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (over)
+        return fail(ctx, LBFGS_HIP_ERR_ARG, "LJ_CELLS: an atom has %u neighbours within cutoff + skin = %g, the list holds %u "
+                    "(raise lbfgs_hip_objective.max_nbr)", over, rl, lc->max_nbr);
+    lc->built = true;
+    lc->rebuilds += 1;
+    return LBFGS_HIP_OK;
+}
+
+int lj_cells_eval(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, const lbfgs_hip_vec* x, lbfgs_hip_vec* g, double* out,
+                  uint32_t natoms) {
+    int rc = lj_cells_prepare(ctx, obj, natoms);
+    if (rc != LBFGS_HIP_OK) return rc;
+    LjCells* lc = ctx->lj_cells;
+    if (!lc->built && (rc = lj_cells_rebuild(ctx, x->p)) != LBFGS_HIP_OK) return rc;
+    const double rc2 = obj->cutoff * obj->cutoff;
+    const double i6 = 1.0 / (rc2 * rc2 * rc2);
+    const double eshift = 4.0 * (i6 * i6 - i6);
+    const double half_skin2 = 0.25 * obj->skin * obj->skin;
+    const uint32_t want = (natoms + BLOCK - 1) / BLOCK;
+    const uint32_t grid = std::max(1u, std::min(want, (uint32_t)MAX_GRID));
+    for (int attempt = 0;; ++attempt) {
+        RedCtl red{};
+        if ((rc = fill_handoff(ctx, red)) != LBFGS_HIP_OK) return rc;
+        red.out[0] = out;
+        red.out[1] = lc->host_dev;  // the "moved too far" count goes straight to host-mapped memory
+        hipLaunchKernelGGL(lj_cells_eval_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, x->p, g->p, lc->nbr, lc->cnt, lc->xref,
+                           natoms, rc2, eshift, half_skin2, red);
+        HIP_TRY(ctx, hipGetLastError());
+        lc->evals += 1;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const double moved = *(volatile double*)lc->host;
+        if (moved == 0.0) return LBFGS_HIP_OK;
+        if (attempt == 1) return fail(ctx, LBFGS_HIP_ERR_HIP, "LJ_CELLS: the list is stale right after a rebuild");
+        // some atom left its skin/2 sphere (or x holds a NaN: the rebuild reports that): rebuild at x, evaluate again
+        if ((rc = lj_cells_rebuild(ctx, x->p)) != LBFGS_HIP_OK) return rc;
+    }
+}
+
 // Lennard-Jones objectives (lj.h): x holds 3*natoms coordinates of ONE rank
 int lj_eval(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, const lbfgs_hip_vec* x, lbfgs_hip_vec* g, double* out) {
     if (ctx->shard.world != 1) return fail(ctx, LBFGS_HIP_ERR_ARG, "the LJ objectives need all atoms on one rank");
     const uint64_t n = ctx->shard.n_local;
     if (n % 3 != 0 || n / 3 > 0x7fffffffULL) return fail(ctx, LBFGS_HIP_ERR_ARG, "LJ needs n = 3*natoms");
     const uint32_t natoms = (uint32_t)(n / 3);
+    const long idx = out - ctx->board;
+    if (idx >= 0 && idx < LBFGS_HIP_BOARD_SLOTS + 2) ctx->mirror_valid[idx] = false;
+    if (obj->kind == LBFGS_HIP_OBJ_LJ_CELLS) {
+        ProfScope ps(ctx, LBFGS_HIP_K_EVAL);
+        return lj_cells_eval(ctx, obj, x, g, out, natoms);
+    }
     RedCtl red{};
     {
         const int rc_h = fill_handoff(ctx, red);
         if (rc_h != LBFGS_HIP_OK) return rc_h;
     }
     red.out[0] = out;
-    const long idx = out - ctx->board;
-    if (idx >= 0 && idx < LBFGS_HIP_BOARD_SLOTS + 2) ctx->mirror_valid[idx] = false;
     {
         ProfScope ps(ctx, LBFGS_HIP_K_EVAL);
         if (obj->kind == LBFGS_HIP_OBJ_LJ_ALLPAIRS) {
@@ -828,6 +1002,10 @@ void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* ctx) {
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     if (ctx->gran) (void)hipFree(ctx->gran);
     if (ctx->lj_scratch) (void)hipFree(ctx->lj_scratch);
+    if (ctx->lj_cells) {
+        ctx->lj_cells->release();
+        delete ctx->lj_cells;
+    }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->mirror) (void)hipHostFree(ctx->mirror);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1497,6 +1675,7 @@ int lbfgs_hip_objective_eval(const lbfgs_hip_objective* obj, const lbfgs_hip_vec
         }
         case LBFGS_HIP_OBJ_LJ_ALLPAIRS:
         case LBFGS_HIP_OBJ_LJ_NEIGHBORS:
+        case LBFGS_HIP_OBJ_LJ_CELLS:
             return lj_eval(ctx, obj, x, g, outs[0]);
         default:
             return fail(ctx, LBFGS_HIP_ERR_ARG, "unknown objective kind %d", obj->kind);
@@ -1522,7 +1701,8 @@ int lbfgs_hip_objective_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec*
             return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
         }
         case LBFGS_HIP_OBJ_LJ_ALLPAIRS:
-        case LBFGS_HIP_OBJ_LJ_NEIGHBORS: {  // gather pattern: line step, evaluate, g.d as three launches
+        case LBFGS_HIP_OBJ_LJ_NEIGHBORS:
+        case LBFGS_HIP_OBJ_LJ_CELLS: {  // gather pattern: line step, evaluate, g.d as three launches
             int rc = lbfgs_hip_line_step(x, xp, d, step, nullptr, 0, 0);
             if (rc != LBFGS_HIP_OK) return rc;
             if ((rc = lj_eval(ctx, obj, x, g, outs[0])) != LBFGS_HIP_OK) return rc;
@@ -1539,6 +1719,22 @@ int lbfgs_hip_objective_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec*
         default:
             return fail(ctx, LBFGS_HIP_ERR_ARG, "unknown objective kind %d", obj->kind);
     }
+}
+
+int lbfgs_hip_lj_cells_stats(lbfgs_hip_ctx* ctx, uint64_t* rebuilds, uint64_t* evaluations, uint32_t* longest_list) {
+    if (!ctx) return LBFGS_HIP_ERR_ARG;
+    const LjCells* lc = ctx->lj_cells;
+    uint32_t longest = 0;
+    if (lc && lc->built && lc->natoms) {  // longest list of the latest build (a small scan, diagnostics only)
+        std::vector<int32_t> cnt(lc->natoms);
+        HIP_TRY(ctx, hipMemcpyAsync(cnt.data(), lc->cnt, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (int32_t c : cnt) longest = std::max(longest, (uint32_t)c);
+    }
+    if (rebuilds) *rebuilds = lc ? lc->rebuilds : 0;
+    if (evaluations) *evaluations = lc ? lc->evals : 0;
+    if (longest_list) *longest_list = longest;
+    return LBFGS_HIP_OK;
 }
 
 int lbfgs_hip_objective_is_elementwise(const lbfgs_hip_objective* obj) {

@@ -105,4 +105,197 @@ __global__ __launch_bounds__(BLOCK) void lj_neighbors_kernel(const double* __res
     grid_reduce<1>(acc, red);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Rebuildable neighbour structure for the cutoff form (LBFGS_HIP_OBJ_LJ_CELLS): a Verlet list with a skin, built on
+// the device from a cell list.
+//   list radius rl = rc + skin; the list stays complete for the cutoff rc while no atom has moved more than skin/2
+//   from where it was at build time (xref).  The evaluation kernel counts the atoms beyond that bound in the same
+//   pass; the host rebuilds and re-evaluates when the count is non-zero, so every result is the exact cutoff sum
+//   E = sum_{i<j, r<rc} [v(r) - v(rc)] whatever the rebuild history.
+//   build: bounding box -> cells of side >= rl -> count (atomics) -> exclusive scan -> fill (atomics) -> each cell's
+//   atoms sorted by index -> per atom the 27 surrounding cells in a fixed order -> ELL table (column-major, padded to a
+//   multiple of 4 with -1).  The sort makes the table, and with it the order of every force sum, independent of the
+//   order in which the atomics landed: results are bitwise reproducible.
+struct LjGrid {
+    double ox, oy, oz, inv_side;
+    int nx, ny, nz;
+};
+
+__device__ __forceinline__ int lj_cell_coord(double v, double o, double inv_side, int nmax) {
+    const double t = (v - o) * inv_side;
+    int c = (t >= 0.0) ? (int)fmin(t, 2.0e9) : 0;  // NaN compares false -> 0
+    return c < nmax ? c : nmax - 1;
+}
+
+// per-workgroup min / max of the coordinates: part[6*blockIdx.x + {0,1,2}] = min, {3,4,5} = max (the host reduces them)
+__global__ __launch_bounds__(BLOCK) void lj_bbox_kernel(const double* __restrict__ x, const uint32_t natoms,
+                                                         double* __restrict__ part) {
+    __shared__ double sh[6][WAVES];
+    double lo[3] = {1.0 / 0.0, 1.0 / 0.0, 1.0 / 0.0}, hi[3] = {-1.0 / 0.0, -1.0 / 0.0, -1.0 / 0.0};
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < natoms; i += gridDim.x * BLOCK)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double v = x[3 * (size_t)i + k];
+            lo[k] = fmin(lo[k], v);
+            hi[k] = fmax(hi[k], v);
+        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = fmin(lo[k], __shfl_down(lo[k], off, 64));
+            hi[k] = fmax(hi[k], __shfl_down(hi[k], off, 64));
+        }
+        if (lane == 0) { sh[k][wave] = lo[k]; sh[3 + k][wave] = hi[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double v = sh[threadIdx.x][0];
+        for (int w = 1; w < WAVES; ++w) v = (threadIdx.x < 3) ? fmin(v, sh[threadIdx.x][w]) : fmax(v, sh[threadIdx.x][w]);
+        part[6 * (size_t)blockIdx.x + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void lj_cells_count_kernel(const double* __restrict__ x, const uint32_t natoms,
+                                                                const LjGrid gr, int32_t* __restrict__ cell_of,
+                                                                int32_t* __restrict__ counts) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < natoms; i += gridDim.x * BLOCK) {
+        const int cx = lj_cell_coord(x[3 * (size_t)i], gr.ox, gr.inv_side, gr.nx);
+        const int cy = lj_cell_coord(x[3 * (size_t)i + 1], gr.oy, gr.inv_side, gr.ny);
+        const int cz = lj_cell_coord(x[3 * (size_t)i + 2], gr.oz, gr.inv_side, gr.nz);
+        const int c = (cz * gr.ny + cy) * gr.nx + cx;
+        cell_of[i] = c;
+        atomicAdd(&counts[c], 1);
+    }
+}
+
+// exclusive scan of counts[0, ncells) into starts[0, ncells] by ONE workgroup of 1024 threads; cursor = starts
+__global__ __launch_bounds__(1024) void lj_cells_scan_kernel(const int32_t* __restrict__ counts, const uint32_t ncells,
+                                                              int32_t* __restrict__ starts, int32_t* __restrict__ cursor) {
+    __shared__ int32_t sums[1024];
+    const uint32_t per = (ncells + 1023u) / 1024u;
+    const uint32_t lo = threadIdx.x * per, hi = min(ncells, lo + per);
+    int32_t s = 0;
+    for (uint32_t c = lo; c < hi; ++c) s += counts[c];
+    sums[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+        const int32_t v = (threadIdx.x >= (unsigned)off) ? sums[threadIdx.x - off] : 0;
+        __syncthreads();
+        sums[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int32_t run = (threadIdx.x == 0) ? 0 : sums[threadIdx.x - 1];
+    for (uint32_t c = lo; c < hi; ++c) {
+        starts[c] = run;
+        cursor[c] = run;
+        run += counts[c];
+    }
+    if (threadIdx.x == 1023) starts[ncells] = sums[1023];
+}
+
+__global__ __launch_bounds__(BLOCK) void lj_cells_fill_kernel(const int32_t* __restrict__ cell_of, const uint32_t natoms,
+                                                               int32_t* __restrict__ cursor, int32_t* __restrict__ sorted) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < natoms; i += gridDim.x * BLOCK)
+        sorted[atomicAdd(&cursor[cell_of[i]], 1)] = (int32_t)i;
+}
+
+// one thread per cell: its atoms into ascending index order (insertion sort: a cell holds a few dozen atoms)
+__global__ __launch_bounds__(BLOCK) void lj_cells_sort_kernel(const int32_t* __restrict__ starts, const uint32_t ncells,
+                                                               int32_t* __restrict__ sorted) {
+    for (uint32_t c = blockIdx.x * BLOCK + threadIdx.x; c < ncells; c += gridDim.x * BLOCK) {
+        const int32_t a = starts[c], b = starts[c + 1];
+        for (int32_t t = a + 1; t < b; ++t) {
+            const int32_t v = sorted[t];
+            int32_t u = t - 1;
+            while (u >= a && sorted[u] > v) { sorted[u + 1] = sorted[u]; --u; }
+            sorted[u + 1] = v;
+        }
+    }
+}
+
+// Verlet list of atom i: every j != i with |x_i - x_j| < rl, in the order (27 cells: z, y, x ascending; atoms ascending).
+// cnt[i] = entries used (a multiple of 4, the tail padded with -1); *overflow = the largest list that did not fit.
+__global__ __launch_bounds__(BLOCK) void lj_cells_build_kernel(const double* __restrict__ x, const uint32_t natoms,
+                                                                const LjGrid gr, const int32_t* __restrict__ cell_of,
+                                                                const int32_t* __restrict__ starts,
+                                                                const int32_t* __restrict__ sorted, const double rl2,
+                                                                const uint32_t max_nbr, int32_t* __restrict__ nbr,
+                                                                int32_t* __restrict__ cnt, double* __restrict__ xref,
+                                                                unsigned int* __restrict__ overflow) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < natoms; i += gridDim.x * BLOCK) {
+        const double xi = x[3 * (size_t)i], yi = x[3 * (size_t)i + 1], zi = x[3 * (size_t)i + 2];
+        xref[3 * (size_t)i] = xi; xref[3 * (size_t)i + 1] = yi; xref[3 * (size_t)i + 2] = zi;
+        const int c = cell_of[i];
+        const int cx = c % gr.nx, cy = (c / gr.nx) % gr.ny, cz = c / (gr.nx * gr.ny);
+        uint32_t k = 0;
+        for (int dz = -1; dz <= 1; ++dz) {
+            const int az = cz + dz;
+            if (az < 0 || az >= gr.nz) continue;
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int ay = cy + dy;
+                if (ay < 0 || ay >= gr.ny) continue;
+                // the three cells of a row are adjacent in memory: one contiguous segment of `sorted`
+                const int ax0 = max(cx - 1, 0), ax1 = min(cx + 1, gr.nx - 1);
+                const int row = (az * gr.ny + ay) * gr.nx;
+                for (int32_t t = starts[row + ax0]; t < starts[row + ax1 + 1]; ++t) {
+                    const int32_t j = sorted[t];
+                    if ((uint32_t)j == i) continue;
+                    const double dx = xi - x[3 * (size_t)j], dyy = yi - x[3 * (size_t)j + 1], dzz = zi - x[3 * (size_t)j + 2];
+                    if (dx * dx + dyy * dyy + dzz * dzz < rl2) {
+                        if (k < max_nbr) nbr[(size_t)k * natoms + i] = j;
+                        ++k;
+                    }
+                }
+            }
+        }
+        if (k > max_nbr) {
+            atomicMax(overflow, k);
+            k = max_nbr;
+        }
+        const uint32_t k4 = (k + 3u) & ~3u;  // max_nbr is a multiple of 4
+        for (uint32_t t = k; t < k4; ++t) nbr[(size_t)t * natoms + i] = -1;
+        cnt[i] = (int32_t)k4;
+    }
+}
+
+// The cutoff sum over the Verlet list, and (second total) the number of atoms that have left their skin/2 sphere.
+__global__ __launch_bounds__(BLOCK) void lj_cells_eval_kernel(const double* __restrict__ x, double* __restrict__ g,
+                                                               const int32_t* __restrict__ nbr,
+                                                               const int32_t* __restrict__ cnt,
+                                                               const double* __restrict__ xref, const uint32_t natoms,
+                                                               const double rc2, const double eshift,
+                                                               const double half_skin2, const RedCtl red) {
+    double e = 0.0, stale = 0.0;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < natoms; i += gridDim.x * BLOCK) {
+        const double xi = x[3 * (size_t)i], yi = x[3 * (size_t)i + 1], zi = x[3 * (size_t)i + 2];
+        {
+            const double ux = xi - xref[3 * (size_t)i], uy = yi - xref[3 * (size_t)i + 1], uz = zi - xref[3 * (size_t)i + 2];
+            const double u2 = ux * ux + uy * uy + uz * uz;
+            stale += (u2 <= half_skin2) ? 0.0 : 1.0;  // NaN counts as moved
+        }
+        double fx = 0.0, fy = 0.0, fz = 0.0;
+        const uint32_t n4 = (uint32_t)cnt[i];
+        for (uint32_t k0 = 0; k0 < n4; k0 += 4) {
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {  // four gathers in flight; an empty slot or a pair beyond rc adds selected zeros
+                const int32_t j = nbr[(size_t)(k0 + u) * natoms + i];
+                const size_t jj = (j < 0) ? (size_t)i : (size_t)j;
+                const double dx = xi - x[3 * jj], dy = yi - x[3 * jj + 1], dz = zi - x[3 * jj + 2];
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                const bool on = (j >= 0) && (r2 < rc2);
+                const double inv2 = 1.0 / (on ? r2 : 1.0);
+                const double s6 = inv2 * inv2 * inv2;
+                e += on ? 4.0 * (s6 * s6 - s6) : 0.0;                     // pair_energy   lj.rs:22-25
+                const double c = 24.0 * (s6 - 2.0 * (s6 * s6)) * inv2;   // pair_gradient/r  lj.rs:28-32, :57-58
+                fx += on ? c * dx : 0.0; fy += on ? c * dy : 0.0; fz += on ? c * dz : 0.0;
+                e -= on ? eshift : 0.0;
+            }
+        }
+        g[3 * (size_t)i] = fx; g[3 * (size_t)i + 1] = fy; g[3 * (size_t)i + 2] = fz;
+    }
+    double acc[2] = {0.5 * e, stale};
+    grid_reduce<2>(acc, red);
+}
+
 }  // namespace lh

@@ -38,6 +38,15 @@ def LennardJonesNeighbors(nbr_index, cutoff):
     return BuiltinObjective(_ffi.OBJ_LJ_NEIGHBORS, fuse_line_eval=True, nbr_index=nbr_index, cutoff=float(cutoff))
 
 
+def LennardJonesCells(cutoff=2.5, skin=0.3, max_nbr=0):
+    """The evaluator of BASELINE config 5 at scale: E = sum_{i<j, r<rc} [v(r) - v(rc)] through a neighbour list the
+    library builds ON THE DEVICE from a cell list (radius cutoff + skin) and rebuilds whenever an atom has moved more
+    than skin/2 since the last build, so atoms may travel freely during a minimisation.  Deviation from
+    examples/lj.rs:38-64 (documented): the cutoff and the energy shift; the pair terms are the example's."""
+    return BuiltinObjective(_ffi.OBJ_LJ_CELLS, fuse_line_eval=True, cutoff=float(cutoff), skin=float(skin),
+                            max_nbr=int(max_nbr))
+
+
 def cubic_lattice_neighbors(nside, spacing, cutoff):
     """Neighbour table of an nside^3 simple-cubic lattice (open boundaries): every site within `cutoff` at the
     ideal positions, so it stays valid while atoms move by less than half the skin.  -> (x0 [3*natoms], table)."""

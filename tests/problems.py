@@ -11,6 +11,16 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def lj38_x0():
+    """examples/lj.rs:72-110: the LJ38 start coordinates of the reference's example (tests/golden/lj38_positions.json)."""
+    import json
+
+    d = json.load(open(os.path.join(GOLDEN, "lj38_positions.json")))
+    x = np.array(d["positions"], dtype=np.float64)
+    assert x.shape == (3 * d["natoms"],) == (114,)
+    return x
+
+
 def rosenbrock_x0(n=100):
     """tests/simple.rs:24-28"""
     x = np.zeros(n)

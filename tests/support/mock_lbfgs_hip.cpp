@@ -338,8 +338,20 @@ static int eval_obj(const lbfgs_hip_objective* obj, lbfgs_hip_ctx* c, const doub
             *f = oracle_obj_lj_neighbors(&u2, x, g, nl(c), &failed);
             break;
         }
+        case LBFGS_HIP_OBJ_LJ_CELLS: {  // the cutoff rule itself (no list to carry on the CPU)
+            oracle_lj_cells u3{obj->cutoff};
+            *f = oracle_obj_lj_cells(&u3, x, g, nl(c), &failed);
+            if (failed) return fail(c, LBFGS_HIP_ERR_ARG, "LJ_CELLS: a coordinate is not finite");
+            break;
+        }
         default: return fail(c, LBFGS_HIP_ERR_ARG, "unknown objective");
     }
+    return LBFGS_HIP_OK;
+}
+int lbfgs_hip_lj_cells_stats(lbfgs_hip_ctx*, uint64_t* rebuilds, uint64_t* evaluations, uint32_t* longest) {
+    if (rebuilds) *rebuilds = 0;
+    if (evaluations) *evaluations = 0;
+    if (longest) *longest = 0;
     return LBFGS_HIP_OK;
 }
 int lbfgs_hip_host_buffer_create(lbfgs_hip_ctx*, uint64_t bytes, void** out) {

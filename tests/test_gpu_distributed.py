@@ -150,7 +150,7 @@ def test_bench_survives_a_hung_leg(tmp_path):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "12", "--dim", "1000", "--device", "0",
-           "--repeats", "2", "--leg-timeout", "60", "--no-vector-free"]
+           "--repeats", "2", "--leg-timeout", "25", "--no-vector-free"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LBFGS_BENCH_LEGS="hang,p2p")
     p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=400)
     assert p.returncode == 0, p.stderr[-2000:]

@@ -166,13 +166,13 @@ def test_owlqn_properties_at_config3_size():
         ys3 = hist.y(3).vecdot(hist.s(3))
         ctx.set_scalars(7, [ys3, hist.y(3).vecdot(hist.y(3))])
         ne1 = hist.two_loop_owlqn(x1, pg, 23, 3, 0, n, 7, 8, 13)
-        a = ctx.scalars(13, 4)                              # ||d||^2, pg.d before; ||d||^2, pg.d after the projection
+        a = ctx.scalars(13, 4)                              # ||d||^2 before (slot 14 unused); ||d||^2, pg.d after the projection
         ne2 = hist.two_loop(x2, pg, 23, 3, 7, 8, 40)
         b_pre = ctx.scalars(40, 2)
         H.constrain_direction(x2, pg, 0, n, 42)
         b_post = ctx.scalars(42, 2)
         assert ne1 == ne2 == 4 and same(x1, x2)
-        for u, v in zip(a, list(b_pre) + list(b_post)):
+        for u, v in zip((a[0], a[2], a[3]), (b_pre[0], b_post[0], b_post[1])):
             assert close(u, v), (a, b_pre, b_post)
         assert a[2] > 0 and a[3] < 0                        # a descent direction survives the projection
         hist.two_loop_owlqn(g1, pg, 23, 3, 0, n, 7, 8, 13)
@@ -180,3 +180,41 @@ def test_owlqn_properties_at_config3_size():
         hist.free()
         for v in (xp, gp, pg, wp, d, tmp, x1, g1, pg1, x2, g2, pg2):
             v.free()
+
+
+def test_lj_cells_properties_at_config5_size():
+    """BASELINE.json config 5 at its own size (Lennard-Jones, 1e6 atoms, n = 3e6) through the library-built,
+    rebuildable neighbour list (LJ_CELLS): energy and forces against the oracle's cutoff rule (its cell list is O(N), a
+    few seconds here), bitwise determinism across a forced rebuild, Newton's third law (the forces sum to zero), and
+    the rebuild trigger at this size."""
+    nside = int(os.environ.get("LBFGS_TEST_CONFIG5_NSIDE", 100))
+    rc, skin = 2.5, 0.3
+    rng = np.random.default_rng(5)
+    g3 = np.stack(np.meshgrid(*[np.arange(nside, dtype=np.float64)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    x = (g3 * 1.1 + rng.uniform(-0.06, 0.06, g3.shape)).reshape(-1)
+    del g3
+    n = len(x)
+    obj = objectives.LennardJonesCells(rc, skin)
+    from oracle import oracle as O
+
+    with R.Context(n) as ctx:
+        xv, gv = DeviceVec(ctx, x), DeviceVec(ctx)
+        H.objective_eval(obj, xv, gv, 0)
+        f1, g1 = ctx.scalars(0)[0], gv.to_numpy()
+        fo, go = O.eval_builtin(O.lj_cells(rc), x)
+        assert abs(f1 - fo) <= 1e-10 * abs(fo)
+        assert np.max(np.abs(g1 - go)) <= 1e-10 * np.max(np.abs(go))
+        for k in range(3):  # Newton's third law: every pair term enters two atoms with opposite signs
+            assert abs(np.sum(g1[k::3])) <= 1e-9 * np.sum(np.abs(g1[k::3]))
+        # a displaced copy forces a rebuild; coming back must reproduce the first result bit for bit
+        x2 = x.copy()
+        x2[: 3 * 1000] += 0.8 * skin
+        H.objective_eval(obj, xv.upload(x2), gv, 0)
+        f2 = ctx.scalars(0)[0]
+        assert f2 != f1
+        H.objective_eval(obj, xv.upload(x), gv, 0)
+        assert ctx.scalars(0)[0] == f1 and np.array_equal(gv.to_numpy(), g1)
+        if os.environ.get("LBFGS_TEST_BACKEND") != "mock":
+            rebuilds, evals, longest = ctx.lj_cells_stats()
+            assert rebuilds == 3 and evals == 5 and 40 <= longest <= 128
+        xv.free(); gv.free()

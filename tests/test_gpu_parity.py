@@ -526,8 +526,7 @@ def test_lj38_damped_closure_matches_oracle():
     """BASELINE config 5 at parity size: examples/lj.rs (LJ38, all-pairs) with with_damping(true), through the
     drop-in host closure.  Powell damping is parity-unpinned by the reference's tests; the oracle follows the
     source text (lbfgs.rs:664-689, incl. the dropped case 2)."""
-    rng = np.random.default_rng(7)
-    x0 = rng.random(38 * 3) * 3.2 + 48.4
+    x0 = P.lj38_x0()  # examples/lj.rs:72-110
 
     def lj(x, g):
         f, gg = O.eval_builtin(O.lj(), np.ascontiguousarray(x))
@@ -702,7 +701,7 @@ def test_lj_neighbors_matches_oracle_and_allpairs_limit():
 
 def test_lj38_damped_device_objective():
     """BASELINE config 5 (parity size) with the objective RESIDENT on the device: damped L-BFGS on an LJ cluster."""
-    x0 = _lj_cluster(38, 11)
+    x0 = P.lj38_x0()  # examples/lj.rs:72-110
     cfg = lambda b: b.with_damping(True).with_max_iterations(30)
     fields = ("niter", "neval", "fx", "gnorm", "step")
 

@@ -133,8 +133,7 @@ def test_booth_and_poisson():
 
 def test_lj38_damped():
     """examples/lj.rs objective with with_damping(true) (BASELINE config 5, parity-size case)."""
-    rng = np.random.default_rng(7)
-    x0 = (rng.random(38 * 3) * 3.2 + 48.4)
+    x0 = P.lj38_x0()  # examples/lj.rs:72-110
     f = lambda x, g: (lambda fg: (g.__setitem__(slice(None), fg[1]), fg[0])[1])(O.eval_builtin(O.lj(), np.ascontiguousarray(x)))
     cfg = lambda b: b.with_damping(True).with_max_iterations(60)
     a, b = run_pair(cfg, x0, O.lj(), f)
