@@ -113,6 +113,8 @@ struct LjCells {
     int32_t *nbr = nullptr, *cnt = nullptr, *cell_of = nullptr, *sorted = nullptr, *counts = nullptr, *starts = nullptr,
             *cursor = nullptr;
     double* xref = nullptr;          // positions at build time
+    double* xs = nullptr;            // positions in cell order (build time only)
+    int32_t* tile_sums = nullptr;    // scan scratch, 1024 entries
     double* bbox_part = nullptr;     // [LJ_BBOX_GRID][6]
     unsigned int* overflow = nullptr;
     double* host = nullptr;          // host-mapped: [0] = atoms outside their skin/2 sphere (written by the evaluation kernel)
@@ -121,7 +123,7 @@ struct LjCells {
     uint64_t rebuilds = 0, evals = 0;
     uint32_t longest = 0;
     void release() {
-        void* ptrs[] = {nbr, cnt, cell_of, sorted, counts, starts, cursor, xref, bbox_part, overflow};
+        void* ptrs[] = {nbr, cnt, cell_of, sorted, counts, starts, cursor, xref, xs, tile_sums, bbox_part, overflow};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (host) (void)hipHostFree(host);
@@ -481,7 +483,7 @@ int lj_cells_prepare(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, uint32_
     lc->release();
     lc->rebuilds = keep_rebuilds; lc->evals = keep_evals;
     lc->natoms = natoms; lc->max_nbr = max_nbr; lc->cutoff = obj->cutoff; lc->skin = obj->skin;
-    lc->ncap = 2 * (size_t)natoms + 64;
+    lc->ncap = std::min<size_t>(2 * (size_t)natoms + 64, (size_t)1024 * LJ_SCAN_TILE);  // (the scan handles 1024 tiles)
 #define LJ_ALLOC(ptr, bytes)                                                                                     \
     do {                                                                                                         \
         hipError_t e_ = hipMalloc(&(ptr), (bytes));                                                              \
@@ -499,6 +501,8 @@ int lj_cells_prepare(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, uint32_
     LJ_ALLOC(lc->starts, (lc->ncap + 1) * sizeof(int32_t));
     LJ_ALLOC(lc->cursor, (lc->ncap + 1) * sizeof(int32_t));
     LJ_ALLOC(lc->xref, 3 * na * sizeof(double));
+    LJ_ALLOC(lc->xs, 3 * na * sizeof(double));
+    LJ_ALLOC(lc->tile_sums, 1024 * sizeof(int32_t));
     LJ_ALLOC(lc->bbox_part, (size_t)LJ_BBOX_GRID * 6 * sizeof(double));
     LJ_ALLOC(lc->overflow, 64);
 #undef LJ_ALLOC
@@ -563,10 +567,15 @@ int lj_cells_rebuild(lbfgs_hip_ctx* ctx, const double* x) {
     HIP_TRY(ctx, hipMemsetAsync(lc->counts, 0, ((size_t)ncells + 1) * sizeof(int32_t), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(lc->overflow, 0, sizeof(unsigned int), ctx->stream));
     hipLaunchKernelGGL(lj_cells_count_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, x, natoms, gr, lc->cell_of, lc->counts);
-    hipLaunchKernelGGL(lj_cells_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, lc->counts, ncells, lc->starts, lc->cursor);
+    const uint32_t ntiles = (ncells + LJ_SCAN_TILE - 1) / LJ_SCAN_TILE;  // <= 1024 by the choice of ncap
+    hipLaunchKernelGGL(lj_scan_tile_sums_kernel, dim3(ntiles), dim3(BLOCK), 0, ctx->stream, lc->counts, ncells, lc->tile_sums);
+    hipLaunchKernelGGL(lj_scan_tile_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, lc->tile_sums, ntiles);
+    hipLaunchKernelGGL(lj_scan_apply_kernel, dim3(ntiles), dim3(BLOCK), 0, ctx->stream, lc->counts, ncells, lc->tile_sums,
+                       lc->starts, lc->cursor);
     hipLaunchKernelGGL(lj_cells_fill_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, lc->cell_of, natoms, lc->cursor, lc->sorted);
     hipLaunchKernelGGL(lj_cells_sort_kernel, dim3(cgrid), dim3(BLOCK), 0, ctx->stream, lc->starts, ncells, lc->sorted);
-    hipLaunchKernelGGL(lj_cells_build_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, x, natoms, gr, lc->cell_of, lc->starts,
+    hipLaunchKernelGGL(lj_cells_gather_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, x, natoms, lc->sorted, lc->xs);
+    hipLaunchKernelGGL(lj_cells_build_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, lc->xs, natoms, gr, lc->cell_of, lc->starts,
                        lc->sorted, rl * rl, lc->max_nbr, lc->nbr, lc->cnt, lc->xref, lc->overflow);
     HIP_TRY(ctx, hipGetLastError());
     unsigned int over = 0;

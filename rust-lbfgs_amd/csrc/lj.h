@@ -13,9 +13,23 @@
 
 namespace lh {
 
+// The LJ evaluators are the USER objective (examples/lj.rs), not an L-BFGS primitive: their parity bar is 1e-10
+// relative against the oracle, not the bit-exactness of the math.rs operators.  So, unlike the rest of the translation
+// unit (-ffp-contract=off), the pair arithmetic may contract mul+add into FMA, and 1/r^2 is a hardware reciprocal
+// estimate (v_rcp_f64, ~2^-23) polished by two Newton steps (4 FMAs, <= 1 ulp) instead of the ~10-instruction IEEE
+// division sequence.  The pragma is switched off again at the end of this header.
+#pragma clang fp contract(fast)
+
+__device__ __forceinline__ double lj_rcp(double a) {
+    double r = __builtin_amdgcn_rcp(a);
+    r = __builtin_fma(r, __builtin_fma(-a, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-a, r, 1.0), r);
+    return r;
+}
+
 __device__ __forceinline__ void lj_pair(double dx, double dy, double dz, double& e, double& fx, double& fy, double& fz) {
     const double r2 = dx * dx + dy * dy + dz * dz;
-    const double inv2 = 1.0 / r2;
+    const double inv2 = lj_rcp(r2);
     const double s6 = inv2 * inv2 * inv2;
     e += 4.0 * (s6 * s6 - s6);                       // pair_energy   lj.rs:22-25
     const double c = 24.0 * (s6 - 2.0 * (s6 * s6)) * inv2;  // pair_gradient/r  lj.rs:28-32, :57-58
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(BLOCK) void lj_neighbors_kernel(const double* __res
             const double dx = xi - x[3 * jj], dy = yi - x[3 * jj + 1], dz = zi - x[3 * jj + 2];
             const double r2 = dx * dx + dy * dy + dz * dz;
             const bool on = (j >= 0) && (r2 < rc2);
-            const double inv2 = 1.0 / (on ? r2 : 1.0);
+            const double inv2 = lj_rcp(on ? r2 : 1.0);
             const double s6 = inv2 * inv2 * inv2;
             e += on ? 4.0 * (s6 * s6 - s6) : 0.0;                     // pair_energy   lj.rs:22-25
             const double c = 24.0 * (s6 - 2.0 * (s6 * s6)) * inv2;   // pair_gradient/r  lj.rs:28-32, :57-58
@@ -169,29 +183,78 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_count_kernel(const double* __r
     }
 }
 
-// exclusive scan of counts[0, ncells) into starts[0, ncells] by ONE workgroup of 1024 threads; cursor = starts
-__global__ __launch_bounds__(1024) void lj_cells_scan_kernel(const int32_t* __restrict__ counts, const uint32_t ncells,
-                                                              int32_t* __restrict__ starts, int32_t* __restrict__ cursor) {
-    __shared__ int32_t sums[1024];
-    const uint32_t per = (ncells + 1023u) / 1024u;
-    const uint32_t lo = threadIdx.x * per, hi = min(ncells, lo + per);
-    int32_t s = 0;
-    for (uint32_t c = lo; c < hi; ++c) s += counts[c];
-    sums[threadIdx.x] = s;
+// exclusive scan of counts[0, ncells) into starts[0, ncells] (and cursor = starts), three small launches:
+//   tiles of LJ_SCAN_TILE cells -> per-tile sums ; one workgroup scans the (<= 1024) tile sums ; every tile scans itself
+// with its offset.  All loads coalesced; ~10 us at 64k cells where a single serial workgroup took 170 us.
+constexpr int LJ_SCAN_TILE = 2048;   // 256 threads x 8 cells
+__device__ __forceinline__ int32_t lj_block_exclusive_scan(int32_t v, int32_t* lds /* [WAVES] */, int32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) lds[wave] = inc;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-        const int32_t v = (threadIdx.x >= (unsigned)off) ? sums[threadIdx.x - off] : 0;
+    int32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        const int32_t s = lds[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+__global__ __launch_bounds__(BLOCK) void lj_scan_tile_sums_kernel(const int32_t* __restrict__ counts, const uint32_t ncells,
+                                                                   int32_t* __restrict__ tile_sums) {
+    __shared__ int32_t lds[WAVES];
+    const uint32_t base = blockIdx.x * LJ_SCAN_TILE;
+    int32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < LJ_SCAN_TILE / BLOCK; ++k) {
+        const uint32_t c = base + k * BLOCK + threadIdx.x;
+        s += (c < ncells) ? counts[c] : 0;
+    }
+    int32_t total;
+    (void)lj_block_exclusive_scan(s, lds, total);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void lj_scan_tile_offsets_kernel(int32_t* __restrict__ tile_sums, const uint32_t ntiles) {
+    __shared__ int32_t sums[1024];
+    const int32_t v = (threadIdx.x < ntiles) ? tile_sums[threadIdx.x] : 0;
+    sums[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan over <= 1024 tile sums
+        const int32_t t = (threadIdx.x >= (unsigned)off) ? sums[threadIdx.x - off] : 0;
         __syncthreads();
-        sums[threadIdx.x] += v;
+        sums[threadIdx.x] += t;
         __syncthreads();
     }
-    int32_t run = (threadIdx.x == 0) ? 0 : sums[threadIdx.x - 1];
-    for (uint32_t c = lo; c < hi; ++c) {
-        starts[c] = run;
-        cursor[c] = run;
-        run += counts[c];
+    if (threadIdx.x < ntiles) tile_sums[threadIdx.x] = sums[threadIdx.x] - v;  // exclusive
+}
+__global__ __launch_bounds__(BLOCK) void lj_scan_apply_kernel(const int32_t* __restrict__ counts, const uint32_t ncells,
+                                                               const int32_t* __restrict__ tile_offsets,
+                                                               int32_t* __restrict__ starts, int32_t* __restrict__ cursor) {
+    __shared__ int32_t lds[WAVES];
+    // thread t owns the 8 consecutive cells [base + 8t, base + 8t + 8)
+    const uint32_t c0 = blockIdx.x * LJ_SCAN_TILE + threadIdx.x * (LJ_SCAN_TILE / BLOCK);
+    int32_t v[LJ_SCAN_TILE / BLOCK], s = 0;
+#pragma unroll
+    for (int k = 0; k < LJ_SCAN_TILE / BLOCK; ++k) {
+        v[k] = (c0 + k < ncells) ? counts[c0 + k] : 0;
+        s += v[k];
     }
-    if (threadIdx.x == 1023) starts[ncells] = sums[1023];
+    int32_t total;
+    int32_t run = tile_offsets[blockIdx.x] + lj_block_exclusive_scan(s, lds, total);
+#pragma unroll
+    for (int k = 0; k < LJ_SCAN_TILE / BLOCK; ++k) {
+        if (c0 + k < ncells) { starts[c0 + k] = run; cursor[c0 + k] = run; }
+        run += v[k];
+        if (c0 + k + 1 == ncells) starts[ncells] = run;
+    }
 }
 
 __global__ __launch_bounds__(BLOCK) void lj_cells_fill_kernel(const int32_t* __restrict__ cell_of, const uint32_t natoms,
@@ -214,20 +277,33 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_sort_kernel(const int32_t* __r
     }
 }
 
-// Verlet list of atom i: every j != i with |x_i - x_j| < rl, in the order (27 cells: z, y, x ascending; atoms ascending).
+// positions in cell order: xs[t] = x[sorted[t]] (the list kernel then reads its candidates sequentially)
+__global__ __launch_bounds__(BLOCK) void lj_cells_gather_kernel(const double* __restrict__ x, const uint32_t natoms,
+                                                                 const int32_t* __restrict__ sorted, double* __restrict__ xs) {
+    for (uint32_t t = blockIdx.x * BLOCK + threadIdx.x; t < natoms; t += gridDim.x * BLOCK) {
+        const size_t j = (size_t)sorted[t];
+        xs[3 * (size_t)t] = x[3 * j]; xs[3 * (size_t)t + 1] = x[3 * j + 1]; xs[3 * (size_t)t + 2] = x[3 * j + 2];
+    }
+}
+
+// Verlet list of atom i = sorted[t]: every j != i with |x_i - x_j| < rl, in the order (27 cells: z, y, x ascending; atoms
+// of a cell ascending).  One thread per atom IN CELL ORDER: the threads of a wave sit in the same few cells and walk the
+// same contiguous candidate segments of xs (the three cells of a row are adjacent in memory).
 // cnt[i] = entries used (a multiple of 4, the tail padded with -1); *overflow = the largest list that did not fit.
-__global__ __launch_bounds__(BLOCK) void lj_cells_build_kernel(const double* __restrict__ x, const uint32_t natoms,
+__global__ __launch_bounds__(BLOCK) void lj_cells_build_kernel(const double* __restrict__ xs, const uint32_t natoms,
                                                                 const LjGrid gr, const int32_t* __restrict__ cell_of,
                                                                 const int32_t* __restrict__ starts,
                                                                 const int32_t* __restrict__ sorted, const double rl2,
                                                                 const uint32_t max_nbr, int32_t* __restrict__ nbr,
                                                                 int32_t* __restrict__ cnt, double* __restrict__ xref,
                                                                 unsigned int* __restrict__ overflow) {
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < natoms; i += gridDim.x * BLOCK) {
-        const double xi = x[3 * (size_t)i], yi = x[3 * (size_t)i + 1], zi = x[3 * (size_t)i + 2];
+    for (uint32_t t = blockIdx.x * BLOCK + threadIdx.x; t < natoms; t += gridDim.x * BLOCK) {
+        const uint32_t i = (uint32_t)sorted[t];
+        const double xi = xs[3 * (size_t)t], yi = xs[3 * (size_t)t + 1], zi = xs[3 * (size_t)t + 2];
         xref[3 * (size_t)i] = xi; xref[3 * (size_t)i + 1] = yi; xref[3 * (size_t)i + 2] = zi;
         const int c = cell_of[i];
         const int cx = c % gr.nx, cy = (c / gr.nx) % gr.ny, cz = c / (gr.nx * gr.ny);
+        const int ax0 = max(cx - 1, 0), ax1 = min(cx + 1, gr.nx - 1);
         uint32_t k = 0;
         for (int dz = -1; dz <= 1; ++dz) {
             const int az = cz + dz;
@@ -235,15 +311,12 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_build_kernel(const double* __r
             for (int dy = -1; dy <= 1; ++dy) {
                 const int ay = cy + dy;
                 if (ay < 0 || ay >= gr.ny) continue;
-                // the three cells of a row are adjacent in memory: one contiguous segment of `sorted`
-                const int ax0 = max(cx - 1, 0), ax1 = min(cx + 1, gr.nx - 1);
                 const int row = (az * gr.ny + ay) * gr.nx;
-                for (int32_t t = starts[row + ax0]; t < starts[row + ax1 + 1]; ++t) {
-                    const int32_t j = sorted[t];
-                    if ((uint32_t)j == i) continue;
-                    const double dx = xi - x[3 * (size_t)j], dyy = yi - x[3 * (size_t)j + 1], dzz = zi - x[3 * (size_t)j + 2];
-                    if (dx * dx + dyy * dyy + dzz * dzz < rl2) {
-                        if (k < max_nbr) nbr[(size_t)k * natoms + i] = j;
+                const int32_t u1 = starts[row + ax1 + 1];
+                for (int32_t u = starts[row + ax0]; u < u1; ++u) {
+                    const double dx = xi - xs[3 * (size_t)u], dyy = yi - xs[3 * (size_t)u + 1], dzz = zi - xs[3 * (size_t)u + 2];
+                    if (dx * dx + dyy * dyy + dzz * dzz < rl2 && (uint32_t)u != t) {
+                        if (k < max_nbr) nbr[(size_t)k * natoms + i] = sorted[u];
                         ++k;
                     }
                 }
@@ -254,7 +327,7 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_build_kernel(const double* __r
             k = max_nbr;
         }
         const uint32_t k4 = (k + 3u) & ~3u;  // max_nbr is a multiple of 4
-        for (uint32_t t = k; t < k4; ++t) nbr[(size_t)t * natoms + i] = -1;
+        for (uint32_t q = k; q < k4; ++q) nbr[(size_t)q * natoms + i] = -1;
         cnt[i] = (int32_t)k4;
     }
 }
@@ -284,7 +357,7 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_eval_kernel(const double* __re
                 const double dx = xi - x[3 * jj], dy = yi - x[3 * jj + 1], dz = zi - x[3 * jj + 2];
                 const double r2 = dx * dx + dy * dy + dz * dz;
                 const bool on = (j >= 0) && (r2 < rc2);
-                const double inv2 = 1.0 / (on ? r2 : 1.0);
+                const double inv2 = lj_rcp(on ? r2 : 1.0);
                 const double s6 = inv2 * inv2 * inv2;
                 e += on ? 4.0 * (s6 * s6 - s6) : 0.0;                     // pair_energy   lj.rs:22-25
                 const double c = 24.0 * (s6 - 2.0 * (s6 * s6)) * inv2;   // pair_gradient/r  lj.rs:28-32, :57-58
@@ -297,5 +370,7 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_eval_kernel(const double* __re
     double acc[2] = {0.5 * e, stale};
     grid_reduce<2>(acc, red);
 }
+
+#pragma clang fp contract(off)
 
 }  // namespace lh
