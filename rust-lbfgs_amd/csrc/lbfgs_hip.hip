@@ -168,6 +168,7 @@ struct lbfgs_hip_ctx {
     int grid_override = 0;
     int gram_grid = 0;  // workgroups of the Gram rows kernel (0 = same as the others)
     size_t nt_threshold_bytes = (size_t)128 << 20;  // measured crossover: 95 MiB vectors prefer plain, 190 MiB prefer nt
+    size_t nt_store_threshold_bytes = (size_t)64 << 20;  // from here up to nt_threshold_bytes: `nt` on the STORES only
     bool prof_on = false;
     ProfClass prof[LBFGS_HIP_K_CLASSES];
     std::vector<ProfPair> prof_pool;
@@ -348,13 +349,21 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out,
     const bool in_kernel_exchange = Op::NRED > 0 && ctx->comm_kind == LBFGS_HIP_COMM_P2P;
     if (in_kernel_exchange) red.p2p = next_p2p(ctx);  // the last workgroup closes the reduction itself
     if (Op::NRED > 0 && Op::NRED <= RED_PTRS) {
-        // totals are final inside the kernel (one rank, or in-kernel exchange): mirror them to the host
+        // totals are final inside the kernel (one rank, or in-kernel exchange): mirror them to the host -- unless every
+        // destination is one of the private slots past the public board (the two-loop's inner dot products), which
+        // the host can never ask for: those kernels skip the two PCIe stores and the sequence word
         const bool final_in_kernel = ctx->comm_kind == LBFGS_HIP_COMM_NONE || in_kernel_exchange;
+        bool any_public = false;
         for (int k = 0; k < Op::NRED; ++k) {
             const long idx = red_out[k] - ctx->board;
-            if (idx >= 0 && idx < LBFGS_HIP_BOARD_SLOTS + 2) ctx->mirror_valid[idx] = final_in_kernel && ctx->mirror;
+            if (idx >= 0 && idx < LBFGS_HIP_BOARD_SLOTS) any_public = true;
         }
-        if (final_in_kernel && ctx->mirror) {
+        const bool mirrored = final_in_kernel && ctx->mirror && any_public;
+        for (int k = 0; k < Op::NRED; ++k) {
+            const long idx = red_out[k] - ctx->board;
+            if (idx >= 0 && idx < LBFGS_HIP_BOARD_SLOTS + 2) ctx->mirror_valid[idx] = mirrored;
+        }
+        if (mirrored) {
             red.mirror.host_board = ctx->mirror_dev;
             red.mirror.board = ctx->board;
             red.mirror.host_seq = reinterpret_cast<unsigned long long*>(ctx->mirror_dev + LBFGS_HIP_BOARD_SLOTS + 2);
@@ -366,12 +375,22 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out,
     constexpr int MAP = tuning<Op>::MAP, UNR = tuning<Op>::UNR;
     const int grid = (kclass >= 0 && kclass < 16 && ctx->grid_class[kclass] > 0)
                          ? std::min(MAX_GRID, ctx->grid_class[kclass]) : grid_for(ctx, tuning<Op>::GRID_X32);
-    // streaming (`nt`) hints once the running vector cannot stay in the 256 MiB Infinity Cache next to the others
-    const bool streaming = n * sizeof(double) >= ctx->nt_threshold_bytes;
+    // Cache hints by vector size (profiles/r02_shard_cache_hints.log):
+    //   >= 128 MiB  `nt` (streaming) on loads and stores: nothing can stay in the 256 MiB Infinity Cache anyway;
+    //   64-128 MiB  `nt` on the stores only: the loads keep finding the running vector in the Infinity Cache, while
+    //               streamed stores leave fewer dirty lines in the L2s to write back when the kernel ends (+2.3 % on
+    //               whole iterations at 100 MB shards, +1.2 % at 80 MB, nothing at 24 MB, -2.5 % at 8 MB);
+    //   below       plain.
+    const size_t vbytes = n * sizeof(double);
+    const bool streaming = vbytes >= ctx->nt_threshold_bytes;
+    const bool stream_stores = !streaming && vbytes >= ctx->nt_store_threshold_bytes && Op::NOUT > 0;
     {
         ProfScope ps(ctx, kclass);
         if (streaming)
             hipLaunchKernelGGL((stream_kernel<Op, UNR, LH_NT_IN, LH_NT_OUT, MAP>), dim3(grid), dim3(BLOCK), 0, ctx->stream,
+                               op, n, ctx->shard.offset, red);
+        else if (stream_stores)
+            hipLaunchKernelGGL((stream_kernel<Op, UNR, 0u, LH_NT_OUT, MAP>), dim3(grid), dim3(BLOCK), 0, ctx->stream,
                                op, n, ctx->shard.offset, red);
         else
             hipLaunchKernelGGL((stream_kernel<Op, UNR, 0u, 0u, MAP>), dim3(grid), dim3(BLOCK), 0, ctx->stream,
@@ -899,6 +918,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     ctx->grid_default = std::max(1, prop.multiProcessorCount * 27 / 32);
     ctx->gram_grid = prop.multiProcessorCount;  // the 21-stream Gram rows pass peaks at one workgroup per CU
     if (const char* e = getenv("LBFGS_HIP_NT_THRESHOLD_MB")) ctx->nt_threshold_bytes = (size_t)atoll(e) << 20;
+    if (const char* e = getenv("LBFGS_HIP_NT_STORE_THRESHOLD_MB")) ctx->nt_store_threshold_bytes = (size_t)atoll(e) << 20;
     if (const char* e = getenv("LBFGS_HIP_GRAM_GRID")) ctx->gram_grid = std::min(MAX_GRID, std::max(0, atoi(e)));
     for (int k = 0; k < LBFGS_HIP_K_CLASSES && k < 16; ++k) {
         char name[32];

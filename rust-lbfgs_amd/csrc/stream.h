@@ -291,7 +291,13 @@ __device__ __forceinline__ void grid_reduce(double (&acc)[NRED], const RedCtl& r
                         __hip_atomic_store(red.mirror.host_err, (unsigned long long)e, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_SYSTEM);
                 }
-                __hip_atomic_store(red.mirror.host_seq, red.mirror.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                // Order "results, then sequence word" WITHOUT a release fence: a system-scope release makes the compiler
+                // write back this XCD's whole L2 (buffer_wbl2 sc0 sc1) -- megabytes of the running vector's dirty lines,
+                // microseconds on every reducing kernel -- although nothing the host reads lives in L2: the stores above
+                // are system-scope atomics (written through).  Waiting for them to complete (vmcnt) before issuing the
+                // sequence store gives the same order at the host.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(red.mirror.host_seq, red.mirror.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }

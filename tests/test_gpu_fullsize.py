@@ -79,12 +79,14 @@ def test_two_loop_properties_at_full_size(n):
 
 
 def test_streaming_hint_kernels_equal_plain_kernels(monkeypatch):
-    """Above 256 MiB per vector the library launches the `nt`-hinted instantiations.  Force them at a
-    small size and require bit-identical results to the plain ones (same arithmetic, same order)."""
+    """From 128 MiB per vector the library launches the `nt`-hinted instantiations, from 64 MiB the ones with `nt` on the
+    stores only.  Force each at a small size and require bit-identical results to the plain ones (same arithmetic,
+    same order)."""
     n = 3_000_017
     out = {}
-    for mode, thr in (("plain", "1000000"), ("nt", "0")):
+    for mode, thr, thr_st in (("plain", "1000000", "1000000"), ("nt", "0", "0"), ("nt_stores", "1000000", "0")):
         monkeypatch.setenv("LBFGS_HIP_NT_THRESHOLD_MB", thr)
+        monkeypatch.setenv("LBFGS_HIP_NT_STORE_THRESHOLD_MB", thr_st)
         with R.Context(n) as ctx:
             hist = H.History(ctx, 4)
             g, d, tmp, x, xp = (DeviceVec(ctx) for _ in range(5))
@@ -108,8 +110,9 @@ def test_streaming_hint_kernels_equal_plain_kernels(monkeypatch):
             hist.free()
             for v in (g, d, tmp, x, xp):
                 v.free()
-    for a, b in zip(out["plain"], out["nt"]):
-        assert np.array_equal(a, b)
+    for other in ("nt", "nt_stores"):
+        for a, b in zip(out["plain"], out[other]):
+            assert np.array_equal(a, b)
 
 
 def test_owlqn_properties_at_config3_size():
