@@ -22,6 +22,7 @@ __global__ __launch_bounds__(BLOCK) void gram_rows_kernel(const GramRowsArgs<M> 
     static_assert(NK <= MAX_RED, "partials buffer overflow");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c_lo = wave * CPW;
+    const unsigned int p2p_epoch0 = red.p2p.world > 1 ? red.ctr->p2p_epoch : 0u;  // read in the prologue (stream.h)
     double acc[3][CPW];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(BLOCK) void gram_rows_kernel(const GramRowsArgs<M> 
     __syncthreads();
     if (red.p2p.world > 1) {  // close the NK sums across ranks before the kernel ends
         __shared__ unsigned int s_bits[P2P_MAX_WORLD][MAX_RED][2];
-        p2p_exchange(red.p2p, s_vals, NK, s_bits);
+        p2p_exchange(red.p2p, p2p_epoch0, s_vals, NK, s_bits);
+        if (threadIdx.x == 0) red.ctr->p2p_epoch = next_epoch(p2p_epoch0);
     }
     for (int k = threadIdx.x; k < NK; k += BLOCK) red.out_contig[k] = s_vals[k];
     if (threadIdx.x == 0) __hip_atomic_store(red.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -12,7 +12,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
+#include <map>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -82,6 +84,7 @@ std::string g_create_error;  // last error of a failed ctx_create (no ctx to hol
 // sums produced by a kernel are exchanged by that kernel's last workgroup and never come here.
 struct P2PArgs {
     P2PCtl ctl;
+    DevCounters* ctr;
     double* val[MAX_RED];
     int count;
 };
@@ -91,8 +94,10 @@ __global__ __launch_bounds__(64) void p2p_allreduce_kernel(const P2PArgs a) {
     __shared__ unsigned int bits[P2P_MAX_WORLD][MAX_RED][2];
     if ((int)threadIdx.x < a.count) vals[threadIdx.x] = *a.val[threadIdx.x];
     __syncthreads();
-    p2p_exchange(a.ctl, vals, a.count, bits);
+    const unsigned int epoch = a.ctr->p2p_epoch;
+    p2p_exchange(a.ctl, epoch, vals, a.count, bits);
     if ((int)threadIdx.x < a.count) *a.val[threadIdx.x] = vals[threadIdx.x];
+    if (threadIdx.x == 0) a.ctr->p2p_epoch = next_epoch(epoch);
 }
 
 // ------------------------------------------------------------------------------------ objects
@@ -144,7 +149,7 @@ struct lbfgs_hip_ctx {
     // P2P communicator
     unsigned long long* p2p_mbox[P2P_MAX_WORLD] = {nullptr};  // [rank] -> that rank's mailbox (own entry = local)
     bool p2p_opened[P2P_MAX_WORLD] = {false};
-    unsigned int p2p_epoch = 0;
+    unsigned long long p2p_count = 0;     // P2P exchanges enqueued so far (shadow of DevCounters::p2p_epoch)
     unsigned int* p2p_err = nullptr;      // device error flag: 1 = a P2P spin timed out, 2 = a workgroup's partials never arrived
     unsigned long long p2p_timeout_ticks = 0;
     double* board = nullptr;         // LBFGS_HIP_BOARD_SLOTS doubles + 2 ping-pong dots
@@ -154,7 +159,15 @@ struct lbfgs_hip_ctx {
     size_t lj_scratch_bytes = 0;
     struct LjCells* lj_cells = nullptr;   // LJ_CELLS: the rebuildable neighbour structure (allocated on demand)
     unsigned long long* gran = nullptr;   // tagged partial granules [MAX_RED][MAX_GRID][2] (stream.h)
-    unsigned int red_epoch = 0;           // tag of the latest reducing launch (never 0)
+    DevCounters* dev_ctr = nullptr;       // device-resident sequence numbers (stream.h); the three fields below shadow them
+    unsigned long long red_count = 0;     // tagged reducing launches enqueued so far: the next one uses tag (red_count % (2^32-1)) + 1
+    // hipGraph replay of the two-loop recursion (lbfgs_hip_two_loop*).  OFF by default: measured on MI355X / ROCm 7.2
+    // (profiles/r02_graph_vs_eager.log) one hipGraphLaunch of the 2m-kernel chain is 0-2 % SLOWER than 2m eager launches
+    // at every size from n = 1e5 to 1.25e7 -- the chain is bound by the GPU-side cost of a dependent kernel boundary,
+    // not by the host's launches.  LBFGS_HIP_GRAPH=1 (or LBFGS_HIP_GRAPH_MAX_MB) turns it on.
+    size_t graph_max_bytes = 0;           // vectors up to this size replay their two-loop as a graph (0 = never)
+    bool capturing = false;
+    std::vector<std::pair<int, bool>> capture_touch;  // mirror_valid assignments made while capturing
     int grid_class[16] = {0};             // LBFGS_HIP_GRID_K<class>=N: grid override per kernel class (in-situ tuning)
     bool handoff_ticket = false;          // LBFGS_HIP_HANDOFF=ticket: the arrival-counter form for every kernel (A/B, fallback)
     double* pinned = nullptr;        // host staging, LBFGS_HIP_BOARD_SLOTS doubles
@@ -180,9 +193,19 @@ struct lbfgs_hip_vec {
     double* p;
 };
 
+// One recorded two-loop recursion: the hipGraph of its kernels plus what launching them does to the host-side shadows.
+struct TwoLoopGraph {
+    hipGraphExec_t exec = nullptr;
+    unsigned long long tagged_launches = 0, mirrored_launches = 0, p2p_exchanges = 0;
+    std::vector<std::pair<int, bool>> mirror_touch;
+    int new_end = 0;
+};
+typedef std::array<uint64_t, 16> TwoLoopKey;
+
 struct lbfgs_hip_history {
     lbfgs_hip_ctx* ctx;
     int m;
+    std::map<TwoLoopKey, TwoLoopGraph> graphs;  // keyed by everything that shapes the launch sequence (two_loop_impl)
     std::vector<lbfgs_hip_vec*> s, y;
     double* ys;     // device, m
     double* alpha;  // device, m
@@ -252,11 +275,17 @@ int fill_handoff(lbfgs_hip_ctx* ctx, RedCtl& red) {
     red.gran = ctx->gran;
     red.err = ctx->p2p_err;
     red.timeout_ticks = 1000000000ULL;  // 10 s of the 100 MHz wall clock
-    if (++ctx->red_epoch == 0u) {  // 2^32 launches: no granule of the buffer may still carry a tag that comes round again
-        HIP_TRY(ctx, hipMemsetAsync(ctx->gran, 0, (size_t)MAX_RED * MAX_GRID * 2 * sizeof(unsigned long long), ctx->stream));
-        ctx->red_epoch = 1u;
+    red.ctr = ctx->dev_ctr;
+    red.tagged = ctx->handoff_ticket ? 0u : 1u;
+    if (red.tagged) {
+        // the device walks the tags 1, 2, ..., 2^32-1, 1, ... by itself; when they come round, no granule of the buffer
+        // may still carry a tag from the previous round
+        if (ctx->red_count > 0 && ctx->red_count % 0xFFFFFFFFull == 0) {
+            if (ctx->capturing) return fail(ctx, LBFGS_HIP_ERR_HIP, "tag wrap inside a graph capture");
+            HIP_TRY(ctx, hipMemsetAsync(ctx->gran, 0, (size_t)MAX_RED * MAX_GRID * 2 * sizeof(unsigned long long), ctx->stream));
+        }
+        ctx->red_count += 1;
     }
-    red.epoch = ctx->handoff_ticket ? 0u : ctx->red_epoch;
     return LBFGS_HIP_OK;
 }
 
@@ -266,7 +295,7 @@ P2PCtl next_p2p(lbfgs_hip_ctx* ctx) {
     for (int r = 0; r < ctx->shard.world && r < P2P_MAX_WORLD; ++r) c.mbox[r] = ctx->p2p_mbox[r];
     c.world = ctx->shard.world;
     c.rank = ctx->shard.rank;
-    c.epoch = ++ctx->p2p_epoch;
+    ctx->p2p_count += 1;
     c.err = ctx->p2p_err;
     c.timeout_ticks = ctx->p2p_timeout_ticks;
     return c;
@@ -303,6 +332,7 @@ int allreduce(lbfgs_hip_ctx* ctx, double* const* ptrs, int count) {
     if (ctx->comm_kind == LBFGS_HIP_COMM_P2P) {
         P2PArgs a{};
         a.ctl = next_p2p(ctx);
+        a.ctr = ctx->dev_ctr;
         for (int i = 0; i < count; ++i) a.val[i] = ptrs[i];
         a.count = count;
         hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(1), dim3(64), 0, ctx->stream, a);
@@ -361,13 +391,16 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out,
         const bool mirrored = final_in_kernel && ctx->mirror && any_public;
         for (int k = 0; k < Op::NRED; ++k) {
             const long idx = red_out[k] - ctx->board;
-            if (idx >= 0 && idx < LBFGS_HIP_BOARD_SLOTS + 2) ctx->mirror_valid[idx] = mirrored;
+            if (idx >= 0 && idx < LBFGS_HIP_BOARD_SLOTS + 2) {
+                ctx->mirror_valid[idx] = mirrored;
+                if (ctx->capturing) ctx->capture_touch.emplace_back((int)idx, mirrored);
+            }
         }
         if (mirrored) {
             red.mirror.host_board = ctx->mirror_dev;
             red.mirror.board = ctx->board;
             red.mirror.host_seq = reinterpret_cast<unsigned long long*>(ctx->mirror_dev + LBFGS_HIP_BOARD_SLOTS + 2);
-            red.mirror.seq = ++ctx->mirror_seq;
+            ctx->mirror_seq += 1;  // (the device counts the same way: DevCounters::mirror_seq)
             red.mirror.host_err = reinterpret_cast<unsigned long long*>(ctx->mirror_dev + LBFGS_HIP_BOARD_SLOTS + 3);
             red.mirror.slots = LBFGS_HIP_BOARD_SLOTS + 2;
         }
@@ -918,6 +951,8 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     ctx->grid_default = std::max(1, prop.multiProcessorCount * 27 / 32);
     ctx->gram_grid = prop.multiProcessorCount;  // the 21-stream Gram rows pass peaks at one workgroup per CU
     if (const char* e = getenv("LBFGS_HIP_NT_THRESHOLD_MB")) ctx->nt_threshold_bytes = (size_t)atoll(e) << 20;
+    if (const char* e = getenv("LBFGS_HIP_GRAPH")) ctx->graph_max_bytes = atoi(e) ? ~(size_t)0 : 0;
+    if (const char* e = getenv("LBFGS_HIP_GRAPH_MAX_MB")) ctx->graph_max_bytes = (size_t)atoll(e) << 20;
     if (const char* e = getenv("LBFGS_HIP_NT_STORE_THRESHOLD_MB")) ctx->nt_store_threshold_bytes = (size_t)atoll(e) << 20;
     if (const char* e = getenv("LBFGS_HIP_GRAM_GRID")) ctx->gram_grid = std::min(MAX_GRID, std::max(0, atoi(e)));
     for (int k = 0; k < LBFGS_HIP_K_CLASSES && k < 16; ++k) {
@@ -934,6 +969,11 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     CTX_TRY(hipMemsetAsync(ctx->ticket, 0, 64, ctx->stream));
     CTX_TRY(hipMalloc(&ctx->gran, (size_t)MAX_RED * MAX_GRID * 2 * sizeof(unsigned long long)));
     CTX_TRY(hipMemsetAsync(ctx->gran, 0, (size_t)MAX_RED * MAX_GRID * 2 * sizeof(unsigned long long), ctx->stream));
+    {
+        const DevCounters init{1u, 1u, 0ull};
+        CTX_TRY(hipMalloc(&ctx->dev_ctr, 4096));  // (a page of its own: nothing else shares its cache lines)
+        CTX_TRY(hipMemcpy(ctx->dev_ctr, &init, sizeof(init), hipMemcpyHostToDevice));
+    }
     CTX_TRY(hipMalloc(&ctx->p2p_err, 64));  // device error flag: 1 = a P2P peer never arrived, 2 = a partial never arrived
     CTX_TRY(hipMemsetAsync(ctx->p2p_err, 0, 64, ctx->stream));
     CTX_TRY(hipHostMalloc(&ctx->pinned, (LBFGS_HIP_BOARD_SLOTS + 1) * sizeof(double), hipHostMallocDefault));
@@ -1030,6 +1070,7 @@ void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* ctx) {
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     if (ctx->gran) (void)hipFree(ctx->gran);
+    if (ctx->dev_ctr) (void)hipFree(ctx->dev_ctr);
     if (ctx->lj_scratch) (void)hipFree(ctx->lj_scratch);
     if (ctx->lj_cells) {
         ctx->lj_cells->release();
@@ -1353,6 +1394,8 @@ void lbfgs_hip_history_destroy(lbfgs_hip_history* h) {
         (void)hipFree(h->ys);
     }
     if (h->gram) (void)hipFree(h->gram);
+    for (auto& kv : h->graphs)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     delete h;
 }
 
@@ -1447,6 +1490,15 @@ int lbfgs_hip_two_loop_owlqn(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs
 
 }  // extern "C"
 
+static int two_loop_eager(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
+                          int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end,
+                          bool owl, uint64_t owl_start, uint64_t owl_end);
+
+// The recursion is a chain of 2*bound kernels whose arguments depend only on (ring position, bound, operand addresses,
+// slots): with the launch-to-launch sequence numbers in device memory (stream.h DevCounters) the chain can be recorded
+// once per such combination and replayed with ONE hipGraphLaunch -- the host stops paying a launch per kernel, which
+// is what bounds iterations/s on vectors of a few MB.  Recording = stream capture of the eager path, so both paths
+// launch the very same kernels with the very same arguments (results are bitwise equal; a test checks it).
 static int two_loop_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
                          int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end,
                          bool owl, uint64_t owl_start, uint64_t owl_end) {
@@ -1454,6 +1506,66 @@ static int two_loop_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip
     if (!h || !d || !g || d->ctx != h->ctx || g->ctx != h->ctx || end < 0 || end >= h->m || !new_end)
         return LBFGS_HIP_ERR_ARG;
     if (!slot_ok(gamma_num_slot, 1) || !slot_ok(gamma_den_slot, 1) || !slot_ok(dnorm_slot, 2)) return LBFGS_HIP_ERR_ARG;
+    lbfgs_hip_ctx* ctx = h->ctx;
+    const uint64_t bound = std::min<uint64_t>((uint64_t)h->m, k);
+    const bool graphable = bound > 0 && !ctx->prof_on && !ctx->capturing &&
+                           (size_t)ctx->shard.n_local * sizeof(double) <= ctx->graph_max_bytes &&
+                           (ctx->comm_kind == LBFGS_HIP_COMM_NONE || ctx->comm_kind == LBFGS_HIP_COMM_P2P) &&
+                           // (a tag wrap needs a memset between two launches: take the eager path across it)
+                           ctx->red_count % 0xFFFFFFFFull + 4ull * (uint64_t)h->m + 8ull < 0xFFFFFFFFull;
+    if (!graphable)
+        return two_loop_eager(h, d, g, k, end, gamma_num_slot, gamma_den_slot, dnorm_slot, first_dot_slot, new_end, owl,
+                              owl_start, owl_end);
+    uint64_t hp = 1469598103934665603ull;  // FNV-1a over the history's vector addresses (they never change; cheap insurance)
+    for (int j = 0; j < h->m; ++j)
+        for (const double* p : {h->s[j]->p, h->y[j]->p}) hp = (hp ^ (uint64_t)(uintptr_t)p) * 1099511628211ull;
+    const TwoLoopKey key = {(uint64_t)end, bound, (uint64_t)(uintptr_t)g->p, (uint64_t)(uintptr_t)d->p, (uint64_t)gamma_num_slot,
+                            (uint64_t)gamma_den_slot, (uint64_t)dnorm_slot, (uint64_t)(int64_t)first_dot_slot, (uint64_t)owl,
+                            owl_start, owl_end, (uint64_t)ctx->grid_override, hp, (uint64_t)ctx->handoff_ticket,
+                            (uint64_t)ctx->shard.n_local, (uint64_t)ctx->nt_threshold_bytes ^ ((uint64_t)ctx->nt_store_threshold_bytes << 1)};
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
+        // record: the eager path under stream capture (nothing executes; the host-side shadows advance as usual)
+        TwoLoopGraph tg;
+        const unsigned long long r0 = ctx->red_count, m0 = ctx->mirror_seq, p0 = ctx->p2p_count;
+        ctx->capture_touch.clear();
+        HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        ctx->capturing = true;
+        int ne = end;
+        const int rc = two_loop_eager(h, d, g, k, end, gamma_num_slot, gamma_den_slot, dnorm_slot, first_dot_slot, &ne, owl,
+                                      owl_start, owl_end);
+        ctx->capturing = false;
+        hipGraph_t graph = nullptr;
+        const hipError_t e_end = hipStreamEndCapture(ctx->stream, &graph);
+        if (rc != LBFGS_HIP_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (e_end != hipSuccess || !graph) return fail(ctx, LBFGS_HIP_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e_end));
+        const hipError_t e_inst = hipGraphInstantiate(&tg.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e_inst != hipSuccess) return fail(ctx, LBFGS_HIP_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e_inst));
+        tg.tagged_launches = ctx->red_count - r0;
+        tg.mirrored_launches = ctx->mirror_seq - m0;
+        tg.p2p_exchanges = ctx->p2p_count - p0;
+        tg.mirror_touch = ctx->capture_touch;
+        tg.new_end = ne;
+        it = h->graphs.emplace(key, std::move(tg)).first;
+    } else {
+        const TwoLoopGraph& tg = it->second;  // replay: what the launches do to the shadows, then the launches themselves
+        ctx->red_count += tg.tagged_launches;
+        ctx->mirror_seq += tg.mirrored_launches;
+        ctx->p2p_count += tg.p2p_exchanges;
+        for (const auto& t : tg.mirror_touch) ctx->mirror_valid[t.first] = t.second;
+    }
+    *new_end = it->second.new_end;
+    HIP_TRY(ctx, hipGraphLaunch(it->second.exec, ctx->stream));
+    return LBFGS_HIP_OK;
+}
+
+static int two_loop_eager(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
+                          int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end,
+                          bool owl, uint64_t owl_start, uint64_t owl_end) {
     lbfgs_hip_ctx* ctx = h->ctx;
     ProfScope whole(ctx, LBFGS_HIP_K_TWOLOOP_ALL);
     const int m = h->m;

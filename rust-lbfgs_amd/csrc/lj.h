@@ -43,6 +43,7 @@ __global__ __launch_bounds__(BLOCK) void lj_allpairs_kernel(const double* __rest
                                                              const uint32_t natoms, const uint32_t ntiles,
                                                              const uint32_t jspan, const RedCtl red) {
     __shared__ double tile[3 * BLOCK];
+    const DevCounters c0 = load_counters(red);
     const uint32_t it = blockIdx.x % ntiles, js = blockIdx.x / ntiles;
     const uint32_t i = it * BLOCK + threadIdx.x;
     const bool live = i < natoms;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(BLOCK) void lj_allpairs_kernel(const double* __rest
         g[3 * (size_t)i] = fx; g[3 * (size_t)i + 1] = fy; g[3 * (size_t)i + 2] = fz;
     }
     double acc[1] = {0.5 * e};  // every pair was seen from both ends
-    grid_reduce<1>(acc, red);
+    grid_reduce<1>(acc, red, c0);
 }
 
 // g = slice_0 + slice_1 + ... + slice_{S-1}, in that order
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(BLOCK) void lj_neighbors_kernel(const double* __res
                                                               const int32_t* __restrict__ nbr, const uint32_t max_nbr,
                                                               const uint32_t natoms, const double rc2, const double eshift,
                                                               const RedCtl red) {
+    const DevCounters c0 = load_counters(red);
     double e = 0.0;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < natoms; i += gridDim.x * BLOCK) {
         const double xi = x[3 * (size_t)i], yi = x[3 * (size_t)i + 1], zi = x[3 * (size_t)i + 2];
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(BLOCK) void lj_neighbors_kernel(const double* __res
         g[3 * (size_t)i] = fx; g[3 * (size_t)i + 1] = fy; g[3 * (size_t)i + 2] = fz;
     }
     double acc[1] = {0.5 * e};
-    grid_reduce<1>(acc, red);
+    grid_reduce<1>(acc, red, c0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -339,6 +341,7 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_eval_kernel(const double* __re
                                                                const double* __restrict__ xref, const uint32_t natoms,
                                                                const double rc2, const double eshift,
                                                                const double half_skin2, const RedCtl red) {
+    const DevCounters c0 = load_counters(red);
     double e = 0.0, stale = 0.0;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < natoms; i += gridDim.x * BLOCK) {
         const double xi = x[3 * (size_t)i], yi = x[3 * (size_t)i + 1], zi = x[3 * (size_t)i + 2];
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_eval_kernel(const double* __re
         g[3 * (size_t)i] = fx; g[3 * (size_t)i + 1] = fy; g[3 * (size_t)i + 2] = fz;
     }
     double acc[2] = {0.5 * e, stale};
-    grid_reduce<2>(acc, red);
+    grid_reduce<2>(acc, red, c0);
 }
 
 #pragma clang fp contract(off)

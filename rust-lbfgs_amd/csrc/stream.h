@@ -58,7 +58,6 @@ constexpr size_t P2P_MBOX_WORDS = (size_t)P2P_RING * P2P_MAX_WORLD * MAX_RED * 2
 struct P2PCtl {
     unsigned long long* mbox[P2P_MAX_WORLD];  // [rank] -> that rank's mailbox (own entry = local)
     int world, rank;                          // world <= 1: no exchange
-    unsigned int epoch;                       // reduction sequence number, identical on all ranks, never 0
     unsigned int* err;
     unsigned long long timeout_ticks;         // wall_clock64 ticks (100 MHz)
 };
@@ -69,17 +68,28 @@ struct P2PCtl {
 struct MirrorCtl {
     double* host_board;             // device address of the host-mapped mirror (nullptr = off)
     const double* board;            // the device board (to turn an output pointer into a slot index)
-    unsigned long long* host_seq;   // device address of the host-mapped sequence word
-    unsigned long long seq;         // this launch's sequence number
+    unsigned long long* host_seq;   // device address of the host-mapped sequence word (value: DevCounters::mirror_seq)
     unsigned long long* host_err;   // device address of the host-mapped copy of the P2P timeout flag
     int slots;                      // mirrored slots
 };
+
+// Launch-to-launch sequence numbers live in DEVICE memory, not in kernel arguments: every workgroup reads them when it
+// starts and the reducer (the last workgroup) advances them before the kernel ends -- stream order makes the next kernel
+// see the new values.  A kernel's arguments are then the same every time it is launched with the same operands, which
+// is what lets a whole two-loop recursion be replayed as a hipGraph.  The host keeps a shadow of each counter.
+struct DevCounters {
+    unsigned int red_epoch;         // tag of the NEXT tagged hand-off: never 0, distinct from every tag still in `gran`
+    unsigned int p2p_epoch;         // epoch of the NEXT P2P exchange: identical on all ranks, never 0
+    unsigned long long mirror_seq;  // sequence number of the LATEST mirrored launch
+};
+__device__ __forceinline__ unsigned int next_epoch(unsigned int e) { return (e + 1u == 0u) ? 1u : e + 1u; }
 
 struct RedCtl {
     double* partials;        // [MAX_RED][MAX_GRID] workgroup partial sums   (ticket hand-off: more than RED_PTRS sums)
     unsigned int* ticket;    // arrival counter, self-resetting
     unsigned long long* gran;     // [MAX_RED][MAX_GRID][2] tagged granules  (tagged hand-off: up to RED_PTRS sums)
-    unsigned int epoch;           // this launch's tag, never 0, distinct from every tag still in `gran`; 0 = use the ticket form
+    DevCounters* ctr;             // the context's counters
+    unsigned int tagged;          // 1 = tagged hand-off (tag = ctr->red_epoch), 0 = the ticket form
     unsigned int* err;            // device error flag (2 = a partial never arrived)
     unsigned long long timeout_ticks;  // bound on the reducer's spin (wall_clock64 ticks, 100 MHz)
     double* out[RED_PTRS];   // where the last workgroup puts the totals (NRED <= RED_PTRS) ...
@@ -96,7 +106,10 @@ __device__ __forceinline__ size_t p2p_word(unsigned epoch, int src_rank, int k, 
 
 // Called by ALL threads of one workgroup (>= 64 threads).  vals[0..count) in LDS: in = this rank's sums,
 // out = the global sums.  bits: LDS scratch [P2P_MAX_WORLD][MAX_RED][2].
-__device__ __forceinline__ void p2p_exchange(const P2PCtl& c, double* vals, int count,
+// `epoch` = this exchange's sequence number (DevCounters::p2p_epoch as read in the kernel's prologue).  It is a separate
+// argument on purpose: a local copy of P2PCtl with the epoch patched in would be indexed dynamically (mbox[p]) and
+// land in scratch memory -- 176 bytes per lane and +12 us of dispatch cost on EVERY reducing kernel (measured).
+__device__ __forceinline__ void p2p_exchange(const P2PCtl& c, const unsigned int epoch, double* vals, int count,
                                              unsigned int (*bits)[MAX_RED][2]) {
     const int per_rank = count * 2, total = c.world * per_rank;
     if (threadIdx.x < 64) {
@@ -105,17 +118,17 @@ __device__ __forceinline__ void p2p_exchange(const P2PCtl& c, double* vals, int 
             const int p = i / per_rank, k = (i % per_rank) >> 1, h = i & 1;
             const unsigned long long b = (unsigned long long)__double_as_longlong(vals[k]);
             const unsigned int data = h ? (unsigned int)(b >> 32) : (unsigned int)b;
-            __hip_atomic_store(c.mbox[p] + p2p_word(c.epoch, c.rank, k, h), ((unsigned long long)c.epoch << 32) | data,
+            __hip_atomic_store(c.mbox[p] + p2p_word(epoch, c.rank, k, h), ((unsigned long long)epoch << 32) | data,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         const long long t0 = wall_clock64();
         for (int i = lane; i < total; i += 64) {  // collect what rank r stored for me
             const int r = i / per_rank, k = (i % per_rank) >> 1, h = i & 1;
-            const unsigned long long* src = c.mbox[c.rank] + p2p_word(c.epoch, r, k, h);
+            const unsigned long long* src = c.mbox[c.rank] + p2p_word(epoch, r, k, h);
             unsigned long long g;
             for (;;) {
                 g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((unsigned int)(g >> 32) == c.epoch) break;
+                if ((unsigned int)(g >> 32) == epoch) break;
                 if ((unsigned long long)(wall_clock64() - t0) > c.timeout_ticks) {
                     atomicExch(c.err, 1u);
                     break;
@@ -184,20 +197,34 @@ __device__ __forceinline__ void block_sum(double (&acc)[NRED], double (*lds)[WAV
     }
 }
 
+// the counters as every workgroup sees them when it STARTS: one 16-byte load issued in the kernel's prologue, so its
+// latency hides behind the sweep instead of sitting in every workgroup's epilogue
+__device__ __forceinline__ DevCounters load_counters(const RedCtl& red) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const u4 v = *reinterpret_cast<const u4*>(red.ctr);
+    DevCounters c;
+    c.red_epoch = v.x;
+    c.p2p_epoch = v.y;
+    c.mirror_seq = ((unsigned long long)v.w << 32) | v.z;
+    return c;
+}
+
 template <int NRED>
-__device__ __forceinline__ void grid_reduce(double (&acc)[NRED], const RedCtl& red) {
+__device__ __forceinline__ void grid_reduce(double (&acc)[NRED], const RedCtl& red, const DevCounters& c0) {
     __shared__ double lds[NRED][WAVES];
     block_sum<NRED>(acc, lds);
     const unsigned int G = gridDim.x;
     double tot[NRED];
-    if (NRED <= RED_PTRS && red.epoch != 0u) {  // (uniform over the grid)
+    const bool tagged = NRED <= RED_PTRS && red.tagged != 0u;  // (uniform over the grid)
+    const unsigned int epoch = c0.red_epoch;   // (the reducer advances the counter only after every partial has arrived)
+    if (tagged) {
         // ---- tagged hand-off ----
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int k = 0; k < NRED; ++k) {
                 const unsigned long long b = (unsigned long long)__double_as_longlong(acc[k]);
                 unsigned long long* g = red.gran + ((size_t)k * MAX_GRID + blockIdx.x) * 2;
-                const unsigned long long tag = (unsigned long long)red.epoch << 32;
+                const unsigned long long tag = (unsigned long long)epoch << 32;
                 __hip_atomic_store(g, tag | (b & 0xffffffffULL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(g + 1, tag | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -219,7 +246,7 @@ __device__ __forceinline__ void grid_reduce(double (&acc)[NRED], const RedCtl& r
                 }
 #pragma unroll
                 for (int k = 0; k < NRED; ++k)
-                    ok = ok && (unsigned int)(lo[k] >> 32) == red.epoch && (unsigned int)(hi[k] >> 32) == red.epoch;
+                    ok = ok && (unsigned int)(lo[k] >> 32) == epoch && (unsigned int)(hi[k] >> 32) == epoch;
                 if (ok) break;
                 if ((unsigned long long)(wall_clock64() - t0) > red.timeout_ticks) {
                     atomicExch(red.err, 2u);
@@ -262,13 +289,15 @@ __device__ __forceinline__ void grid_reduce(double (&acc)[NRED], const RedCtl& r
             for (int k = 0; k < NRED; ++k) s_vals[k] = tot[k];
         }
         __syncthreads();
-        p2p_exchange(red.p2p, s_vals, NRED, s_bits);
+        p2p_exchange(red.p2p, c0.p2p_epoch, s_vals, NRED, s_bits);
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int k = 0; k < NRED; ++k) tot[k] = s_vals[k];
+            red.ctr->p2p_epoch = next_epoch(c0.p2p_epoch);
         }
     }
     if (threadIdx.x == 0) {
+        if (tagged) red.ctr->red_epoch = next_epoch(epoch);
 #pragma unroll
         for (int k = 0; k < NRED; ++k) {
             if constexpr (NRED <= RED_PTRS) *red.out[k] = tot[k];
@@ -296,8 +325,10 @@ __device__ __forceinline__ void grid_reduce(double (&acc)[NRED], const RedCtl& r
                 // microseconds on every reducing kernel -- although nothing the host reads lives in L2: the stores above
                 // are system-scope atomics (written through).  Waiting for them to complete (vmcnt) before issuing the
                 // sequence store gives the same order at the host.
+                const unsigned long long seq = c0.mirror_seq + 1ull;
+                red.ctr->mirror_seq = seq;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(red.mirror.host_seq, red.mirror.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(red.mirror.host_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -494,12 +525,14 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const Op op, const uint64
                                                         const RedCtl red) {
     constexpr int NRED = Op::NRED;
     static_assert(NRED <= MAX_RED, "partials buffer overflow");
+    DevCounters c0{};
+    if constexpr (NRED > 0) c0 = load_counters(red);
     const typename Op::Coef cf = op.setup();
     double acc[NRED ? NRED : 1];
 #pragma unroll
     for (int k = 0; k < (NRED ? NRED : 1); ++k) acc[k] = 0.0;
     stream_body<Op, UNR, NTI, NTO, MAP, SPAN>(op, cf, n, gofs, acc);
-    if constexpr (NRED > 0) grid_reduce<NRED>(reinterpret_cast<double(&)[NRED]>(acc), red);
+    if constexpr (NRED > 0) grid_reduce<NRED>(reinterpret_cast<double(&)[NRED]>(acc), red, c0);
 }
 
 }  // namespace lh

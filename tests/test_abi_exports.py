@@ -144,3 +144,18 @@ def test_rust_shim_mirrors_the_abi(libs):
         m = re.search(r"\b" + name + r"\s*=\s*(-?\d+)", hdr)
         if m:
             assert int(m.group(1)) == int(val), name
+
+
+def test_no_kernel_uses_scratch_memory(libs):
+    """Every gfx950 kernel of the library keeps its state in registers: a single kernel that spills or indexes a local
+    array dynamically gets a private-segment (scratch) allocation, and on MI355X that costs ~12 us of extra dispatch
+    time on EVERY launch of it (measured in round 2: a by-value copy of a small struct did it).  The build keeps the
+    compiler's per-kernel resource report next to the library."""
+    if not os.path.exists(_build.RESOURCES) or os.path.getmtime(_build.RESOURCES) < os.path.getmtime(_build.HIP_LIB) - 5:
+        _build.build_hip(force=True)
+    txt = open(_build.RESOURCES).read()
+    names = re.findall(r"Function Name: (\S+)", txt)
+    scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", txt)]
+    assert len(names) == len(scratch) >= 100
+    bad = [(n, s) for n, s in zip(names, scratch) if s != 0]
+    assert not bad, bad[:5]

@@ -929,3 +929,27 @@ def test_handoff_forms_are_bitwise_identical(monkeypatch):
     assert o1 == o2
     assert r1 == r2
     assert np.array_equal(x1, x2)
+
+
+@pytest.mark.parametrize("owl", [False, True])
+def test_two_loop_graph_replay_equals_eager_launches(owl, monkeypatch):
+    """The two-loop recorded once per (ring position, bound, operands) and replayed as a hipGraph launches the same
+    kernels with the same arguments as the eager path: whole runs must agree BITWISE (x, f, ||g||, step per iteration),
+    including the first iterations (bound < m: other graphs), the ring wrap and the alternating gx/gp buffers."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("the test double has no graphs")
+    n, iters = 50_001, 45
+    rows = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("LBFGS_HIP_GRAPH", mode)
+        b = R.lbfgs().with_m(5).with_epsilon(0.0).with_max_iterations(iters)
+        obj = objectives.Quadratic()
+        if owl:
+            b, obj = b.with_orthantwise(0.5, 0, None), objectives.Logistic()
+        x = np.zeros(n)
+        rr = []
+        b.minimize(x, obj, lambda p: rr.append((p.niter, p.neval, p.fx, p.xnorm, p.gnorm, p.step)) and False)
+        rows[mode] = (rr, x)
+    assert len(rows["0"][0]) == iters
+    assert rows["0"][0] == rows["1"][0]
+    assert np.array_equal(rows["0"][1], rows["1"][1])

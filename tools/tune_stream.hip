@@ -125,12 +125,18 @@ struct Bufs {
     unsigned* err;
     uint64_t n;
 };
-static unsigned g_epoch = 0;
-// the hand-off part of a RedCtl for the next launch (a fresh tag per launch, as the library does)
+static DevCounters* g_ctr = nullptr;
+// the hand-off part of a RedCtl for the next launch (the tag comes from device counters, as in the library)
 static void handoff(RedCtl& red, const Bufs& b) {
+    if (!g_ctr) {
+        DevCounters init{1u, 1u, 0ull};
+        CK(hipMalloc(&g_ctr, sizeof(DevCounters)));
+        CK(hipMemcpy(g_ctr, &init, sizeof(init), hipMemcpyHostToDevice));
+    }
     red.partials = b.partials; red.ticket = b.ticket; red.gran = b.gran; red.err = b.err;
     red.timeout_ticks = 200000000ULL;
-    red.epoch = ++g_epoch;
+    red.ctr = g_ctr;
+    red.tagged = 1u;
 }
 
 template <class Op, int UNR, unsigned NTL, unsigned NTS, int MAP, int SPAN = 1>
