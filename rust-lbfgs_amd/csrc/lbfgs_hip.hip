@@ -358,38 +358,34 @@ int allreduce(lbfgs_hip_ctx* ctx, double* const* ptrs, int count) {
 #ifndef LH_NT_OUT
 #define LH_NT_OUT ~0u
 #endif
-// ---- launch one operator ---------------------------------------------------------------------
-template <class Op>
-int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out, double* dup_ptr = nullptr,
-           int dup_k = 0) {
-    static_assert(Op::NRED <= MAX_RED, "the partials buffer holds MAX_RED sums per workgroup");
-    RedCtl red{};
+// ---- the reduction-control block of the NEXT launch with NRED sums (hand-off, P2P exchange, host mirror) ------
+int prep_red(lbfgs_hip_ctx* ctx, RedCtl& red, int nred, double* const* red_out, double* dup_ptr, int dup_k,
+             bool* in_kernel_exchange) {
     red.dup_ptr = dup_ptr;
     red.dup_k = dup_k;
-    if (Op::NRED > 0) {
+    if (nred > 0) {
         const int rc_h = fill_handoff(ctx, red);
         if (rc_h != LBFGS_HIP_OK) return rc_h;
     }
-    if constexpr (Op::NRED <= RED_PTRS) {
-        for (int k = 0; k < Op::NRED; ++k) red.out[k] = red_out[k];
+    if (nred <= RED_PTRS) {
+        for (int k = 0; k < nred; ++k) red.out[k] = red_out[k];
     } else {
         red.out_contig = red_out[0];  // caller guarantees red_out[k] == red_out[0] + k
     }
-    const uint64_t n = ctx->shard.n_local;
-    const bool in_kernel_exchange = Op::NRED > 0 && ctx->comm_kind == LBFGS_HIP_COMM_P2P;
-    if (in_kernel_exchange) red.p2p = next_p2p(ctx);  // the last workgroup closes the reduction itself
-    if (Op::NRED > 0 && Op::NRED <= RED_PTRS) {
+    *in_kernel_exchange = nred > 0 && ctx->comm_kind == LBFGS_HIP_COMM_P2P;
+    if (*in_kernel_exchange) red.p2p = next_p2p(ctx);  // the last workgroup closes the reduction itself
+    if (nred > 0 && nred <= RED_PTRS) {
         // totals are final inside the kernel (one rank, or in-kernel exchange): mirror them to the host -- unless every
         // destination is one of the private slots past the public board (the two-loop's inner dot products), which
         // the host can never ask for: those kernels skip the two PCIe stores and the sequence word
-        const bool final_in_kernel = ctx->comm_kind == LBFGS_HIP_COMM_NONE || in_kernel_exchange;
+        const bool final_in_kernel = ctx->comm_kind == LBFGS_HIP_COMM_NONE || *in_kernel_exchange;
         bool any_public = false;
-        for (int k = 0; k < Op::NRED; ++k) {
+        for (int k = 0; k < nred; ++k) {
             const long idx = red_out[k] - ctx->board;
             if (idx >= 0 && idx < LBFGS_HIP_BOARD_SLOTS) any_public = true;
         }
         const bool mirrored = final_in_kernel && ctx->mirror && any_public;
-        for (int k = 0; k < Op::NRED; ++k) {
+        for (int k = 0; k < nred; ++k) {
             const long idx = red_out[k] - ctx->board;
             if (idx >= 0 && idx < LBFGS_HIP_BOARD_SLOTS + 2) {
                 ctx->mirror_valid[idx] = mirrored;
@@ -405,6 +401,21 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out,
             red.mirror.slots = LBFGS_HIP_BOARD_SLOTS + 2;
         }
     }
+    return LBFGS_HIP_OK;
+}
+
+// ---- launch one operator ---------------------------------------------------------------------
+template <class Op>
+int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out, double* dup_ptr = nullptr,
+           int dup_k = 0) {
+    static_assert(Op::NRED <= MAX_RED, "the partials buffer holds MAX_RED sums per workgroup");
+    RedCtl red{};
+    bool in_kernel_exchange = false;
+    {
+        const int rc_p = prep_red(ctx, red, Op::NRED, red_out, dup_ptr, dup_k, &in_kernel_exchange);
+        if (rc_p != LBFGS_HIP_OK) return rc_p;
+    }
+    const uint64_t n = ctx->shard.n_local;
     constexpr int MAP = tuning<Op>::MAP, UNR = tuning<Op>::UNR;
     const int grid = (kclass >= 0 && kclass < 16 && ctx->grid_class[kclass] > 0)
                          ? std::min(MAX_GRID, ctx->grid_class[kclass]) : grid_for(ctx, tuning<Op>::GRID_X32);
@@ -423,10 +434,10 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out,
             hipLaunchKernelGGL((stream_kernel<Op, UNR, LH_NT_IN, LH_NT_OUT, MAP>), dim3(grid), dim3(BLOCK), 0, ctx->stream,
                                op, n, ctx->shard.offset, red);
         else if (stream_stores)
-            hipLaunchKernelGGL((stream_kernel<Op, UNR, 0u, LH_NT_OUT, MAP>), dim3(grid), dim3(BLOCK), 0, ctx->stream,
+            hipLaunchKernelGGL((stream_kernel<Op, UNR, 0u, LH_NT_OUT, MAP, 1, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream,
                                op, n, ctx->shard.offset, red);
-        else
-            hipLaunchKernelGGL((stream_kernel<Op, UNR, 0u, 0u, MAP>), dim3(grid), dim3(BLOCK), 0, ctx->stream,
+        else  // (the two smaller regimes issue the first trip's loads before Op::setup(): stream.h LATE)
+            hipLaunchKernelGGL((stream_kernel<Op, UNR, 0u, 0u, MAP, 1, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream,
                                op, n, ctx->shard.offset, red);
     }
     HIP_TRY(ctx, hipGetLastError());

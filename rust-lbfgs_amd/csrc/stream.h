@@ -433,9 +433,13 @@ __device__ __forceinline__ void do_pair(const Op& op, const typename Op::Coef& c
 // NTI / NTO are bit masks over the input / output streams: bit s set = stream s uses the `nt` hint.
 // The sweep itself: this workgroup's share of the n elements, running sums into acc[].  Shared by the one-launch-
 // per-operator kernel below and by experiments that call it from other kernels (tools/tune_stream.hip).
-template <class Op, int UNR, unsigned NTI, unsigned NTO, int MAP, int SPAN>
-__device__ __forceinline__ void stream_body(const Op& op, const typename Op::Coef& cf, const uint64_t n,
-                                            const uint64_t gofs, double* acc) {
+// `coef()` yields the operator's wave-uniform coefficients (Op::setup(): board reads + a division).  It is called AFTER
+// the first trip's loads have been issued, so that the ~1 us it takes (dependent scalar loads of values the previous
+// kernel has just written) overlaps the first vector loads instead of preceding them.
+// LATE = false keeps the plain order (coefficients, then the sweep): on vectors of hundreds of MB the overlap buys
+// nothing and the longer-lived first-trip registers cost ~0.5 % (profiles/r02_late_setup_ab.log).
+template <class Op, int UNR, unsigned NTI, unsigned NTO, int MAP, int SPAN, bool LATE, class CoefFn>
+__device__ __forceinline__ void stream_sweep(const Op& op, CoefFn coef, const uint64_t n, const uint64_t gofs, double* acc) {
     constexpr int UNROLL = UNR;
     constexpr int NIN = Op::NIN, NOUT = Op::NOUT;
     const uint64_t n2 = n >> 1;                           // 16-byte pairs
@@ -472,7 +476,7 @@ __device__ __forceinline__ void stream_body(const Op& op, const typename Op::Coe
             for (int s = 0; s < NIN; ++s) v[u][s] = ld_masked<NTI>(op.in[s], p, s);
         }
     };
-    auto work_trip = [&](uint64_t t, d2 (&v)[UNROLL][NIN ? NIN : 1]) {
+    auto work_trip = [&](const typename Op::Coef& cf, uint64_t t, d2 (&v)[UNROLL][NIN ? NIN : 1]) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const uint64_t p = chunk_of(t, u) * BLOCK + tid;
@@ -482,7 +486,7 @@ __device__ __forceinline__ void stream_body(const Op& op, const typename Op::Coe
             for (int s = 0; s < NOUT; ++s) st_masked<NTO>(op.out[s], p, w[s], s);
         }
     };
-    auto ragged_trip = [&](uint64_t t) {  // chunk by chunk, pair by pair
+    auto ragged_trip = [&](const typename Op::Coef& cf, uint64_t t) {  // chunk by chunk, pair by pair
         for (int u = 0; u < UNROLL; ++u) {
             const uint64_t c = chunk_of(t, u);
             const uint64_t p = c * BLOCK + tid;
@@ -496,14 +500,21 @@ __device__ __forceinline__ void stream_body(const Op& op, const typename Op::Coe
             }
         }
     };
-    for (uint64_t t = 0; t < trips; ++t) {
+    // first trip: loads first, coefficients second
+    d2 v0[UNROLL][NIN ? NIN : 1];
+    const bool first_full = LATE && trips > 0 && full_trip(0);
+    if (first_full) load_trip(0, v0);
+    const typename Op::Coef cf = coef();
+    if (first_full) work_trip(cf, 0, v0);
+    else if (LATE && trips > 0) ragged_trip(cf, 0);
+    for (uint64_t t = LATE ? 1 : 0; t < trips; ++t) {
         if (full_trip(t)) {
             // fast path: UNROLL full chunks, all loads issued before the first use
             d2 v[UNROLL][NIN ? NIN : 1];
             load_trip(t, v);
-            work_trip(t, v);
+            work_trip(cf, t, v);
         } else {
-            ragged_trip(t);
+            ragged_trip(cf, t);
         }
     }
     // odd n: the last element, scalar (never taken by PAIRWISE ops: their n is even)
@@ -520,18 +531,24 @@ __device__ __forceinline__ void stream_body(const Op& op, const typename Op::Coe
     }
 }
 
-template <class Op, int UNR = UNROLL, unsigned NTI = 0, unsigned NTO = 0, int MAP = 0, int SPAN = 1>
+// the sweep with coefficients that are already known (experiments in tools/tune_stream.hip)
+template <class Op, int UNR, unsigned NTI, unsigned NTO, int MAP, int SPAN>
+__device__ __forceinline__ void stream_body(const Op& op, const typename Op::Coef& cf, const uint64_t n,
+                                            const uint64_t gofs, double* acc) {
+    stream_sweep<Op, UNR, NTI, NTO, MAP, SPAN, false>(op, [&]() { return cf; }, n, gofs, acc);
+}
+
+template <class Op, int UNR = UNROLL, unsigned NTI = 0, unsigned NTO = 0, int MAP = 0, int SPAN = 1, bool LATE = false>
 __global__ __launch_bounds__(BLOCK) void stream_kernel(const Op op, const uint64_t n, const uint64_t gofs,
                                                         const RedCtl red) {
     constexpr int NRED = Op::NRED;
     static_assert(NRED <= MAX_RED, "partials buffer overflow");
     DevCounters c0{};
     if constexpr (NRED > 0) c0 = load_counters(red);
-    const typename Op::Coef cf = op.setup();
     double acc[NRED ? NRED : 1];
 #pragma unroll
     for (int k = 0; k < (NRED ? NRED : 1); ++k) acc[k] = 0.0;
-    stream_body<Op, UNR, NTI, NTO, MAP, SPAN>(op, cf, n, gofs, acc);
+    stream_sweep<Op, UNR, NTI, NTO, MAP, SPAN, LATE>(op, [&]() { return op.setup(); }, n, gofs, acc);
     if constexpr (NRED > 0) grid_reduce<NRED>(reinterpret_cast<double(&)[NRED]>(acc), red, c0);
 }
 
