@@ -159,6 +159,8 @@ struct lbfgs_hip_ctx {
     size_t lj_scratch_bytes = 0;
     struct LjCells* lj_cells = nullptr;   // LJ_CELLS: the rebuildable neighbour structure (allocated on demand)
     unsigned long long* gran = nullptr;   // tagged partial granules [MAX_RED][MAX_GRID][2] (stream.h)
+    bool defer_inner_sums = true;         // LBFGS_HIP_DEFER_SUMS=0: the two-loop's inner dots are reduced by their own kernels (A/B)
+    double* dot_parts = nullptr;          // 2 x MAX_GRID: workgroup partials of the two-loop's inner dot products (ping-pong)
     DevCounters* dev_ctr = nullptr;       // device-resident sequence numbers (stream.h); the three fields below shadow them
     unsigned long long red_count = 0;     // tagged reducing launches enqueued so far: the next one uses tag (red_count % (2^32-1)) + 1
     // hipGraph replay of the two-loop recursion (lbfgs_hip_two_loop*).  OFF by default: measured on MI355X / ROCm 7.2
@@ -405,13 +407,19 @@ int prep_red(lbfgs_hip_ctx* ctx, RedCtl& red, int nred, double* const* red_out, 
 }
 
 // ---- launch one operator ---------------------------------------------------------------------
+// partials_only (Op::NRED == 1, single rank): the kernel leaves its workgroups' partial sums in red_out[0][0 .. grid) and
+// nobody reduces them -- the consumer does (stream.h RedCtl::tagged == 2); *grid_out receives the number of partials.
 template <class Op>
 int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out, double* dup_ptr = nullptr,
-           int dup_k = 0) {
+           int dup_k = 0, bool partials_only = false, unsigned int* grid_out = nullptr) {
     static_assert(Op::NRED <= MAX_RED, "the partials buffer holds MAX_RED sums per workgroup");
     RedCtl red{};
     bool in_kernel_exchange = false;
-    {
+    if (partials_only) {
+        red.tagged = 2u;
+        red.ctr = ctx->dev_ctr;
+        for (int k = 0; k < Op::NRED && k < RED_PTRS; ++k) red.out[k] = red_out[k];
+    } else {
         const int rc_p = prep_red(ctx, red, Op::NRED, red_out, dup_ptr, dup_k, &in_kernel_exchange);
         if (rc_p != LBFGS_HIP_OK) return rc_p;
     }
@@ -419,6 +427,7 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out,
     constexpr int MAP = tuning<Op>::MAP, UNR = tuning<Op>::UNR;
     const int grid = (kclass >= 0 && kclass < 16 && ctx->grid_class[kclass] > 0)
                          ? std::min(MAX_GRID, ctx->grid_class[kclass]) : grid_for(ctx, tuning<Op>::GRID_X32);
+    if (grid_out) *grid_out = (unsigned int)grid;
     // Cache hints by vector size (profiles/r02_shard_cache_hints.log):
     //   >= 128 MiB  `nt` (streaming) on loads and stores: nothing can stay in the 256 MiB Infinity Cache anyway;
     //   64-128 MiB  `nt` on the stores only: the loads keep finding the running vector in the Infinity Cache, while
@@ -441,7 +450,7 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out,
                                op, n, ctx->shard.offset, red);
     }
     HIP_TRY(ctx, hipGetLastError());
-    if (Op::NRED > 0 && !in_kernel_exchange) return allreduce(ctx, red_out, Op::NRED);
+    if (Op::NRED > 0 && !in_kernel_exchange && !partials_only) return allreduce(ctx, red_out, Op::NRED);
     return LBFGS_HIP_OK;
 }
 
@@ -510,14 +519,24 @@ __global__ __launch_bounds__(64) void gram_coef_kernel(const GramArgs a) {
 
 // ---- helpers of the C-ABI functions below (templates need C++ linkage) -----------------------
 namespace {
+// A dot product on its way from the kernel that sums it to the kernel that consumes it: either a finished scalar
+// (board slot), or -- single rank, tagged hand-off -- the producer's workgroup partials, left for the consumer to add up.
+struct DotRef {
+    double* scalar = nullptr;
+    double* parts = nullptr;
+    unsigned int nparts = 0;  // > 0: `parts` holds that many partials; else `scalar` holds the sum
+};
+
 template <bool NEG_SRC, bool SCALE, int VMODE>
 int two_loop_step(lbfgs_hip_history* h, const double* src, const double* u, const double* v, double* dst,
-                  const double* dot_in, int j, int mode_b, const double* gnum, const double* gden, double* out,
+                  const DotRef& dot_in, int j, int mode_b, const double* gnum, const double* gden, DotRef* dot_out,
                   int kclass, uint64_t owl_start = 0, uint64_t owl_end = 0) {
     OpTwoLoopStep<NEG_SRC, SCALE, VMODE> op{};
     op.in[0] = src; op.in[1] = u; op.in[2] = v;
     op.out[0] = dst;
-    op.dot_in = dot_in;
+    op.dot_in = dot_in.scalar;
+    op.dot_parts = dot_in.parts;
+    op.dot_nparts = dot_in.nparts;
     op.ys_j = h->ys + j;
     op.alpha_j = h->alpha + j;
     op.gamma_num = gnum;
@@ -525,6 +544,11 @@ int two_loop_step(lbfgs_hip_history* h, const double* src, const double* u, cons
     op.mode_b = mode_b;
     op.owl_start = owl_start;
     op.owl_end = owl_end;
+    if (dot_out->parts) {  // (single-sum kernels only: VMODE 0 / 1)
+        double* outs[1] = {dot_out->parts};
+        return launch(h->ctx, kclass, op, outs, nullptr, 0, true, &dot_out->nparts);
+    }
+    double* out = dot_out->scalar;
     double* outs[4] = {out, out + 1, out + 2, out + 3};  // VMODE 2 / 3 produce 2 / 4 adjacent sums
     return launch(h->ctx, kclass, op, outs);
 }
@@ -962,6 +986,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     ctx->grid_default = std::max(1, prop.multiProcessorCount * 27 / 32);
     ctx->gram_grid = prop.multiProcessorCount;  // the 21-stream Gram rows pass peaks at one workgroup per CU
     if (const char* e = getenv("LBFGS_HIP_NT_THRESHOLD_MB")) ctx->nt_threshold_bytes = (size_t)atoll(e) << 20;
+    if (const char* e = getenv("LBFGS_HIP_DEFER_SUMS")) ctx->defer_inner_sums = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_GRAPH")) ctx->graph_max_bytes = atoi(e) ? ~(size_t)0 : 0;
     if (const char* e = getenv("LBFGS_HIP_GRAPH_MAX_MB")) ctx->graph_max_bytes = (size_t)atoll(e) << 20;
     if (const char* e = getenv("LBFGS_HIP_NT_STORE_THRESHOLD_MB")) ctx->nt_store_threshold_bytes = (size_t)atoll(e) << 20;
@@ -985,6 +1010,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
         CTX_TRY(hipMalloc(&ctx->dev_ctr, 4096));  // (a page of its own: nothing else shares its cache lines)
         CTX_TRY(hipMemcpy(ctx->dev_ctr, &init, sizeof(init), hipMemcpyHostToDevice));
     }
+    CTX_TRY(hipMalloc(&ctx->dot_parts, 2 * (size_t)MAX_GRID * sizeof(double)));
     CTX_TRY(hipMalloc(&ctx->p2p_err, 64));  // device error flag: 1 = a P2P peer never arrived, 2 = a partial never arrived
     CTX_TRY(hipMemsetAsync(ctx->p2p_err, 0, 64, ctx->stream));
     CTX_TRY(hipHostMalloc(&ctx->pinned, (LBFGS_HIP_BOARD_SLOTS + 1) * sizeof(double), hipHostMallocDefault));
@@ -1082,6 +1108,7 @@ void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* ctx) {
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     if (ctx->gran) (void)hipFree(ctx->gran);
     if (ctx->dev_ctr) (void)hipFree(ctx->dev_ctr);
+    if (ctx->dot_parts) (void)hipFree(ctx->dot_parts);
     if (ctx->lj_scratch) (void)hipFree(ctx->lj_scratch);
     if (ctx->lj_cells) {
         ctx->lj_cells->release();
@@ -1532,7 +1559,7 @@ static int two_loop_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip
         for (const double* p : {h->s[j]->p, h->y[j]->p}) hp = (hp ^ (uint64_t)(uintptr_t)p) * 1099511628211ull;
     const TwoLoopKey key = {(uint64_t)end, bound, (uint64_t)(uintptr_t)g->p, (uint64_t)(uintptr_t)d->p, (uint64_t)gamma_num_slot,
                             (uint64_t)gamma_den_slot, (uint64_t)dnorm_slot, (uint64_t)(int64_t)first_dot_slot, (uint64_t)owl,
-                            owl_start, owl_end, (uint64_t)ctx->grid_override, hp, (uint64_t)ctx->handoff_ticket,
+                            owl_start, owl_end, (uint64_t)ctx->grid_override, hp, (uint64_t)ctx->handoff_ticket | ((uint64_t)ctx->defer_inner_sums << 1),
                             (uint64_t)ctx->shard.n_local, (uint64_t)ctx->nt_threshold_bytes ^ ((uint64_t)ctx->nt_store_threshold_bytes << 1)};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
@@ -1600,59 +1627,74 @@ static int two_loop_eager(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hi
     auto jat = [&](int i) { return ((e1 - 1 - i) % m + m) % m; };
     int pp = 0;
     int rc;
-    const double* cur = dots + pp;  // where the pending numerator lives
+    // Inner dot products: with one rank and the tagged hand-off nobody reduces them inside the producing kernel -- its
+    // workgroups leave their partial sums and exit, and the next step adds them up in its prologue (same order, same
+    // bits), where that work overlaps the first loads.  Saves the reducer's poll + sum + store on 2*bound - 1 dependent
+    // kernels.  With several ranks the totals have to exist before they can be exchanged, so the reducer stays.
+    const bool defer = ctx->comm_kind == LBFGS_HIP_COMM_NONE && !ctx->handoff_ticket && ctx->defer_inner_sums;
+    auto slot_of = [&](int par) {
+        DotRef r;
+        if (defer) r.parts = ctx->dot_parts + (size_t)par * MAX_GRID;
+        else r.scalar = dots + par;
+        return r;
+    };
+    DotRef cur;  // where the pending numerator lives
     if (first_dot_slot >= 0) {
         // alpha_0 numerator already on the board (the history-update kernel summed s_new.(-g)): no pass at all
-        cur = ctx->board + first_dot_slot;
+        cur.scalar = ctx->board + first_dot_slot;
     } else {   // alpha_0 numerator: s_{j0} . (-g)                                         2r
         OpTwoLoopFirst op{};
         op.in[0] = g->p; op.in[1] = h->s[jat(0)]->p;
-        double* outs[1] = {dots + pp};
-        rc = launch(ctx, LBFGS_HIP_K_TWOLOOP_EDGE, op, outs);
+        cur = slot_of(pp);
+        double* outs[1] = {defer ? cur.parts : cur.scalar};
+        rc = launch(ctx, LBFGS_HIP_K_TWOLOOP_EDGE, op, outs, nullptr, 0, defer, defer ? &cur.nparts : nullptr);
         if (rc != LBFGS_HIP_OK) return rc;
     }
     // first loop, steps 1..bound-1: q -= alpha_{i-1} y_{j_{i-1}} ; next numerator s_{j_i} . q     3r 1w
     for (int i = 1; i < bound; ++i) {
         const int jp = jat(i - 1), jn = jat(i);
         const double* src = (i == 1) ? g->p : d->p;
-        double* nxt = dots + (pp ^ 1);
+        DotRef nxt = slot_of(pp ^ 1);
         if (i == 1)
-            rc = two_loop_step<true, false, 0>(h, src, h->y[jp]->p, h->s[jn]->p, d->p, cur, jp, 0, gnum, gden, nxt,
+            rc = two_loop_step<true, false, 0>(h, src, h->y[jp]->p, h->s[jn]->p, d->p, cur, jp, 0, gnum, gden, &nxt,
                                                LBFGS_HIP_K_TWOLOOP_STEP);
         else
-            rc = two_loop_step<false, false, 0>(h, src, h->y[jp]->p, h->s[jn]->p, d->p, cur, jp, 0, gnum, gden, nxt,
+            rc = two_loop_step<false, false, 0>(h, src, h->y[jp]->p, h->s[jn]->p, d->p, cur, jp, 0, gnum, gden, &nxt,
                                                 LBFGS_HIP_K_TWOLOOP_STEP);
         if (rc != LBFGS_HIP_OK) return rc;
         pp ^= 1;
-        cur = dots + pp;
+        cur = nxt;
     }
     {   // transition: q = gamma*(q - alpha_last y_last) ; beta numerator y_last . q      2r 1w
         const int jl = jat(bound - 1);
-        double* nxt = dots + (pp ^ 1);
+        DotRef nxt = slot_of(pp ^ 1);
         if (bound == 1)
-            rc = two_loop_step<true, true, 1>(h, g->p, h->y[jl]->p, nullptr, d->p, cur, jl, 0, gnum, gden, nxt,
+            rc = two_loop_step<true, true, 1>(h, g->p, h->y[jl]->p, nullptr, d->p, cur, jl, 0, gnum, gden, &nxt,
                                               LBFGS_HIP_K_TWOLOOP_EDGE);
         else
-            rc = two_loop_step<false, true, 1>(h, d->p, h->y[jl]->p, nullptr, d->p, cur, jl, 0, gnum, gden, nxt,
+            rc = two_loop_step<false, true, 1>(h, d->p, h->y[jl]->p, nullptr, d->p, cur, jl, 0, gnum, gden, &nxt,
                                                LBFGS_HIP_K_TWOLOOP_EDGE);
         if (rc != LBFGS_HIP_OK) return rc;
         pp ^= 1;
-        cur = dots + pp;
+        cur = nxt;
     }
     // second loop (lbfgs.rs:594-601), slots in the reverse order: j = jat(bound-1) ... jat(0)
     for (int i = bound - 1; i >= 1; --i) {
         const int j = jat(i), jn = jat(i - 1);  // q += (alpha_j - beta_j) s_j ; next numerator y_{jn} . q   3r 1w
-        rc = two_loop_step<false, false, 0>(h, d->p, h->s[j]->p, h->y[jn]->p, d->p, cur, j, 1, gnum, gden,
-                                            dots + (pp ^ 1), LBFGS_HIP_K_TWOLOOP_STEP);
+        DotRef nxt = slot_of(pp ^ 1);
+        rc = two_loop_step<false, false, 0>(h, d->p, h->s[j]->p, h->y[jn]->p, d->p, cur, j, 1, gnum, gden, &nxt,
+                                            LBFGS_HIP_K_TWOLOOP_STEP);
         if (rc != LBFGS_HIP_OK) return rc;
         pp ^= 1;
-        cur = dots + pp;
+        cur = nxt;
     }
     // last step: q += (alpha_{j0} - beta_{j0}) s_{j0} ; ||d||^2 (lbfgs.rs:543) and g.d (core.rs:78-92)   3r 1w
+    DotRef fin;
+    fin.scalar = dn;
     if (owl)  // ... plus the orthant projection of d and the post-projection ||d||^2, pg.d (orthantwise.rs:140-161)
-        return two_loop_step<false, false, 3>(h, d->p, h->s[jat(0)]->p, g->p, d->p, cur, jat(0), 1, gnum, gden, dn,
+        return two_loop_step<false, false, 3>(h, d->p, h->s[jat(0)]->p, g->p, d->p, cur, jat(0), 1, gnum, gden, &fin,
                                               LBFGS_HIP_K_TWOLOOP_EDGE, owl_start, owl_end);
-    return two_loop_step<false, false, 2>(h, d->p, h->s[jat(0)]->p, g->p, d->p, cur, jat(0), 1, gnum, gden, dn,
+    return two_loop_step<false, false, 2>(h, d->p, h->s[jat(0)]->p, g->p, d->p, cur, jat(0), 1, gnum, gden, &fin,
                                           LBFGS_HIP_K_TWOLOOP_EDGE);
 }
 

@@ -190,7 +190,9 @@ struct OpTwoLoopStep {
     static constexpr int TUNE_MAP = (VMODE == 1) ? DEFAULT_MAP : LH_STEP_MAP, TUNE_UNROLL = (VMODE == 1) ? UNROLL : LH_STEP_UNROLL;  // 3r+1w shapes
     const double* in[3];  // src, u, v (VMODE 2: g)
     double* out[1];       // dst (= d)
-    const double* dot_in; // previous reduction (global sum)
+    const double* dot_in; // previous reduction (global sum) ...
+    const double* dot_parts;  // ... or, when dot_nparts > 0, the producing kernel's dot_nparts workgroup partials, which
+    unsigned int dot_nparts;  //     this kernel adds up itself (stream.h sum_partials: the reducer's order, bitwise)
     const double* ys_j;   // ys of the slot whose coefficient this step applies
     double* alpha_j;      // alpha of that slot (written in mode A, read in mode B)
     const double* gamma_num;
@@ -200,7 +202,8 @@ struct OpTwoLoopStep {
     typedef TwoLoopCoef Coef;
     __device__ Coef setup() const {
         Coef cf;
-        const double r = *dot_in / *ys_j;
+        const double dot = dot_nparts ? sum_partials(dot_parts, dot_nparts) : *dot_in;
+        const double r = dot / *ys_j;
         if (mode_b) {
             cf.c = *alpha_j - r;
         } else {

@@ -89,7 +89,10 @@ struct RedCtl {
     unsigned int* ticket;    // arrival counter, self-resetting
     unsigned long long* gran;     // [MAX_RED][MAX_GRID][2] tagged granules  (tagged hand-off: up to RED_PTRS sums)
     DevCounters* ctr;             // the context's counters
-    unsigned int tagged;          // 1 = tagged hand-off (tag = ctr->red_epoch), 0 = the ticket form
+    unsigned int tagged;          // 1 = tagged hand-off (tag = ctr->red_epoch), 0 = the ticket form,
+                                  // 2 = PARTIALS ONLY: every workgroup stores its partial sums to out[k][blockIdx.x] and
+                                  //     exits; nobody waits.  The consumer -- the next kernel on the stream -- adds them up
+                                  //     itself in its prologue (sum_partials below), in the reducer's order.
     unsigned int* err;            // device error flag (2 = a partial never arrived)
     unsigned long long timeout_ticks;  // bound on the reducer's spin (wall_clock64 ticks, 100 MHz)
     double* out[RED_PTRS];   // where the last workgroup puts the totals (NRED <= RED_PTRS) ...
@@ -209,13 +212,36 @@ __device__ __forceinline__ DevCounters load_counters(const RedCtl& red) {
     return c;
 }
 
+// The total of G workgroup partials, formed by EVERY workgroup of the consuming kernel in exactly the order in which the
+// reducer of grid_reduce forms it (thread-strided partials, wave tree, waves in order), so that a sum closed this way is
+// bitwise the sum the producing kernel's reducer would have stored.  All threads of the workgroup call it.
+__device__ __forceinline__ double sum_partials(const double* parts, const unsigned int G) {
+    __shared__ double lds[1][WAVES];
+    __shared__ double total;
+    double t[1] = {0.0};
+    for (unsigned int b = threadIdx.x; b < G; b += BLOCK) t[0] += parts[b];
+    block_sum<1>(t, lds);
+    if (threadIdx.x == 0) total = t[0];
+    __syncthreads();
+    return total;
+}
+
 template <int NRED>
 __device__ __forceinline__ void grid_reduce(double (&acc)[NRED], const RedCtl& red, const DevCounters& c0) {
     __shared__ double lds[NRED][WAVES];
     block_sum<NRED>(acc, lds);
+    if constexpr (NRED <= RED_PTRS) {
+        if (red.tagged == 2u) {  // partials only (uniform over the grid): no reducer, no waiting
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int k = 0; k < NRED; ++k) red.out[k][blockIdx.x] = acc[k];
+            }
+            return;
+        }
+    }
     const unsigned int G = gridDim.x;
     double tot[NRED];
-    const bool tagged = NRED <= RED_PTRS && red.tagged != 0u;  // (uniform over the grid)
+    const bool tagged = NRED <= RED_PTRS && red.tagged == 1u;  // (uniform over the grid)
     const unsigned int epoch = c0.red_epoch;   // (the reducer advances the counter only after every partial has arrived)
     if (tagged) {
         // ---- tagged hand-off ----

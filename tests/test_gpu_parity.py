@@ -932,24 +932,29 @@ def test_handoff_forms_are_bitwise_identical(monkeypatch):
 
 
 @pytest.mark.parametrize("owl", [False, True])
-def test_two_loop_graph_replay_equals_eager_launches(owl, monkeypatch):
-    """The two-loop recorded once per (ring position, bound, operands) and replayed as a hipGraph launches the same
-    kernels with the same arguments as the eager path: whole runs must agree BITWISE (x, f, ||g||, step per iteration),
-    including the first iterations (bound < m: other graphs), the ring wrap and the alternating gx/gp buffers."""
+@pytest.mark.parametrize("knob", ["LBFGS_HIP_GRAPH", "LBFGS_HIP_DEFER_SUMS"])
+def test_two_loop_launch_forms_are_bitwise_equal(knob, owl, monkeypatch):
+    """Two pairs of launch forms of the same recursion must agree BITWISE over whole runs (x, f, ||g||, step per
+    iteration), including the first iterations (bound < m), the ring wrap and the alternating gx/gp buffers:
+      LBFGS_HIP_GRAPH       the two-loop recorded once per (ring position, bound, operands) and replayed as a hipGraph
+                            vs eager launches (same kernels, same arguments);
+      LBFGS_HIP_DEFER_SUMS  inner dot products left as workgroup partials for the consuming kernel to add up in its
+                            prologue vs reduced by the producing kernel's last workgroup (same summation order)."""
     if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
-        pytest.skip("the test double has no graphs")
-    n, iters = 50_001, 45
+        pytest.skip("the test double has neither")
+    iters = 45
     rows = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("LBFGS_HIP_GRAPH", mode)
-        b = R.lbfgs().with_m(5).with_epsilon(0.0).with_max_iterations(iters)
-        obj = objectives.Quadratic()
-        if owl:
-            b, obj = b.with_orthantwise(0.5, 0, None), objectives.Logistic()
-        x = np.zeros(n)
-        rr = []
-        b.minimize(x, obj, lambda p: rr.append((p.niter, p.neval, p.fx, p.xnorm, p.gnorm, p.step)) and False)
-        rows[mode] = (rr, x)
-    assert len(rows["0"][0]) == iters
-    assert rows["0"][0] == rows["1"][0]
-    assert np.array_equal(rows["0"][1], rows["1"][1])
+    for n in (50_001, 2_000_003):
+        for mode in ("0", "1"):
+            monkeypatch.setenv(knob, mode)
+            b = R.lbfgs().with_m(5).with_epsilon(0.0).with_max_iterations(iters if n < 100_000 else 12)
+            obj = objectives.Quadratic()
+            if owl:
+                b, obj = b.with_orthantwise(0.5, 0, None), objectives.Logistic()
+            x = np.zeros(n)
+            rr = []
+            b.minimize(x, obj, lambda p: rr.append((p.niter, p.neval, p.fx, p.xnorm, p.gnorm, p.step)) and False)
+            rows[mode] = (rr, x)
+        assert len(rows["0"][0]) in (iters, 12)
+        assert rows["0"][0] == rows["1"][0]
+        assert np.array_equal(rows["0"][1], rows["1"][1])
