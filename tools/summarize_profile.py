@@ -39,7 +39,7 @@ def shape(name):
 
 
 def short(name):
-    m = re.search(r"stream_kernel<lh::(.*?)(, \d+, \d+u, \d+u, \d+, \d+)?>\(", name)
+    m = re.search(r"stream_kernel<lh::(.*?)(, \d+, \d+u, \d+u, \d+, \d+(, (true|false))?)?>\(", name)
     return ("stream_kernel<" + m.group(1) + ">") if m else name[:60]
 
 
