@@ -167,6 +167,10 @@ struct lbfgs_state {
     // Problem (core.rs:10-52)
     lbfgs_hip_vec *x = nullptr, *gx = nullptr, *xp = nullptr, *gp = nullptr, *pg = nullptr, *wp = nullptr,
                   *d = nullptr;
+    // The next direction is built HERE and exchanged with d only once IterationData::update's checks have passed: the
+    // whole tail of an iteration is enqueued before its scalars are read, and after Err("gx not changed") /
+    // Err("x not changed") the reference's d is still the old one (lbfgs.rs:646,655 return before :536-540).
+    lbfgs_hip_vec* d_next = nullptr;
     double fx = 0.0;
     uint64_t neval = 0;
     uint64_t owl_start = 0, owl_end = 0;
@@ -616,7 +620,7 @@ void lbfgs_state_free(lbfgs_state* st) {
     lbfgs_hip_history_destroy(st->hist);
     lbfgs_hip_host_buffer_destroy(st->ctx, st->host_x);
     lbfgs_hip_host_buffer_destroy(st->ctx, st->host_g);
-    lbfgs_hip_vec* vs[] = {st->x, st->gx, st->xp, st->gp, st->pg, st->wp, st->d};
+    lbfgs_hip_vec* vs[] = {st->x, st->gx, st->xp, st->gp, st->pg, st->wp, st->d, st->d_next};
     for (auto* v : vs) lbfgs_hip_vec_free(v);
     delete st;
 }
@@ -648,6 +652,7 @@ static int problem_new(lbfgs_state** out, lbfgs_hip_ctx* ctx, const lbfgs_param*
     // lbfgs.rs:449: m zeroed (s, y) pairs
     if (with_history && (rc = backend(st, lbfgs_hip_history_create(ctx, (int)param->m, &st->hist))) != LBFGS_OK)
         return bail_out(rc);
+    if (with_history && (rc = backend(st, lbfgs_hip_vec_alloc(ctx, &st->d_next))) != LBFGS_OK) return bail_out(rc);
     if ((rc = backend(st, lbfgs_hip_vec_upload(st->x, x0, st->shard.n_local))) != LBFGS_OK) return bail_out(rc);
     *out = st;
     return LBFGS_OK;
@@ -848,21 +853,22 @@ int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
     int new_end = st->end;
     bool projected = false;  // constrain_search_direction already applied by the two-loop's last step?
     if (st->vars.vector_free)
-        TRYB(st, lbfgs_hip_two_loop_gram(st->hist, st->d, st->grad_for_direction(), st->k - 1, st->end, S_UPD + 1,
+        TRYB(st, lbfgs_hip_two_loop_gram(st->hist, st->d_next, st->grad_for_direction(), st->k - 1, st->end, S_UPD + 1,
                                          S_UPD + 2, S_DNORM2, &new_end));
     else if (st->owlqn()) {  // :554 folded into the last step (it streams pg anyway); slots S_DNORM2C follow S_DNORM2
         static_assert(S_DNORM2C == S_DNORM2 + 2, "two_loop_owlqn writes 4 adjacent slots");
-        TRYB(st, lbfgs_hip_two_loop_owlqn(st->hist, st->d, st->pg, st->k - 1, st->end, S_UPD + 1, S_UPD + 2, S_DNORM2,
+        TRYB(st, lbfgs_hip_two_loop_owlqn(st->hist, st->d_next, st->pg, st->k - 1, st->end, S_UPD + 1, S_UPD + 2, S_DNORM2,
                                           st->owl_start, st->owl_end, &new_end));
         projected = true;
     } else  // without OWL-QN the update kernel already summed s_new.(-g): start from it
-        TRYB(st, lbfgs_hip_two_loop_from(st->hist, st->d, st->grad_for_direction(), st->k - 1, st->end, S_UPD + 1,
+        TRYB(st, lbfgs_hip_two_loop_from(st->hist, st->d_next, st->grad_for_direction(), st->k - 1, st->end, S_UPD + 1,
                                          S_UPD + 2, S_DNORM2, st->owlqn() ? -1 : S_UPD + 6, &new_end));
     if (st->owlqn() && !projected)  // :554, orthantwise.rs:140-161 (after dnorm, as in the reference)
-        TRYB(st, lbfgs_hip_constrain_direction(st->d, st->pg, st->owl_start, st->owl_end, S_DNORM2C));
+        TRYB(st, lbfgs_hip_constrain_direction(st->d_next, st->pg, st->owl_start, st->owl_end, S_DNORM2C));
     // plain L-BFGS never writes S_DNORM2C..: asking for them would force the copy path of scalars_read every iteration
     TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_UPD, (st->owlqn() ? S_END_BLOCK : S_DNORM2C) - S_UPD, u));
     if (!early) TRY(check_update());
+    TRYB(st, lbfgs_hip_vec_swap(st->d, st->d_next));  // the update succeeded: the new direction takes effect (:536-540)
     st->end = new_end;
     if (!st->owlqn()) {
         st->xnorm2 = u[3];

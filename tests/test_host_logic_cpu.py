@@ -243,6 +243,35 @@ def test_error_paths():
         R.lbfgs().with_linesearch_algorithm("Newton")
 
 
+def test_state_after_update_errors_is_the_references():
+    """Err("gx not changed") (lbfgs.rs:655) and Err("x not changed") (:646) return BEFORE the search direction is
+    rebuilt (:536-540): d must still be the direction of the failed iteration.  The product enqueues the two-loop
+    before it has read the update's scalars, so it builds the next direction in a spare vector and exchanges it with d
+    only after those checks."""
+    c = np.linspace(-2.0, 3.0, 40)
+
+    def linear(x, g):  # constant gradient: y = 0 at the first update
+        g[:] = c
+        return float(np.dot(c, x))
+
+    for cfg, ev, code in [(lambda b: b, linear, _ffi.ERR_GX_NOT_CHANGED),
+                          (lambda b: b.with_max_linesearch(1), P.rosenbrock, _ffi.ERR_X_NOT_CHANGED)]:
+        x0 = np.zeros(40) if ev is linear else P.rosenbrock_x0(40)
+        so = cfg(O.lbfgs()).build(x0.copy(), ev)
+        with cfg(R.lbfgs()).build(x0.copy(), ev) as sp:
+            so.propagate(); sp.propagate()
+            with pytest.raises(O.OracleError) as eo:
+                for _ in range(5):
+                    so.propagate()
+            with pytest.raises(R.LbfgsError) as ep:
+                for _ in range(5):
+                    sp.propagate()
+            assert eo.value.code == ep.value.code == code
+            assert np.array_equal(sp.download("d"), so.vec("d"))
+            assert np.array_equal(sp.download("x"), so.vec("x")) and np.array_equal(sp.download("gx"), so.vec("gx"))
+        so.close()
+
+
 def test_gradient_only_matches_oracle():
     a, b = run_pair(lambda b: b.with_gradient_only().with_max_iterations(30), P.rosenbrock_x0(), O.rosenbrock(),
                     R.default_evaluate())
