@@ -21,6 +21,13 @@
 //     one partial per workgroup, published as tagged 8-byte granules -> the
 //     last-index workgroup polls them and sums in a FIXED order.  No float
 //     atomics, so results are bitwise reproducible for a given (n, grid).
+//     A sum that only the NEXT kernel consumes is not reduced at all by its
+//     producer: the consumer adds the partials in its prologue (sum_partials);
+//   * what a DEPENDENT kernel costs besides its bytes (the bound below ~100 MB
+//     per vector): no release fences towards the host (a system-scope release
+//     writes back a whole L2), no scratch memory (+12 us per dispatch), first
+//     loads before the board reads, launch-to-launch sequence numbers in device
+//     memory (DevCounters) instead of kernel arguments.
 //
 // An operator (ops.h) only states: its input/output streams, how one element is
 // computed, and how many sums it accumulates.

@@ -141,6 +141,17 @@ def test_lj38_damped():
     assert_identical(a, b)
 
 
+def test_lj_cells_damped():
+    """Config 5's evaluator (cutoff + shift rule, LJ_CELLS) with with_damping(true): on the test double the objective is
+    the oracle's own cutoff rule, so host logic and oracle must agree bit for bit while the block relaxes."""
+    g3 = np.stack(np.meshgrid(*[np.arange(5, dtype=np.float64)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    x0 = (g3 * 1.2 + np.random.default_rng(3).uniform(-0.1, 0.1, g3.shape)).reshape(-1)
+    cfg = lambda b: b.with_damping(True).with_max_iterations(40)
+    a, b = run_pair(cfg, x0, O.lj_cells(2.5), objectives.LennardJonesCells(2.5, 0.3))
+    assert len(a[1]) >= 20 and a[1][-1][3] < a[1][0][3] - 10.0
+    assert_identical(a, b)
+
+
 def test_progress_cancel_and_lazy_vectors():
     x = P.rosenbrock_x0()
     seen = []
