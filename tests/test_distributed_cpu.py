@@ -224,6 +224,25 @@ def test_three_ranks_uneven_shards(tmp_path):
     assert np.max(np.abs(x - ref_x)) <= 1e-9 * max(np.max(np.abs(ref_x)), 1e-12)
 
 
+def test_eight_ranks_as_in_the_metric(tmp_path):
+    """world = 8, the rank count BASELINE.json's metric names: eight contiguous 256-aligned shards (the last one
+    short), OWL-QN range straddling several shard boundaries, every rank holding the same global scalars."""
+    case = dict(name="owlqn8", n=20_011, m=6, iters=12, objective="logistic", owl=[0.5, 3000, 17_500])
+    outs = run_world(case, 8, tmp_path)
+    ref_rows, ref_x = oracle_rows(case)
+    sizes = [o["hi"] - o["lo"] for o in outs]
+    assert sizes == [2560] * 7 + [20_011 - 7 * 2560] and outs[0]["lo"] == 0 and outs[-1]["hi"] == case["n"]
+    for o in outs[1:]:
+        assert o["rows"] == outs[0]["rows"]
+    assert len(outs[0]["rows"]) == len(ref_rows)
+    for got, ref in zip(outs[0]["rows"], ref_rows):
+        assert got[:3] == ref[:3]
+        for a, b in zip(got[3:], ref[3:]):
+            assert abs(a - b) <= 1e-9 * max(abs(b), 1e-6)
+    x = np.concatenate([np.array(o["x"]) for o in outs])
+    assert np.max(np.abs(x - ref_x)) <= 1e-9 * max(np.max(np.abs(ref_x)), 1e-12)
+
+
 # ------------------------------------------------------------------------------------------------------------
 # bench.py's N > 1 supervisor: rank processes run on the test double (tests/support/bench_on_mock.py)
 # ------------------------------------------------------------------------------------------------------------
