@@ -16,7 +16,7 @@ HIP_LIB = os.path.join(HERE, "liblbfgs_hip.so")
 SOLVER_LIB = os.path.join(HERE, "liblbfgs_solver.so")
 RESOURCES = os.path.join(HERE, "liblbfgs_hip.resources.txt")  # per-kernel register / scratch usage of the last build
 
-HIP_SRCS = [os.path.join(CSRC, f) for f in ("lbfgs_hip.hip", "ops.h", "stream.h", "gram.h", "lj.h")] + [
+HIP_SRCS = [os.path.join(CSRC, f) for f in ("lbfgs_hip.hip", "ops.h", "stream.h", "gram.h", "lj.h", "resident.h")] + [
     os.path.join(ROOT, "include", "lbfgs_hip.h")
 ]
 SOLVER_SRCS = [os.path.join(CSRC, "host", "solver.cpp"), os.path.join(ROOT, "include", "lbfgs_solver.h"),
@@ -50,6 +50,8 @@ def build_hip(force=False):
         # (tests/test_abi_exports.py requires ScratchSize == 0 everywhere: a kernel that touches scratch memory pays
         # ~12 us of extra dispatch cost per launch on MI355X, measured)
         r = _run([hipcc(), "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+                  # (resident.h parks data in the accumulation registers by hand: the compiler must not spill into them)
+                  "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",
                   "-Wall", "-Rpass-analysis=kernel-resource-usage", HIP_SRCS[0], "-o", HIP_LIB, "-ldl"])
         with open(RESOURCES, "w") as f:
             f.write(r.stderr)

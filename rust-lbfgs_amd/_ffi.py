@@ -90,7 +90,7 @@ class CReport(C.Structure):
 HIP_SYMBOLS = """
 lbfgs_hip_abi_version lbfgs_hip_device_count lbfgs_hip_rccl_unique_id lbfgs_hip_p2p_mailbox_create
 lbfgs_hip_p2p_mailbox_destroy lbfgs_hip_ctx_create lbfgs_hip_ctx_destroy
-lbfgs_hip_last_error lbfgs_hip_sync lbfgs_hip_stream lbfgs_hip_get_shard lbfgs_hip_set_grid
+lbfgs_hip_last_error lbfgs_hip_sync lbfgs_hip_stream lbfgs_hip_get_shard lbfgs_hip_set_grid lbfgs_hip_path_stats
 lbfgs_hip_vec_alloc lbfgs_hip_vec_free lbfgs_hip_vec_upload lbfgs_hip_vec_download lbfgs_hip_vec_fill
 lbfgs_hip_vec_ptr lbfgs_hip_vec_swap
 lbfgs_hip_scalars_read lbfgs_hip_scalars_write lbfgs_hip_scalars_ptr lbfgs_hip_scalars_allreduce
@@ -137,6 +137,7 @@ def declare(L):
         "lbfgs_hip_stream": (vp, [vp]),
         "lbfgs_hip_get_shard": (i, [vp, C.POINTER(Shard)]),
         "lbfgs_hip_set_grid": (i, [vp, i]),
+        "lbfgs_hip_path_stats": (i, [vp, C.POINTER(u64)]),
         "lbfgs_hip_vec_alloc": (i, [vp, C.POINTER(vp)]),
         "lbfgs_hip_vec_free": (None, [vp]),
         "lbfgs_hip_vec_upload": (i, [vp, dp, u64]),

@@ -116,6 +116,12 @@ class Context:
         self.check(self._L.lbfgs_hip_lj_cells_stats(self._h, C.byref(r), C.byref(e), C.byref(m)))
         return r.value, e.value, m.value
 
+    def resident_two_loops(self):
+        """How many two-loop recursions of this context ran as the single on-chip-resident kernel."""
+        r = C.c_uint64()
+        self.check(self._L.lbfgs_hip_path_stats(self._h, C.byref(r)))
+        return r.value
+
     def set_grid(self, blocks):
         self.check(self._L.lbfgs_hip_set_grid(self._h, blocks))
 

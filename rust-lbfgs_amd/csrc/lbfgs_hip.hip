@@ -25,6 +25,7 @@
 #include "ops.h"
 #include "gram.h"
 #include "lj.h"
+#include "resident.h"
 
 using namespace lh;
 
@@ -159,6 +160,9 @@ struct lbfgs_hip_ctx {
     size_t lj_scratch_bytes = 0;
     struct LjCells* lj_cells = nullptr;   // LJ_CELLS: the rebuildable neighbour structure (allocated on demand)
     unsigned long long* gran = nullptr;   // tagged partial granules [MAX_RED][MAX_GRID][2] (stream.h)
+    bool resident_on = true;              // LBFGS_HIP_RESIDENT=0: never use the on-chip-resident two-loop kernel (resident.h)
+    unsigned long long resident_launches = 0;  // two-loops that ran as the resident kernel (tests / bench read it)
+    int resident_ok = -1;                 // -1 = not probed yet, 0 = this device cannot hold the grid resident, 1 = usable
     bool defer_inner_sums = true;         // LBFGS_HIP_DEFER_SUMS=0: the two-loop's inner dots are reduced by their own kernels (A/B)
     double* dot_parts = nullptr;          // 2 x MAX_GRID: workgroup partials of the two-loop's inner dot products (ping-pong)
     DevCounters* dev_ctr = nullptr;       // device-resident sequence numbers (stream.h); the three fields below shadow them
@@ -987,6 +991,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     ctx->gram_grid = prop.multiProcessorCount;  // the 21-stream Gram rows pass peaks at one workgroup per CU
     if (const char* e = getenv("LBFGS_HIP_NT_THRESHOLD_MB")) ctx->nt_threshold_bytes = (size_t)atoll(e) << 20;
     if (const char* e = getenv("LBFGS_HIP_DEFER_SUMS")) ctx->defer_inner_sums = atoi(e) != 0;
+    if (const char* e = getenv("LBFGS_HIP_RESIDENT")) ctx->resident_on = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_GRAPH")) ctx->graph_max_bytes = atoi(e) ? ~(size_t)0 : 0;
     if (const char* e = getenv("LBFGS_HIP_GRAPH_MAX_MB")) ctx->graph_max_bytes = (size_t)atoll(e) << 20;
     if (const char* e = getenv("LBFGS_HIP_NT_STORE_THRESHOLD_MB")) ctx->nt_store_threshold_bytes = (size_t)atoll(e) << 20;
@@ -1133,6 +1138,12 @@ void* lbfgs_hip_stream(lbfgs_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : n
 int lbfgs_hip_get_shard(const lbfgs_hip_ctx* ctx, lbfgs_hip_shard* out) {
     if (!ctx || !out) return LBFGS_HIP_ERR_ARG;
     *out = ctx->shard;
+    return LBFGS_HIP_OK;
+}
+
+int lbfgs_hip_path_stats(lbfgs_hip_ctx* ctx, uint64_t* resident_two_loops) {
+    if (!ctx) return LBFGS_HIP_ERR_ARG;
+    if (resident_two_loops) *resident_two_loops = ctx->resident_launches;
     return LBFGS_HIP_OK;
 }
 
@@ -1528,6 +1539,116 @@ int lbfgs_hip_two_loop_owlqn(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs
 
 }  // extern "C"
 
+// ---- the two-loop as ONE kernel with the running vector resident in registers + LDS (resident.h) ----------------
+namespace {
+template <int ER>
+int resident_launch(lbfgs_hip_ctx* ctx, const ResArgs& ra, const RedCtl& red, int grid, size_t lds_bytes, bool nt) {
+    auto kern_nt = two_loop_resident_kernel<ER, true>;
+    auto kern_pl = two_loop_resident_kernel<ER, false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[nt ? 1 : 0]) {  // more than 64 KiB of dynamic LDS has to be asked for
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(nt ? kern_nt : kern_pl),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, RES_LDS_PAIRS_MAX * BLOCK * (int)sizeof(d2)));
+        attr_set[nt ? 1 : 0] = true;
+    }
+    if (nt) hipLaunchKernelGGL(kern_nt, dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, ra, red);
+    else hipLaunchKernelGGL(kern_pl, dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, ra, red);
+    HIP_TRY(ctx, hipGetLastError());
+    return LBFGS_HIP_OK;
+}
+
+// -> 1 if the recursion was launched as the resident kernel, 0 if this case is not eligible (caller falls back), < 0 error
+int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
+                      int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end) {
+    lbfgs_hip_ctx* ctx = h->ctx;
+    const int m = h->m;
+    const int bound = (int)std::min<uint64_t>((uint64_t)m, k);
+    if (!ctx->resident_on || ctx->comm_kind != LBFGS_HIP_COMM_NONE || ctx->handoff_ticket || bound < 1 || ctx->capturing ||
+        ctx->grid_override > 0 || 2 * bound > RES_MAX_STEPS)
+        return 0;
+    const int grid = ctx->cu_count;  // one workgroup per CU: all of them resident at once
+    if (grid < 1 || grid > BLOCK || grid > MAX_GRID) return 0;  // (every thread polls one workgroup's granules)
+    const uint64_t n = ctx->shard.n_local;
+    const uint64_t per_round = (uint64_t)grid * BLOCK;
+    const uint64_t E = ((n >> 1) + per_round - 1) / per_round;  // 16-byte pairs per thread
+    constexpr int ER_MAX = 60;
+    if (E == 0 || E > ER_MAX + RES_LDS_PAIRS_MAX || (n >> 1) + per_round * 4 >= (1ull << 28)) return 0;
+    if (ctx->red_count % 0xFFFFFFFFull + 2ull * (uint64_t)bound + 4ull >= 0xFFFFFFFFull) return 0;  // tag wrap: eager path
+    // Rounds 0 .. E-2 are full for every thread, round E-1 is the ragged one.  The register rounds carry no bounds checks,
+    // so ER <= E-1; the rest (the ragged round included) lives in LDS.
+    if (E < 2) return 0;
+    const int er = E - 1 >= ER_MAX ? ER_MAX : E - 1 >= 40 ? 40 : E - 1 >= 24 ? 24 : E - 1 >= 8 ? 8 : 0;
+    if (er == 0) return 0;  // (vectors of < 1.2 MB: the launch-per-step path)
+    const uint32_t el = (uint32_t)((E - er + RES_UNROLL - 1) / RES_UNROLL * RES_UNROLL);
+    if (el > (uint32_t)RES_LDS_PAIRS_MAX) return 0;
+    if (ctx->resident_ok < 0) {  // once: can this device hold one such workgroup per CU?
+        int nb = 0;
+        const size_t lds_max = (size_t)RES_LDS_PAIRS_MAX * BLOCK * sizeof(d2);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(two_loop_resident_kernel<ER_MAX, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        if (e == hipSuccess)
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, two_loop_resident_kernel<ER_MAX, false>, BLOCK, lds_max);
+        ctx->resident_ok = (e == hipSuccess && nb >= 1) ? 1 : 0;
+        (void)hipGetLastError();
+        if (getenv("LBFGS_HIP_VERBOSE"))
+            fprintf(stderr, "[lbfgs_hip] resident two-loop kernel: %s (%s, %d workgroup(s) per CU with %zu bytes of LDS)\n",
+                    ctx->resident_ok ? "usable" : "not usable", hipGetErrorString(e), nb, lds_max);
+    }
+    if (ctx->resident_ok != 1) return 0;
+
+    ProfScope whole(ctx, LBFGS_HIP_K_TWOLOOP_ALL);
+    const int e1 = (end + 1) % m;                                   // lbfgs.rs:577
+    auto jat = [&](int i) { return ((e1 - 1 - i) % m + m) % m; };   // lbfgs.rs:583
+    ResArgs ra{};
+    ra.g = g->p;
+    ra.d = d->p;
+    ra.first_dot = first_dot_slot >= 0 ? ctx->board + first_dot_slot : nullptr;
+    ra.first_s = h->s[jat(0)]->p;
+    ra.gnum = ctx->board + gamma_num_slot;
+    ra.gden = ctx->board + gamma_den_slot;
+    ra.out_dn = ctx->board + dnorm_slot;
+    ra.n = n;
+    ra.pairs_per_thread = (uint32_t)E;
+    ra.lds_pairs = el;
+    int ns = 0;
+    auto add = [&](const double* u, const double* v, int j, int mode_b, int scale, int aidx, int last) {
+        ResStep& st = ra.step[ns++];
+        st.u = u; st.v = v; st.ys = h->ys + j; st.alpha = h->alpha + j;
+        st.mode_b = mode_b; st.scale = scale; st.alpha_idx = aidx; st.last = last;
+    };
+    for (int i = 1; i < bound; ++i)   // first loop: q -= alpha_{i-1} y_{j_{i-1}} ; next numerator s_{j_i} . q
+        add(h->y[jat(i - 1)]->p, h->s[jat(i)]->p, jat(i - 1), 0, 0, i - 1, 0);
+    add(h->y[jat(bound - 1)]->p, nullptr, jat(bound - 1), 0, 1, bound - 1, 0);  // transition: *gamma ; y_last . q
+    for (int i = bound - 1; i >= 1; --i)  // second loop: q += (alpha_j - beta_j) s_j ; next numerator y_{j-1} . q
+        add(h->s[jat(i)]->p, h->y[jat(i - 1)]->p, jat(i), 1, 0, i, 0);
+    add(h->s[jat(0)]->p, g->p, jat(0), 1, 0, 0, 1);  // last step: ||d||^2 and g.d
+    ra.nsteps = ns;
+
+    RedCtl red{};
+    bool in_kernel_exchange = false;
+    double* outs2[2] = {ra.out_dn, ra.out_dn + 1};
+    const int rc_p = prep_red(ctx, red, 2, outs2, nullptr, 0, &in_kernel_exchange);
+    if (rc_p != LBFGS_HIP_OK) return rc_p;
+    ctx->red_count += (unsigned long long)(ns + (ra.first_dot ? 0 : 1)) - 1ull;  // one tag per hand-off (prep_red counted one)
+    const bool nt = n * sizeof(double) >= ctx->nt_store_threshold_bytes;  // the history vectors are read once per step either way
+    const size_t lds_bytes = (size_t)el * BLOCK * sizeof(d2);
+    int rc;
+    {
+        ProfScope ps(ctx, LBFGS_HIP_K_TWOLOOP_STEP);
+        switch (er) {
+            case 8: rc = resident_launch<8>(ctx, ra, red, grid, lds_bytes, nt); break;
+            case 24: rc = resident_launch<24>(ctx, ra, red, grid, lds_bytes, nt); break;
+            case 40: rc = resident_launch<40>(ctx, ra, red, grid, lds_bytes, nt); break;
+            default: rc = resident_launch<ER_MAX>(ctx, ra, red, grid, lds_bytes, nt); break;
+        }
+    }
+    if (rc != LBFGS_HIP_OK) return rc;
+    ctx->resident_launches += 1;
+    *new_end = e1;
+    return 1;
+}
+}  // namespace
+
 static int two_loop_eager(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
                           int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end,
                           bool owl, uint64_t owl_start, uint64_t owl_end);
@@ -1545,6 +1666,10 @@ static int two_loop_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip
         return LBFGS_HIP_ERR_ARG;
     if (!slot_ok(gamma_num_slot, 1) || !slot_ok(gamma_den_slot, 1) || !slot_ok(dnorm_slot, 2)) return LBFGS_HIP_ERR_ARG;
     lbfgs_hip_ctx* ctx = h->ctx;
+    if (!owl) {  // small enough to keep the running vector on the chip?  then the whole recursion is one kernel
+        const int rr = two_loop_resident(h, d, g, k, end, gamma_num_slot, gamma_den_slot, dnorm_slot, first_dot_slot, new_end);
+        if (rr != 0) return rr < 0 ? rr : LBFGS_HIP_OK;
+    }
     const uint64_t bound = std::min<uint64_t>((uint64_t)h->m, k);
     const bool graphable = bound > 0 && !ctx->prof_on && !ctx->capturing &&
                            (size_t)ctx->shard.n_local * sizeof(double) <= ctx->graph_max_bytes &&

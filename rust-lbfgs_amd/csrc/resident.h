@@ -1,0 +1,443 @@
+// rust-lbfgs_amd/csrc/resident.h -- the two-loop recursion (lbfgs.rs:569-604) as ONE kernel that keeps the running
+// vector q ON THE CHIP for the whole recursion.
+//
+// MI355X has 128 MiB of vector registers (256 CUs x 4 SIMD x 512 x 64 lanes x 4 B) and 40 MiB of LDS.  The running
+// vector of the recursion -- read and rewritten by every one of its 2*bound steps -- fits there whenever a rank's shard
+// is at most ~1.25e7 elements (100 MB): each of 256 workgroups x 256 threads holds ER 16-byte pairs in registers and up
+// to EL more in LDS.  Then a step streams only its TWO history vectors from HBM (q += c*u ; out = v.q) instead of three
+// reads and a write, and the steps are separated by a grid-wide hand-off of the partial sums instead of a kernel
+// boundary:
+//      launch-per-step path   8*bound - 1 passes of an n-vector, 2*bound kernel boundaries
+//      this kernel            4*bound + 1 passes (g once, every s and y once... twice over both loops, d written once),
+//                             one launch
+// That is the per-rank regime of the 8-GPU run of BASELINE.json's metric (n = 1e8 / 8), and of its configs 2 and 3.
+//
+// Synchronisation between steps.  Nothing but the partial sums crosses workgroups: q never leaves its thread, u / v / g
+// were written by earlier kernels.  After a step every workgroup publishes its partial sum(s) as tagged 8-byte
+// granules (tag = the step's sequence number; agent-scope atomics on both sides, no fence: stream.h) into a double
+// buffer indexed by the step's parity, and then EVERY workgroup collects all G partials -- thread t polls workgroup t's
+// granules -- and adds them up in the fixed order of stream.h's reducer (wave tree, waves in order).  All workgroups
+// therefore hold the same bits for the total and form the same coefficient; no broadcast step is needed.  A workgroup can
+// be at most one step ahead of any other (it needs everybody's partial of step s to leave step s), so two buffers
+// suffice.  All G workgroups must be resident at once: the grid is one workgroup per CU (the LDS share makes it exactly
+// one), the kernel is launched alone on its stream, and every spin is bounded by a wall-clock timeout that raises
+// *red.err (surfaced at the next scalar read) -- a missing workgroup ends as an error, not as a hang.
+//
+// Arithmetic is the reference's, operation by operation (q + c*u: a multiply then an add, math.rs:35; dot products as
+// running sums, math.rs:41; -ffp-contract=off); only the order of the dot products' partial sums differs from the
+// launch-per-step kernels (other element -> thread map), as it differs between any two grids.
+#pragma once
+#include "stream.h"
+
+namespace lh {
+
+constexpr int RES_MAX_STEPS = 2 * 24;  // 2 * bound for bound <= 24 (the step table travels as a kernel argument: < 4 KiB)
+constexpr int RES_LDS_PAIRS_MAX = 36;  // 160 KiB / (256 threads x 16 B) = 40, less the kernel's small static arrays,
+                                       // rounded down to a multiple of RES_UNROLL
+constexpr int RES_UNROLL = 4;          // pairs whose loads are issued together
+
+struct ResStep {
+    const double* u;     // the vector added to q:   q += c * u
+    const double* v;     // the vector the new q is multiplied with (nullptr: with u itself -- the gamma transition)
+    const double* ys;    // ys of the correction whose coefficient this step applies (lbfgs.rs:587,597)
+    double* alpha;       // its alpha: written in mode A (first loop), for API parity with the other paths
+    int mode_b;          // 0: c = -(dot/ys), alpha = dot/ys     1: c = alpha - dot/ys
+    int scale;           // 1: q *= gamma after the update (lbfgs.rs:591)
+    int alpha_idx;       // position in this kernel's private alpha stack
+    int last;            // 1: the last step -- sums ||q||^2 and v.q (v = g: the next line search's dginit)
+};
+
+struct ResArgs {
+    const double* g;         // q starts as -g (core.rs:95-101)
+    double* d;               // the result
+    const double* first_dot; // s_{j0}.(-g) if somebody has summed it already (the history-update kernel), else nullptr
+    const double* first_s;   // ... else it is summed here: s_{j0}
+    const double* gnum;      // gamma = *gnum / *gden (lbfgs.rs:691)
+    const double* gden;
+    double* out_dn;          // ||d||^2 ; out_dn[1] = g.d
+    uint64_t n;              // elements of this rank's shard
+    uint32_t pairs_per_thread;  // E: 16-byte pairs each thread owns (registers first, then LDS)
+    uint32_t lds_pairs;         // of which in LDS (a multiple of RES_UNROLL)
+    int nsteps;
+    ResStep step[RES_MAX_STEPS];
+};
+
+// Publish this workgroup's NS partial sums of sequence number `tag`, then collect everybody's and return the totals
+// (identical bits in every workgroup).  gran rows: [parity][k].  All threads call it.
+template <int NS>
+__device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& red, const unsigned int tag, const int parity,
+                                             double (*lds)[WAVES], double* s_tot) {
+    block_sum<NS>(acc, lds);
+    const unsigned int G = gridDim.x;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(acc[k]);
+            unsigned long long* g = red.gran + ((size_t)(parity * 2 + k) * MAX_GRID + blockIdx.x) * 2;
+            const unsigned long long t = (unsigned long long)tag << 32;
+            __hip_atomic_store(g, t | (b & 0xffffffffULL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 1, t | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();  // lds is reused below
+    double tot[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) tot[k] = 0.0;
+    const long long t0 = wall_clock64();
+    for (unsigned int b = threadIdx.x; b < G; b += BLOCK) {  // (G <= BLOCK in practice: one poll loop per thread)
+        unsigned long long lo[NS], hi[NS];
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const unsigned long long* g = red.gran + ((size_t)(parity * 2 + k) * MAX_GRID + b) * 2;
+                lo[k] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hi[k] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) ok = ok && (unsigned int)(lo[k] >> 32) == tag && (unsigned int)(hi[k] >> 32) == tag;
+            if (ok) break;
+            if ((unsigned long long)(wall_clock64() - t0) > red.timeout_ticks) {
+                atomicExch(red.err, 2u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) tot[k] += __longlong_as_double((long long)((hi[k] << 32) | (lo[k] & 0xffffffffULL)));
+    }
+    block_sum<NS>(tot, lds);  // the reducer's order: thread-strided partials, wave tree, waves in order
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s_tot[k] = tot[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = s_tot[k];
+    __syncthreads();  // s_tot and lds are free again
+}
+
+// One step over this thread's pairs.  MODE 0: q += c*u ; acc0 += v.q     (3 streams -> 2: u and v)
+//                                     MODE 1: q = (q + c*u)*gamma ; acc0 += u.q   (the gamma transition)
+//                                     MODE 2: q += c*u ; acc0 += q.q ; acc1 += v.q   (the last step, v = g)
+// Register rounds are FULL by construction (the host picks ER <= E-1), so they carry no bounds checks at all.
+template <int MODE>
+__device__ __forceinline__ void res_one(d2& q, const d2 uu, const d2 vv, const double c, const double gamma, double* acc) {
+    q.x = q.x + c * uu.x;  // math.rs:35
+    q.y = q.y + c * uu.y;
+    if constexpr (MODE == 1) { q.x = q.x * gamma; q.y = q.y * gamma; }  // math.rs:47
+    if constexpr (MODE == 2) {
+        acc[0] += q.x * q.x; acc[1] += vv.x * q.x;
+        acc[0] += q.y * q.y; acc[1] += vv.y * q.y;
+    } else if constexpr (MODE == 1) {
+        acc[0] += uu.x * q.x; acc[0] += uu.y * q.y;
+    } else {
+        acc[0] += vv.x * q.x; acc[0] += vv.y * q.y;
+    }
+}
+
+// ---- the register-resident part of q lives in the ACCUMULATION registers ------------------------------------------
+// gfx950 gives a wave that runs alone on its SIMD 512 registers per lane: 256 architectural VGPRs and 256 AGPRs.  The
+// compiler allocates the former; the latter it only uses for MFMA and as spill space.  Here pair k of a thread is parked
+// in a[4k .. 4k+3] by hand (v_accvgpr_write / _read through inline asm with the register NUMBER as a template constant),
+// which leaves all 256 VGPRs to the loads in flight and the arithmetic: 60 pairs = 240 AGPRs = 960 bytes per lane,
+// 60 MiB over the chip.  (Register arrays in C++ were tried first: with more than 24 pairs the allocator spills.)
+// The translation unit is built with -amdgpu-spill-vgpr-to-agpr=0 so that the compiler never touches an AGPR itself.
+template <int IDX>
+__device__ __forceinline__ unsigned int acc_rd() {  // (the number is spelled digit by digit: immediates above 9 print in hex)
+    unsigned int v;
+    if constexpr (IDX < 10) asm volatile("v_accvgpr_read_b32 %0, a%1" : "=v"(v) : "n"(IDX));
+    else if constexpr (IDX < 100) asm volatile("v_accvgpr_read_b32 %0, a%1%2" : "=v"(v) : "n"(IDX / 10), "n"(IDX % 10));
+    else asm volatile("v_accvgpr_read_b32 %0, a%1%2%3" : "=v"(v) : "n"(IDX / 100), "n"(IDX / 10 % 10), "n"(IDX % 10));
+    return v;
+}
+template <int IDX>
+__device__ __forceinline__ void acc_wr(unsigned int v) {
+    if constexpr (IDX < 10) asm volatile("v_accvgpr_write_b32 a%1, %0" ::"v"(v), "n"(IDX));
+    else if constexpr (IDX < 100) asm volatile("v_accvgpr_write_b32 a%1%2, %0" ::"v"(v), "n"(IDX / 10), "n"(IDX % 10));
+    else asm volatile("v_accvgpr_write_b32 a%1%2%3, %0" ::"v"(v), "n"(IDX / 100), "n"(IDX / 10 % 10), "n"(IDX % 10));
+}
+template <int K>
+__device__ __forceinline__ d2 acc_get() {
+    d2 q;
+    q.x = __hiloint2double((int)acc_rd<4 * K + 1>(), (int)acc_rd<4 * K>());
+    q.y = __hiloint2double((int)acc_rd<4 * K + 3>(), (int)acc_rd<4 * K + 2>());
+    return q;
+}
+template <int K>
+__device__ __forceinline__ void acc_put(const d2 q) {
+    acc_wr<4 * K>((unsigned int)__double2loint(q.x));
+    acc_wr<4 * K + 1>((unsigned int)__double2hiint(q.x));
+    acc_wr<4 * K + 2>((unsigned int)__double2loint(q.y));
+    acc_wr<4 * K + 3>((unsigned int)__double2hiint(q.y));
+}
+
+// a 16-byte access at uniform base + 32-bit byte offset (one VGPR per address: "saddr + voffset")
+template <bool NT>
+__device__ __forceinline__ d2 ld16_at(const double* base, const uint32_t byte_off) {
+    const d2* p = reinterpret_cast<const d2*>(reinterpret_cast<const char*>(base) + byte_off);
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st16_at(double* base, const uint32_t byte_off, const d2 v) {
+    d2* p = reinterpret_cast<d2*>(reinterpret_cast<char*>(base) + byte_off);
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+// The per-pair offsets are invariant across the steps, so the optimiser would compute all of them ONCE and keep them
+// live for the whole kernel -- one or two registers per pair, as much as the state itself.  Passing the first offset
+// through an empty asm makes it opaque: every group recomputes its four offsets (four v_add) right where it needs them.
+__device__ __forceinline__ uint32_t res_opaque(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// groups of RES_UNROLL pairs, unrolled by template recursion (the AGPR numbers must be compile-time constants)
+template <int G, int NG, bool NT, int MODE>
+struct ResGroups {
+    // loads of group G (issued one group AHEAD of their use: two groups = 16 loads of 16 bytes in flight per thread)
+    static __device__ __forceinline__ void fetch(const uint32_t p_first, const uint32_t p_stride, const double* up, const double* vp,
+                                                 d2 (&uu)[RES_UNROLL], d2 (&vv)[RES_UNROLL]) {
+        const uint32_t o0 = res_opaque(p_first);  // (p_first / p_stride are BYTE offsets here)
+#pragma unroll
+        for (int u = 0; u < RES_UNROLL; ++u) {
+            const uint32_t o = o0 + (uint32_t)(G * RES_UNROLL + u) * p_stride;
+            uu[u] = ld16_at<NT>(up, o);
+            if constexpr (MODE != 1) vv[u] = ld16_at<NT>(vp, o);
+            else vv[u] = uu[u];
+        }
+    }
+    static __device__ __forceinline__ void step_with(d2 (&uu)[RES_UNROLL], d2 (&vv)[RES_UNROLL], const uint32_t p_first,
+                                                     const uint32_t p_stride, const double* up, const double* vp, const double c,
+                                                     const double gamma, double* acc) {
+        if constexpr (G < NG) {
+            d2 nu[RES_UNROLL], nv[RES_UNROLL];
+            if constexpr (G + 1 < NG) ResGroups<G + 1, NG, NT, MODE>::fetch(p_first, p_stride, up, vp, nu, nv);
+            // a compiler barrier: without it every group's loads are hoisted to the top of the step and the kernel spills
+            asm volatile("" ::: "memory");
+            d2 q0 = acc_get<G * RES_UNROLL + 0>(), q1 = acc_get<G * RES_UNROLL + 1>(), q2 = acc_get<G * RES_UNROLL + 2>(),
+               q3 = acc_get<G * RES_UNROLL + 3>();
+            res_one<MODE>(q0, uu[0], vv[0], c, gamma, acc);
+            res_one<MODE>(q1, uu[1], vv[1], c, gamma, acc);
+            res_one<MODE>(q2, uu[2], vv[2], c, gamma, acc);
+            res_one<MODE>(q3, uu[3], vv[3], c, gamma, acc);
+            acc_put<G * RES_UNROLL + 0>(q0);
+            acc_put<G * RES_UNROLL + 1>(q1);
+            acc_put<G * RES_UNROLL + 2>(q2);
+            acc_put<G * RES_UNROLL + 3>(q3);
+            if constexpr (G + 1 < NG) ResGroups<G + 1, NG, NT, MODE>::step_with(nu, nv, p_first, p_stride, up, vp, c, gamma, acc);
+        }
+    }
+    static __device__ __forceinline__ void step(const uint32_t p_first, const uint32_t p_stride, const double* up, const double* vp,
+                                                const double c, const double gamma, double* acc) {
+        d2 uu[RES_UNROLL], vv[RES_UNROLL];
+        fetch(p_first, p_stride, up, vp, uu, vv);
+        step_with(uu, vv, p_first, p_stride, up, vp, c, gamma, acc);
+    }
+    // q = -g ; acc0 += s * (-g) when the first numerator is summed here
+    template <bool NEED_FIRST>
+    static __device__ __forceinline__ void init(const uint32_t p_first, const uint32_t p_stride, const double* gp, const double* sp,
+                                                double* acc) {
+        if constexpr (G < NG) {
+            d2 gg[RES_UNROLL], ss[RES_UNROLL];
+            const uint32_t o0 = res_opaque(p_first);
+#pragma unroll
+            for (int u = 0; u < RES_UNROLL; ++u) {
+                const uint32_t o = o0 + (uint32_t)(G * RES_UNROLL + u) * p_stride;
+                gg[u] = ld16_at<NT>(gp, o);
+                if constexpr (NEED_FIRST) ss[u] = ld16_at<NT>(sp, o);
+            }
+            asm volatile("" ::: "memory");  // (as in step_with: one group of loads at a time)
+#pragma unroll
+            for (int u = 0; u < RES_UNROLL; ++u) {
+                gg[u].x = -gg[u].x;
+                gg[u].y = -gg[u].y;
+                if constexpr (NEED_FIRST) {  // OpTwoLoopFirst: acc += s * (-g), element by element
+                    acc[0] += ss[u].x * gg[u].x;
+                    acc[0] += ss[u].y * gg[u].y;
+                }
+            }
+            acc_put<G * RES_UNROLL + 0>(gg[0]);
+            acc_put<G * RES_UNROLL + 1>(gg[1]);
+            acc_put<G * RES_UNROLL + 2>(gg[2]);
+            acc_put<G * RES_UNROLL + 3>(gg[3]);
+            ResGroups<G + 1, NG, NT, MODE>::template init<NEED_FIRST>(p_first, p_stride, gp, sp, acc);
+        }
+    }
+    static __device__ __forceinline__ void store(const uint32_t p_first, const uint32_t p_stride, double* dp) {
+        if constexpr (G < NG) {
+            const uint32_t o0 = res_opaque(p_first);
+            st16_at<NT>(dp, o0 + (uint32_t)(G * RES_UNROLL + 0) * p_stride, acc_get<G * RES_UNROLL + 0>());
+            st16_at<NT>(dp, o0 + (uint32_t)(G * RES_UNROLL + 1) * p_stride, acc_get<G * RES_UNROLL + 1>());
+            st16_at<NT>(dp, o0 + (uint32_t)(G * RES_UNROLL + 2) * p_stride, acc_get<G * RES_UNROLL + 2>());
+            st16_at<NT>(dp, o0 + (uint32_t)(G * RES_UNROLL + 3) * p_stride, acc_get<G * RES_UNROLL + 3>());
+            ResGroups<G + 1, NG, NT, MODE>::store(p_first, p_stride, dp);
+        }
+    }
+};
+
+// the LDS-resident rounds of one step (the ragged last round is among them: bounds-checked)
+template <int ER, bool NT, int MODE>
+__device__ __forceinline__ void res_step_lds(d2* q_lds, const uint32_t EL, const uint32_t p_first, const uint32_t p_stride,
+                                             const uint32_t n2, const double* up, const double* vp, const double c,
+                                             const double gamma, double* acc) {
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t e0 = 0; e0 < EL; e0 += RES_UNROLL) {
+        d2 uu[RES_UNROLL], vv[RES_UNROLL];
+        bool in[RES_UNROLL];
+#pragma unroll
+        for (int u = 0; u < RES_UNROLL; ++u) {
+            const uint32_t p = p_first + (ER + e0 + u) * p_stride;
+            in[u] = p < n2;
+            const uint32_t pc = in[u] ? p : 0u;  // (a valid address; the value is masked out below)
+            uu[u] = ld16<NT>(up, pc);
+            if constexpr (MODE != 1) vv[u] = ld16<NT>(vp, pc);
+            else vv[u] = uu[u];
+        }
+#pragma unroll
+        for (int u = 0; u < RES_UNROLL; ++u) {
+            if (!in[u]) { uu[u] = d2{0.0, 0.0}; vv[u] = d2{0.0, 0.0}; }  // padding pairs stay 0 and add 0
+            d2 q = q_lds[(size_t)(e0 + u) * BLOCK + tid];
+            res_one<MODE>(q, uu[u], vv[u], c, gamma, acc);
+            q_lds[(size_t)(e0 + u) * BLOCK + tid] = q;
+        }
+    }
+}
+
+// ER = pairs per thread held in (accumulation) registers: a multiple of RES_UNROLL, at most 60.
+template <int ER, bool NT>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
+    static_assert(ER % RES_UNROLL == 0 && ER >= RES_UNROLL && 4 * ER <= 256, "pairs in AGPRs");
+    asm volatile("" ::: "a255");  // this kernel owns the whole accumulation register file (the wave gets 512 registers)
+    extern __shared__ d2 q_lds[];  // [lds_pairs][BLOCK]
+    __shared__ double lds[2][WAVES];
+    __shared__ double s_tot[2];
+    __shared__ double s_alpha[RES_MAX_STEPS / 2];
+    constexpr int NG = ER / RES_UNROLL;
+    const DevCounters c0 = load_counters(red);
+    // 32-bit pair indices (the host admits only shards of < 2^28 pairs): one uniform stride, one add per element
+    const uint32_t n2 = (uint32_t)(a.n >> 1);
+    const uint32_t G = gridDim.x, B = blockIdx.x, tid = threadIdx.x;
+    const uint32_t EL = a.lds_pairs;
+    const uint32_t p_first = B * BLOCK + tid, p_stride = G * BLOCK;
+    // pair e of this thread: e < ER in registers (all in range), ER <= e < ER + EL in LDS; global pair (e*G + B)*BLOCK + tid
+    const bool tail_owner = (a.n & 1) && B == G - 1 && tid == 0;  // odd n: the last element, kept by one thread
+    double q_tail = 0.0;
+
+    double acc[2] = {0.0, 0.0};
+    // ---- q = -g ; optionally the first numerator s.(-g)
+    const bool need_first = a.first_dot == nullptr;
+    const uint32_t b_first = p_first * 16u, b_stride = p_stride * 16u;  // byte offsets (shards of < 2^28 pairs: < 2^32 bytes)
+    if (need_first) ResGroups<0, NG, NT, 0>::template init<true>(b_first, b_stride, a.g, a.first_s, acc);
+    else ResGroups<0, NG, NT, 0>::template init<false>(b_first, b_stride, a.g, a.first_s, acc);
+    for (uint32_t e0 = 0; e0 < EL; e0 += RES_UNROLL) {
+#pragma unroll
+        for (int u = 0; u < RES_UNROLL; ++u) {
+            const uint32_t p = p_first + (ER + e0 + u) * p_stride;
+            d2 q = d2{0.0, 0.0}, sv = d2{0.0, 0.0};
+            if (p < n2) {
+                const d2 gv = ld16<NT>(a.g, p);
+                q.x = -gv.x;
+                q.y = -gv.y;
+                if (need_first) sv = ld16<NT>(a.first_s, p);
+            }
+            acc[0] += sv.x * q.x;
+            acc[0] += sv.y * q.y;
+            q_lds[(size_t)(e0 + u) * BLOCK + tid] = q;
+        }
+    }
+    if (tail_owner) {
+        q_tail = -a.g[a.n - 1];
+        if (need_first) acc[0] += a.first_s[a.n - 1] * q_tail;
+    }
+    unsigned int tag = c0.red_epoch;
+    int parity = 0;
+    double dot;
+    if (need_first) {
+        double t1[1] = {acc[0]};
+        res_exchange<1>(t1, red, tag, parity, lds, s_tot);
+        dot = t1[0];
+        tag = next_epoch(tag);
+        parity ^= 1;
+    } else {
+        dot = *a.first_dot;
+    }
+    const double gamma = *a.gnum / *a.gden;  // lbfgs.rs:691 (the quotient every path forms)
+
+    // ---- the 2*bound steps
+    for (int si = 0; si < a.nsteps; ++si) {
+        const ResStep st = a.step[si];
+        const double r = dot / *st.ys;
+        double c;
+        if (st.mode_b) {
+            c = s_alpha[st.alpha_idx] - r;
+        } else {
+            c = -r;
+            if (tid == 0) s_alpha[st.alpha_idx] = r;  // read again (by every thread) only after later barriers
+            if (B == 0 && tid == 0) *st.alpha = r;
+        }
+        acc[0] = 0.0;
+        acc[1] = 0.0;
+        const int mode = st.last ? 2 : (st.v == nullptr ? 1 : 0);
+        if (mode == 0) {
+            ResGroups<0, NG, NT, 0>::step(b_first, b_stride, st.u, st.v, c, gamma, acc);
+            res_step_lds<ER, NT, 0>(q_lds, EL, p_first, p_stride, n2, st.u, st.v, c, gamma, acc);
+        } else if (mode == 1) {
+            ResGroups<0, NG, NT, 1>::step(b_first, b_stride, st.u, st.u, c, gamma, acc);
+            res_step_lds<ER, NT, 1>(q_lds, EL, p_first, p_stride, n2, st.u, st.u, c, gamma, acc);
+        } else {
+            ResGroups<0, NG, NT, 2>::step(b_first, b_stride, st.u, st.v, c, gamma, acc);
+            res_step_lds<ER, NT, 2>(q_lds, EL, p_first, p_stride, n2, st.u, st.v, c, gamma, acc);
+        }
+        if (tail_owner) {
+            const double ut = st.u[a.n - 1], vt = (mode == 1) ? ut : st.v[a.n - 1];
+            q_tail = q_tail + c * ut;
+            if (mode == 1) q_tail = q_tail * gamma;
+            if (mode == 2) { acc[0] += q_tail * q_tail; acc[1] += vt * q_tail; }
+            else acc[0] += vt * q_tail;
+        }
+        if (mode == 2) {
+            res_exchange<2>(acc, red, tag, parity, lds, s_tot);
+        } else {
+            double t1[1] = {acc[0]};
+            res_exchange<1>(t1, red, tag, parity, lds, s_tot);
+            dot = t1[0];
+        }
+        tag = next_epoch(tag);
+        parity ^= 1;
+    }
+
+    // ---- d = q ; totals
+    ResGroups<0, NG, NT, 0>::store(b_first, b_stride, a.d);
+    for (uint32_t e = 0; e < EL; ++e) {
+        const uint32_t p = p_first + (ER + e) * p_stride;
+        if (p < n2) st16<NT>(a.d, p, q_lds[(size_t)e * BLOCK + tid]);
+    }
+    if (tail_owner) a.d[a.n - 1] = q_tail;
+    if (B == 0 && tid == 0) {
+        a.out_dn[0] = acc[0];
+        a.out_dn[1] = acc[1];
+        red.ctr->red_epoch = tag;  // every workgroup has left the last hand-off with `tag - 1`: nobody reads the counter again
+        if (red.mirror.host_board) {
+            const long i0 = a.out_dn - red.mirror.board;
+            if (i0 >= 0 && i0 + 1 < red.mirror.slots) {
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(red.mirror.host_board + i0),
+                                   (unsigned long long)__double_as_longlong(acc[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(red.mirror.host_board + i0 + 1),
+                                   (unsigned long long)__double_as_longlong(acc[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            if (red.mirror.host_err) {
+                const unsigned int e = __hip_atomic_load(red.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (e) __hip_atomic_store(red.mirror.host_err, (unsigned long long)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            const unsigned long long seq = c0.mirror_seq + 1ull;
+            red.ctr->mirror_seq = seq;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(red.mirror.host_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+}  // namespace lh

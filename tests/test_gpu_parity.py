@@ -958,3 +958,55 @@ def test_two_loop_launch_forms_are_bitwise_equal(knob, owl, monkeypatch):
         assert len(rows["0"][0]) in (iters, 12)
         assert rows["0"][0] == rows["1"][0]
         assert np.array_equal(rows["0"][1], rows["1"][1])
+
+
+@pytest.mark.parametrize("n", [1_200_001, 2_097_152, 3_000_017, 8_000_000, 12_500_224])
+@pytest.mark.parametrize("m,k,end", [(10, 37, 3), (10, 4, 3), (6, 1, 0), (7, 7, 6)])
+def test_two_loop_resident_kernel_vs_launch_per_step(n, m, k, end, monkeypatch):
+    """The recursion as ONE kernel with the running vector resident in registers + LDS (resident.h) against the
+    launch-per-step path on the same device data: direction within 1e-12 of each other (only the order of the dot
+    products' partial sums differs), the two sums it leaves for the host, the alphas, the new ring position; with the
+    first numerator summed by the kernel itself (two_loop) and handed in (two_loop_from); and bitwise determinism."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("the test double has one path")
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("LBFGS_HIP_RESIDENT", mode)
+        with R.Context(n) as ctx:
+            hist = H.History(ctx, m)
+            g, d, tmp = (DeviceVec(ctx) for _ in range(3))
+            q = objectives.Quadratic()
+            for j in range(m):
+                tmp.fill(0.25 + 0.1 * j)
+                H.objective_eval(q, tmp, hist.s(j), 0)
+                H.objective_eval(q, hist.s(j), hist.y(j), 0)
+                hist.y(j).vecadd(hist.s(j), 2.0)
+            ys = [hist.y(j).vecdot(hist.s(j)) for j in range(m)]
+            hist.set_scalars(ys=np.array(ys), alpha=np.zeros(m))
+            tmp.fill(-0.3)
+            H.objective_eval(objectives.Logistic(), tmp, g, 0)
+            ctx.set_scalars(7, [ys[end], hist.y(end).vecdot(hist.y(end))])
+            res = []
+            ne = hist.two_loop(d, g, k, end, 7, 8, 12)
+            res.append((ne, d.to_numpy(), ctx.scalars(12, 2), hist.scalars()[1]))
+            hist.two_loop(d, g, k, end, 7, 8, 12)   # determinism
+            assert np.array_equal(d.to_numpy(), res[0][1]) and np.array_equal(ctx.scalars(12, 2), res[0][2])
+            # the first numerator handed in: s_{j0} . (-g), j0 = the slot `end` (the newest correction)
+            tmp.vecncpy(g)
+            ctx.set_scalars(30, [hist.s(end).vecdot(tmp)])
+            ne2 = hist.two_loop_from(d, g, k, end, 30, 7, 8, 13)
+            res.append((ne2, d.to_numpy(), ctx.scalars(13, 2), hist.scalars()[1]))
+            assert ctx.resident_two_loops() == (3 if mode == "1" else 0)  # the path under test really ran
+            out[mode] = res
+            hist.free()
+            for v in (g, d, tmp):
+                v.free()
+    for a, b in zip(out["0"], out["1"]):
+        assert a[0] == b[0]
+        scale = np.max(np.abs(a[1]))
+        assert scale > 0 and np.all(np.isfinite(b[1]))
+        assert np.max(np.abs(a[1] - b[1])) <= 1e-12 * scale
+        assert np.max(np.abs(a[2] - b[2])) <= 1e-12 * np.max(np.abs(a[2]))
+        assert np.max(np.abs(a[3] - b[3])) <= 1e-12 * max(np.max(np.abs(a[3])), 1e-300)
+    # two_loop and two_loop_from agree with each other too
+    assert np.max(np.abs(out["1"][0][1] - out["1"][1][1])) <= 1e-12 * np.max(np.abs(out["1"][0][1]))
