@@ -230,7 +230,8 @@ def make_context(env, kind):
         return R.Context(a.n, device=env.dev), "none"
     ok, ctx = 1.0, None
     try:
-        ctx = sharded_context(a.n, device=env.dev, kind=kind)
+        # one rank per GPU (the driver's launch) unless --device forces several ranks onto one card (tests)
+        ctx = sharded_context(a.n, device=env.dev, kind=kind, exclusive_device=a.device < 0)
         # known-answer reductions through the real code path before trusting it
         tri = env.world * (env.world + 1) / 2.0
         for it in range(16):

@@ -78,7 +78,10 @@ typedef int (*lbfgs_hip_allreduce_cb)(void* user, double* buf, int32_t count);
 
 typedef struct lbfgs_hip_comm {
     int32_t kind;
-    int32_t _pad;
+    int32_t exclusive_device;    /* P2P: non-zero = this rank has its GPU to itself (one process per GPU, the deployment this
+                                    library is built for).  Only then may a kernel that occupies the WHOLE chip while it waits
+                                    for its peers be used (the on-chip-resident two-loop, rust-lbfgs_amd/csrc/resident.h): ranks
+                                    that share a GPU would keep each other from running.  0 = assume the GPU may be shared. */
     const void* rccl_unique_id;  /* 128 bytes from lbfgs_hip_rccl_unique_id() on rank 0, shared out of band */
     lbfgs_hip_allreduce_cb callback;
     void* callback_user;

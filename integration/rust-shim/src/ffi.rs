@@ -52,7 +52,7 @@ pub type lbfgs_hip_allreduce_cb = Option<unsafe extern "C" fn(user: *mut c_void,
 #[repr(C)]
 pub struct lbfgs_hip_comm {
     pub kind: i32,
-    pub _pad: i32,
+    pub exclusive_device: i32,
     pub rccl_unique_id: *const c_void,
     pub callback: lbfgs_hip_allreduce_cb,
     pub callback_user: *mut c_void,

@@ -38,7 +38,7 @@ ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32
 
 
 class Comm(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("rccl_unique_id", C.c_void_p),
+    _fields_ = [("kind", C.c_int32), ("exclusive_device", C.c_int32), ("rccl_unique_id", C.c_void_p),
                 ("callback", ALLREDUCE_CB), ("callback_user", C.c_void_p),
                 ("p2p_mailbox", C.c_void_p), ("p2p_handles", C.c_void_p), ("p2p_timeout_s", C.c_double)]
 

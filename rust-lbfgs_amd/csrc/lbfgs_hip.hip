@@ -160,6 +160,8 @@ struct lbfgs_hip_ctx {
     size_t lj_scratch_bytes = 0;
     struct LjCells* lj_cells = nullptr;   // LJ_CELLS: the rebuildable neighbour structure (allocated on demand)
     unsigned long long* gran = nullptr;   // tagged partial granules [MAX_RED][MAX_GRID][2] (stream.h)
+    bool p2p_exclusive = false;           // lbfgs_hip_comm.exclusive_device: no other rank shares this GPU
+    int resident_grid = 0;                // LBFGS_HIP_RESIDENT_GRID: workgroups of the resident kernel (0 = one per CU); tests
     bool resident_on = true;              // LBFGS_HIP_RESIDENT=0: never use the on-chip-resident two-loop kernel (resident.h)
     unsigned long long resident_launches = 0;  // two-loops that ran as the resident kernel (tests / bench read it)
     int resident_ok = -1;                 // -1 = not probed yet, 0 = this device cannot hold the grid resident, 1 = usable
@@ -992,6 +994,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     if (const char* e = getenv("LBFGS_HIP_NT_THRESHOLD_MB")) ctx->nt_threshold_bytes = (size_t)atoll(e) << 20;
     if (const char* e = getenv("LBFGS_HIP_DEFER_SUMS")) ctx->defer_inner_sums = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT")) ctx->resident_on = atoi(e) != 0;
+    if (const char* e = getenv("LBFGS_HIP_RESIDENT_GRID")) ctx->resident_grid = std::max(0, atoi(e));
     if (const char* e = getenv("LBFGS_HIP_GRAPH")) ctx->graph_max_bytes = atoi(e) ? ~(size_t)0 : 0;
     if (const char* e = getenv("LBFGS_HIP_GRAPH_MAX_MB")) ctx->graph_max_bytes = (size_t)atoll(e) << 20;
     if (const char* e = getenv("LBFGS_HIP_NT_STORE_THRESHOLD_MB")) ctx->nt_store_threshold_bytes = (size_t)atoll(e) << 20;
@@ -1080,6 +1083,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
         }
         const double tmo = comm->p2p_timeout_s > 0 ? comm->p2p_timeout_s : 5.0;
         ctx->p2p_timeout_ticks = (unsigned long long)(tmo * 1e8);  // wall_clock64 runs at 100 MHz
+        ctx->p2p_exclusive = comm->exclusive_device != 0;
         ctx->comm_kind = LBFGS_HIP_COMM_P2P;
     } else if (kind == LBFGS_HIP_COMM_CALLBACK) {
         if (!comm->callback) {
@@ -1559,14 +1563,19 @@ int resident_launch(lbfgs_hip_ctx* ctx, const ResArgs& ra, const RedCtl& red, in
 
 // -> 1 if the recursion was launched as the resident kernel, 0 if this case is not eligible (caller falls back), < 0 error
 int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
-                      int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end) {
+                      int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end, bool owl,
+                      uint64_t owl_start, uint64_t owl_end) {
     lbfgs_hip_ctx* ctx = h->ctx;
     const int m = h->m;
     const int bound = (int)std::min<uint64_t>((uint64_t)m, k);
-    if (!ctx->resident_on || ctx->comm_kind != LBFGS_HIP_COMM_NONE || ctx->handoff_ticket || bound < 1 || ctx->capturing ||
-        ctx->grid_override > 0 || 2 * bound > RES_MAX_STEPS)
+    // One rank -- or several that each have their GPU to themselves: a kernel that fills the chip and waits for its peers
+    // inside would starve ranks sharing the GPU (lbfgs_hip_comm.exclusive_device).
+    const bool comm_ok = ctx->comm_kind == LBFGS_HIP_COMM_NONE || (ctx->comm_kind == LBFGS_HIP_COMM_P2P && ctx->p2p_exclusive);
+    if (!ctx->resident_on || !comm_ok || ctx->handoff_ticket || bound < 1 || ctx->capturing || ctx->grid_override > 0 ||
+        2 * bound > RES_MAX_STEPS)
         return 0;
-    const int grid = ctx->cu_count;  // one workgroup per CU: all of them resident at once
+    // one workgroup per CU: all of them resident at once (fewer only on request: tests run two ranks on one GPU)
+    const int grid = ctx->resident_grid > 0 ? std::min(ctx->resident_grid, ctx->cu_count) : ctx->cu_count;
     if (grid < 1 || grid > BLOCK || grid > MAX_GRID) return 0;  // (every thread polls one workgroup's granules)
     const uint64_t n = ctx->shard.n_local;
     const uint64_t per_round = (uint64_t)grid * BLOCK;
@@ -1608,6 +1617,10 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     ra.gden = ctx->board + gamma_den_slot;
     ra.out_dn = ctx->board + dnorm_slot;
     ra.n = n;
+    ra.gofs = ctx->shard.offset;
+    ra.owl = owl ? 1 : 0;
+    ra.owl_start = owl_start;
+    ra.owl_end = owl_end;
     ra.pairs_per_thread = (uint32_t)E;
     ra.lds_pairs = el;
     int ns = 0;
@@ -1626,10 +1639,12 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
 
     RedCtl red{};
     bool in_kernel_exchange = false;
-    double* outs2[2] = {ra.out_dn, ra.out_dn + 1};
-    const int rc_p = prep_red(ctx, red, 2, outs2, nullptr, 0, &in_kernel_exchange);
+    double* outs2[4] = {ra.out_dn, ra.out_dn + 1, ra.out_dn + 2, ra.out_dn + 3};
+    const int rc_p = prep_red(ctx, red, owl ? 4 : 2, outs2, nullptr, 0, &in_kernel_exchange);
     if (rc_p != LBFGS_HIP_OK) return rc_p;
-    ctx->red_count += (unsigned long long)(ns + (ra.first_dot ? 0 : 1)) - 1ull;  // one tag per hand-off (prep_red counted one)
+    const unsigned long long handoffs = (unsigned long long)(ns + (ra.first_dot ? 0 : 1) + (owl ? 1 : 0));
+    ctx->red_count += handoffs - 1ull;  // one tag per hand-off (prep_red counted one)
+    if (in_kernel_exchange) ctx->p2p_count += handoffs - 1ull;  // ... and one P2P epoch each (prep_red counted one)
     const bool nt = n * sizeof(double) >= ctx->nt_store_threshold_bytes;  // the history vectors are read once per step either way
     const size_t lds_bytes = (size_t)el * BLOCK * sizeof(d2);
     int rc;
@@ -1666,8 +1681,9 @@ static int two_loop_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip
         return LBFGS_HIP_ERR_ARG;
     if (!slot_ok(gamma_num_slot, 1) || !slot_ok(gamma_den_slot, 1) || !slot_ok(dnorm_slot, 2)) return LBFGS_HIP_ERR_ARG;
     lbfgs_hip_ctx* ctx = h->ctx;
-    if (!owl) {  // small enough to keep the running vector on the chip?  then the whole recursion is one kernel
-        const int rr = two_loop_resident(h, d, g, k, end, gamma_num_slot, gamma_den_slot, dnorm_slot, first_dot_slot, new_end);
+    {  // small enough to keep the running vector on the chip?  then the whole recursion is one kernel
+        const int rr = two_loop_resident(h, d, g, k, end, gamma_num_slot, gamma_den_slot, dnorm_slot, first_dot_slot, new_end, owl,
+                                         owl_start, owl_end);
         if (rr != 0) return rr < 0 ? rr : LBFGS_HIP_OK;
     }
     const uint64_t bound = std::min<uint64_t>((uint64_t)h->m, k);

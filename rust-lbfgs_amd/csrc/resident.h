@@ -32,7 +32,7 @@
 namespace lh {
 
 constexpr int RES_MAX_STEPS = 2 * 24;  // 2 * bound for bound <= 24 (the step table travels as a kernel argument: < 4 KiB)
-constexpr int RES_LDS_PAIRS_MAX = 36;  // 160 KiB / (256 threads x 16 B) = 40, less the kernel's small static arrays,
+constexpr int RES_LDS_PAIRS_MAX = 36;  // 160 KiB / (256 threads x 16 B) = 40, less the kernel's static arrays (4.3 KiB),
                                        // rounded down to a multiple of RES_UNROLL
 constexpr int RES_UNROLL = 4;          // pairs whose loads are issued together
 
@@ -56,6 +56,9 @@ struct ResArgs {
     const double* gden;
     double* out_dn;          // ||d||^2 ; out_dn[1] = g.d
     uint64_t n;              // elements of this rank's shard
+    uint64_t gofs;           // global index of this shard's first element (OWL-QN's range is global)
+    uint64_t owl_start, owl_end;  // OWL-QN: the last step also projects d onto the orthant of -pg on [start, end)
+    int owl;                      //   (orthantwise.rs:140-161; then v of the last step is pg) and leaves 3 sums
     uint32_t pairs_per_thread;  // E: 16-byte pairs each thread owns (registers first, then LDS)
     uint32_t lds_pairs;         // of which in LDS (a multiple of RES_UNROLL)
     int nsteps;
@@ -63,18 +66,25 @@ struct ResArgs {
 };
 
 // Publish this workgroup's NS partial sums of sequence number `tag`, then collect everybody's and return the totals
-// (identical bits in every workgroup).  gran rows: [parity][k].  All threads call it.
+// (identical bits in every workgroup).  gran rows: [parity*4 + k], k < 4.  All threads call it.
+//   one rank      EVERY workgroup polls all G partials itself and adds them up: one hop.
+//   several ranks only workgroup 0 does that; it then exchanges this rank's totals with the peers through the xGMI
+//                 mailboxes (stream.h p2p_exchange, epoch `p2p_tag`; rank-ordered sum: the same bits on every rank) and
+//                 publishes the global totals as tagged granules in rows [8 + parity*4 + k], which the other workgroups
+//                 poll.  The mailbox is uncached and system-scope: one poller per GPU, not 256.
 template <int NS>
-__device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& red, const unsigned int tag, const int parity,
-                                             double (*lds)[WAVES], double* s_tot) {
+__device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& red, const unsigned int tag, const unsigned int p2p_tag,
+                                             const int parity, double (*lds)[WAVES], double* s_tot,
+                                             unsigned int (*s_bits)[MAX_RED][2]) {
     block_sum<NS>(acc, lds);
     const unsigned int G = gridDim.x;
+    const bool multi = red.p2p.world > 1;
+    const unsigned long long t = (unsigned long long)tag << 32;
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             const unsigned long long b = (unsigned long long)__double_as_longlong(acc[k]);
-            unsigned long long* g = red.gran + ((size_t)(parity * 2 + k) * MAX_GRID + blockIdx.x) * 2;
-            const unsigned long long t = (unsigned long long)tag << 32;
+            unsigned long long* g = red.gran + ((size_t)(parity * 4 + k) * MAX_GRID + blockIdx.x) * 2;
             __hip_atomic_store(g, t | (b & 0xffffffffULL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(g + 1, t | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -84,34 +94,65 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
 #pragma unroll
     for (int k = 0; k < NS; ++k) tot[k] = 0.0;
     const long long t0 = wall_clock64();
-    for (unsigned int b = threadIdx.x; b < G; b += BLOCK) {  // (G <= BLOCK in practice: one poll loop per thread)
-        unsigned long long lo[NS], hi[NS];
-        for (;;) {
-            bool ok = true;
+    if (!multi || blockIdx.x == 0) {
+        for (unsigned int b = threadIdx.x; b < G; b += BLOCK) {  // (G <= BLOCK in practice: one poll loop per thread)
+            unsigned long long lo[NS], hi[NS];
+            for (;;) {
+                bool ok = true;
 #pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const unsigned long long* g = red.gran + ((size_t)(parity * 2 + k) * MAX_GRID + b) * 2;
-                lo[k] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                hi[k] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int k = 0; k < NS; ++k) {
+                    const unsigned long long* g = red.gran + ((size_t)(parity * 4 + k) * MAX_GRID + b) * 2;
+                    lo[k] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hi[k] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int k = 0; k < NS; ++k) ok = ok && (unsigned int)(lo[k] >> 32) == tag && (unsigned int)(hi[k] >> 32) == tag;
+                if (ok) break;
+                if ((unsigned long long)(wall_clock64() - t0) > red.timeout_ticks) {
+                    atomicExch(red.err, 2u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
             }
 #pragma unroll
-            for (int k = 0; k < NS; ++k) ok = ok && (unsigned int)(lo[k] >> 32) == tag && (unsigned int)(hi[k] >> 32) == tag;
-            if (ok) break;
-            if ((unsigned long long)(wall_clock64() - t0) > red.timeout_ticks) {
-                atomicExch(red.err, 2u);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
+            for (int k = 0; k < NS; ++k) tot[k] += __longlong_as_double((long long)((hi[k] << 32) | (lo[k] & 0xffffffffULL)));
         }
+        block_sum<NS>(tot, lds);  // the reducer's order: thread-strided partials, wave tree, waves in order
+        if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < NS; ++k) tot[k] += __longlong_as_double((long long)((hi[k] << 32) | (lo[k] & 0xffffffffULL)));
-    }
-    block_sum<NS>(tot, lds);  // the reducer's order: thread-strided partials, wave tree, waves in order
-    if (threadIdx.x == 0) {
+            for (int k = 0; k < NS; ++k) s_tot[k] = tot[k];
+        }
+        __syncthreads();
+        if (multi) {  // (workgroup 0 only) this rank's totals -> the global totals, then tell the other workgroups
+            p2p_exchange(red.p2p, p2p_tag, s_tot, NS, s_bits);
+            if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < NS; ++k) s_tot[k] = tot[k];
+                for (int k = 0; k < NS; ++k) {
+                    const unsigned long long b = (unsigned long long)__double_as_longlong(s_tot[k]);
+                    unsigned long long* g = red.gran + ((size_t)(8 + parity * 4 + k) * MAX_GRID) * 2;
+                    __hip_atomic_store(g, t | (b & 0xffffffffULL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(g + 1, t | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    } else {
+        if (threadIdx.x < NS) {  // one lane per sum polls the global total workgroup 0 will publish
+            const unsigned long long* g = red.gran + ((size_t)(8 + parity * 4 + threadIdx.x) * MAX_GRID) * 2;
+            unsigned long long lo, hi;
+            for (;;) {
+                lo = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hi = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned int)(lo >> 32) == tag && (unsigned int)(hi >> 32) == tag) break;
+                if ((unsigned long long)(wall_clock64() - t0) > red.timeout_ticks + red.p2p.timeout_ticks) {
+                    atomicExch(red.err, 2u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            s_tot[threadIdx.x] = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffULL)));
+        }
+        __syncthreads();
     }
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < NS; ++k) acc[k] = s_tot[k];
     __syncthreads();  // s_tot and lds are free again
@@ -121,6 +162,19 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
 //                                     MODE 1: q = (q + c*u)*gamma ; acc0 += u.q   (the gamma transition)
 //                                     MODE 2: q += c*u ; acc0 += q.q ; acc1 += v.q   (the last step, v = g)
 // Register rounds are FULL by construction (the host picks ER <= E-1), so they carry no bounds checks at all.
+// Under OWL-QN the last step is MODE 2 with v = pg (acc0 = ||d||^2 BEFORE the projection: lbfgs.rs:543 precedes :554); the
+// projection d_i = 0 where signum(d_i) != signum(-pg_i) on [start, end) (orthantwise.rs:140-161) is applied where d is
+// written out, which sums ||d||^2 and pg.d of the projected direction (one more hand-off, pg read once more).
+struct ResOwl {
+    uint64_t gofs, start, end;
+};
+// orthantwise.rs:174-180 as an integer, branch-free: NaN and +-0 -> 0, else the sign
+__device__ __forceinline__ int res_sgn(const double x) { return (int)(x > 0.0) - (int)(x < 0.0); }
+// d_i = 0 where signum(d_i) != signum(-pg_i), for i in [start, end) (orthantwise.rs:140-161); selects only
+__device__ __forceinline__ double res_project(const double q, const double pg, const uint64_t gi, const ResOwl& ow) {
+    const bool out = (gi >= ow.start) & (gi < ow.end) & (res_sgn(q) != -res_sgn(pg));
+    return out ? 0.0 : q;
+}
 template <int MODE>
 __device__ __forceinline__ void res_one(d2& q, const d2 uu, const d2 vv, const double c, const double gamma, double* acc) {
     q.x = q.x + c * uu.x;  // math.rs:35
@@ -192,6 +246,16 @@ __device__ __forceinline__ uint32_t res_opaque(uint32_t v) {
     asm volatile("" : "+v"(v));
     return v;
 }
+// The running sums are one serial chain of additions per step; left alone, the scheduler (which believes it has 512
+// registers to spend) defers that chain and keeps every group's loaded operands alive for it -- over 256 live registers,
+// at which point the register allocator parks values in the very AGPRs that hold q.  Pinning the sums at the end of each
+// group (volatile asm statements keep their order) makes a group's arithmetic finish before the next group's begins.
+__device__ __forceinline__ void res_pin(double& a) { asm volatile("" : "+v"(a)); }
+template <int NS>
+__device__ __forceinline__ void res_pin_sums(double* acc) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) res_pin(acc[k]);
+}
 
 // groups of RES_UNROLL pairs, unrolled by template recursion (the AGPR numbers must be compile-time constants)
 template <int G, int NG, bool NT, int MODE>
@@ -226,6 +290,7 @@ struct ResGroups {
             acc_put<G * RES_UNROLL + 1>(q1);
             acc_put<G * RES_UNROLL + 2>(q2);
             acc_put<G * RES_UNROLL + 3>(q3);
+            res_pin_sums<(MODE == 2 ? 2 : 1)>(acc);
             if constexpr (G + 1 < NG) ResGroups<G + 1, NG, NT, MODE>::step_with(nu, nv, p_first, p_stride, up, vp, c, gamma, acc);
         }
     }
@@ -262,7 +327,33 @@ struct ResGroups {
             acc_put<G * RES_UNROLL + 1>(gg[1]);
             acc_put<G * RES_UNROLL + 2>(gg[2]);
             acc_put<G * RES_UNROLL + 3>(gg[3]);
+            if constexpr (NEED_FIRST) res_pin_sums<1>(acc);
             ResGroups<G + 1, NG, NT, MODE>::template init<NEED_FIRST>(p_first, p_stride, gp, sp, acc);
+        }
+    }
+    // d = project(q) ; acc1 += d.d ; acc2 += pg.d  (OWL-QN: see res_one's note)
+    static __device__ __forceinline__ void store_owl(const uint32_t p_first, const uint32_t p_stride, double* dp, const double* pgp,
+                                                     const ResOwl& ow, double* acc) {
+        if constexpr (G < NG) {
+            const uint32_t o0 = res_opaque(p_first);
+            d2 pg[RES_UNROLL];
+#pragma unroll
+            for (int u = 0; u < RES_UNROLL; ++u) pg[u] = ld16_at<NT>(pgp, o0 + (uint32_t)(G * RES_UNROLL + u) * p_stride);
+            asm volatile("" ::: "memory");
+            d2 q[RES_UNROLL] = {acc_get<G * RES_UNROLL + 0>(), acc_get<G * RES_UNROLL + 1>(), acc_get<G * RES_UNROLL + 2>(),
+                                acc_get<G * RES_UNROLL + 3>()};
+#pragma unroll
+            for (int u = 0; u < RES_UNROLL; ++u) {
+                const uint32_t o = o0 + (uint32_t)(G * RES_UNROLL + u) * p_stride;
+                const uint64_t gi = ow.gofs + 2ull * (o >> 4);
+                q[u].x = res_project(q[u].x, pg[u].x, gi, ow);
+                acc[1] += q[u].x * q[u].x; acc[2] += pg[u].x * q[u].x;
+                q[u].y = res_project(q[u].y, pg[u].y, gi + 1, ow);
+                acc[1] += q[u].y * q[u].y; acc[2] += pg[u].y * q[u].y;
+                st16_at<NT>(dp, o, q[u]);
+            }
+            res_pin_sums<2>(acc + 1);
+            ResGroups<G + 1, NG, NT, MODE>::store_owl(p_first, p_stride, dp, pgp, ow, acc);
         }
     }
     static __device__ __forceinline__ void store(const uint32_t p_first, const uint32_t p_stride, double* dp) {
@@ -312,9 +403,10 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
     static_assert(ER % RES_UNROLL == 0 && ER >= RES_UNROLL && 4 * ER <= 256, "pairs in AGPRs");
     asm volatile("" ::: "a255");  // this kernel owns the whole accumulation register file (the wave gets 512 registers)
     extern __shared__ d2 q_lds[];  // [lds_pairs][BLOCK]
-    __shared__ double lds[2][WAVES];
-    __shared__ double s_tot[2];
+    __shared__ double lds[3][WAVES];
+    __shared__ double s_tot[3];
     __shared__ double s_alpha[RES_MAX_STEPS / 2];
+    __shared__ unsigned int s_bits[P2P_MAX_WORLD][MAX_RED][2];  // (p2p_exchange's staging: 4 KiB; unused with one rank)
     constexpr int NG = ER / RES_UNROLL;
     const DevCounters c0 = load_counters(red);
     // 32-bit pair indices (the host admits only shards of < 2^28 pairs): one uniform stride, one add per element
@@ -326,7 +418,8 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
     const bool tail_owner = (a.n & 1) && B == G - 1 && tid == 0;  // odd n: the last element, kept by one thread
     double q_tail = 0.0;
 
-    double acc[2] = {0.0, 0.0};
+    double acc[3] = {0.0, 0.0, 0.0};
+    const ResOwl ow{a.gofs, a.owl_start, a.owl_end};
     // ---- q = -g ; optionally the first numerator s.(-g)
     const bool need_first = a.first_dot == nullptr;
     const uint32_t b_first = p_first * 16u, b_stride = p_stride * 16u;  // byte offsets (shards of < 2^28 pairs: < 2^32 bytes)
@@ -352,14 +445,15 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         q_tail = -a.g[a.n - 1];
         if (need_first) acc[0] += a.first_s[a.n - 1] * q_tail;
     }
-    unsigned int tag = c0.red_epoch;
+    unsigned int tag = c0.red_epoch, ptag = c0.p2p_epoch;
     int parity = 0;
     double dot;
     if (need_first) {
         double t1[1] = {acc[0]};
-        res_exchange<1>(t1, red, tag, parity, lds, s_tot);
+        res_exchange<1>(t1, red, tag, ptag, parity, lds, s_tot, s_bits);
         dot = t1[0];
         tag = next_epoch(tag);
+        ptag = next_epoch(ptag);
         parity ^= 1;
     } else {
         dot = *a.first_dot;
@@ -380,6 +474,7 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         }
         acc[0] = 0.0;
         acc[1] = 0.0;
+        acc[2] = 0.0;
         const int mode = st.last ? 2 : (st.v == nullptr ? 1 : 0);
         if (mode == 0) {
             ResGroups<0, NG, NT, 0>::step(b_first, b_stride, st.u, st.v, c, gamma, acc);
@@ -399,34 +494,76 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
             else acc[0] += vt * q_tail;
         }
         if (mode == 2) {
-            res_exchange<2>(acc, red, tag, parity, lds, s_tot);
+            double t2[2] = {acc[0], acc[1]};
+            res_exchange<2>(t2, red, tag, ptag, parity, lds, s_tot, s_bits);
+            acc[0] = t2[0];
+            acc[1] = t2[1];
         } else {
             double t1[1] = {acc[0]};
-            res_exchange<1>(t1, red, tag, parity, lds, s_tot);
+            res_exchange<1>(t1, red, tag, ptag, parity, lds, s_tot, s_bits);
             dot = t1[0];
         }
         tag = next_epoch(tag);
+        ptag = next_epoch(ptag);
         parity ^= 1;
     }
 
-    // ---- d = q ; totals
-    ResGroups<0, NG, NT, 0>::store(b_first, b_stride, a.d);
-    for (uint32_t e = 0; e < EL; ++e) {
-        const uint32_t p = p_first + (ER + e) * p_stride;
-        if (p < n2) st16<NT>(a.d, p, q_lds[(size_t)e * BLOCK + tid]);
+    // ---- d = q (OWL-QN: projected, with the sums of the projected direction) ; totals
+    if (a.owl) {
+        const double* pgp = a.step[a.nsteps - 1].v;  // the last step's v is pg
+        const double pre = acc[0];                     // ||d||^2 before the projection (global)
+        acc[1] = 0.0;
+        acc[2] = 0.0;
+        ResGroups<0, NG, NT, 0>::store_owl(b_first, b_stride, a.d, pgp, ow, acc);
+        for (uint32_t e = 0; e < EL; ++e) {
+            const uint32_t p = p_first + (ER + e) * p_stride;
+            if (p < n2) {
+                const d2 pg = ld16<NT>(pgp, p);
+                d2 q = q_lds[(size_t)e * BLOCK + tid];
+                const uint64_t gi = a.gofs + 2ull * p;
+                q.x = res_project(q.x, pg.x, gi, ow);
+                acc[1] += q.x * q.x; acc[2] += pg.x * q.x;
+                q.y = res_project(q.y, pg.y, gi + 1, ow);
+                acc[1] += q.y * q.y; acc[2] += pg.y * q.y;
+                st16<NT>(a.d, p, q);
+            }
+        }
+        if (tail_owner) {
+            const double pgt = pgp[a.n - 1];
+            q_tail = res_project(q_tail, pgt, a.gofs + a.n - 1, ow);
+            acc[1] += q_tail * q_tail; acc[2] += pgt * q_tail;
+            a.d[a.n - 1] = q_tail;
+        }
+        double t2[2] = {acc[1], acc[2]};
+        res_exchange<2>(t2, red, tag, ptag, parity, lds, s_tot, s_bits);
+        tag = next_epoch(tag);
+        ptag = next_epoch(ptag);
+        acc[0] = pre;
+        acc[1] = t2[0];
+        acc[2] = t2[1];
+    } else {
+        ResGroups<0, NG, NT, 0>::store(b_first, b_stride, a.d);
+        for (uint32_t e = 0; e < EL; ++e) {
+            const uint32_t p = p_first + (ER + e) * p_stride;
+            if (p < n2) st16<NT>(a.d, p, q_lds[(size_t)e * BLOCK + tid]);
+        }
+        if (tail_owner) a.d[a.n - 1] = q_tail;
     }
-    if (tail_owner) a.d[a.n - 1] = q_tail;
     if (B == 0 && tid == 0) {
-        a.out_dn[0] = acc[0];
-        a.out_dn[1] = acc[1];
+        // plain: ||d||^2, g.d.   OWL-QN: ||d||^2 before the projection, (unused), ||d||^2 and pg.d after it -- the layout of
+        // the launch-per-step last step (ops.h VMODE 3)
+        const int nout = a.owl ? 4 : 2;
+        double outv[4] = {acc[0], acc[1], 0.0, 0.0};
+        if (a.owl) { outv[1] = 0.0; outv[2] = acc[1]; outv[3] = acc[2]; }
+        for (int k = 0; k < nout; ++k) a.out_dn[k] = outv[k];
         red.ctr->red_epoch = tag;  // every workgroup has left the last hand-off with `tag - 1`: nobody reads the counter again
+        if (red.p2p.world > 1) red.ctr->p2p_epoch = ptag;
         if (red.mirror.host_board) {
             const long i0 = a.out_dn - red.mirror.board;
-            if (i0 >= 0 && i0 + 1 < red.mirror.slots) {
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(red.mirror.host_board + i0),
-                                   (unsigned long long)__double_as_longlong(acc[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(red.mirror.host_board + i0 + 1),
-                                   (unsigned long long)__double_as_longlong(acc[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (i0 >= 0 && i0 + nout - 1 < red.mirror.slots) {
+                for (int k = 0; k < nout; ++k)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(red.mirror.host_board + i0 + k),
+                                       (unsigned long long)__double_as_longlong(outv[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             if (red.mirror.host_err) {
                 const unsigned int e = __hip_atomic_load(red.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

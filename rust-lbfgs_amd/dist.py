@@ -58,8 +58,10 @@ def rccl_comm(process_group=None):
     return CommSpec(_ffi.COMM_RCCL, unique_id=buf)
 
 
-def p2p_comm(device, process_group=None, timeout_s=5.0):
-    """Direct xGMI exchange: every rank exports its mailbox by IPC handle, torch.distributed gathers them."""
+def p2p_comm(device, process_group=None, timeout_s=5.0, exclusive_device=False):
+    """Direct xGMI exchange: every rank exports its mailbox by IPC handle, torch.distributed gathers them.
+    exclusive_device=True tells the library that no other rank shares this rank's GPU (lbfgs_hip_comm.exclusive_device):
+    only then does it use kernels that fill the whole chip while they wait for their peers."""
     import torch.distributed as dist
 
     L = _ffi.load()
@@ -82,6 +84,7 @@ def p2p_comm(device, process_group=None, timeout_s=5.0):
     spec.c.p2p_mailbox = mbox
     spec.c.p2p_handles = C.cast(handles, C.c_void_p)
     spec.c.p2p_timeout_s = timeout_s
+    spec.c.exclusive_device = int(bool(exclusive_device))
     return spec
 
 
@@ -103,8 +106,8 @@ def callback_comm(process_group=None):
     return CommSpec(_ffi.COMM_CALLBACK, callback=_ffi.ALLREDUCE_CB(allreduce))
 
 
-def sharded_context(n, device=0, kind="rccl", process_group=None, stream=None):
-    """Context for this rank's shard of a global n-vector (world from torch.distributed)."""
+def sharded_context(n, device=0, kind="rccl", process_group=None, stream=None, exclusive_device=False):
+    """Context for this rank's shard of a global n-vector (world from torch.distributed).  exclusive_device: see p2p_comm."""
     import torch.distributed as dist
 
     rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
@@ -119,7 +122,7 @@ def sharded_context(n, device=0, kind="rccl", process_group=None, stream=None):
     elif kind == "callback":
         comm = callback_comm(process_group)
     elif kind == "p2p":
-        comm = p2p_comm(device, process_group)
+        comm = p2p_comm(device, process_group, exclusive_device=exclusive_device)
     else:
         raise ValueError(kind)
     return Context(n, device=device, shard=shard, comm=comm, stream=stream)

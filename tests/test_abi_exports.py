@@ -159,3 +159,21 @@ def test_no_kernel_uses_scratch_memory(libs):
     assert len(names) == len(scratch) >= 100
     bad = [(n, s) for n, s in zip(names, scratch) if s != 0]
     assert not bad, bad[:5]
+
+
+def test_resident_kernels_own_their_accumulation_registers(libs):
+    """resident.h parks the running vector in a0..a239 through inline asm.  The compiler knows nothing of that: if the
+    register allocator ever places a value of its own in an AGPR inside one of those kernels (it does so silently once
+    more than 256 vector registers are live -- seen in round 2, with every element of the result wrong), the parked data
+    is overwritten.  The build scans the device assembly of every resident kernel for AGPR operands outside inline-asm
+    blocks; there must be none, and the kernels must stay well clear of the 256-VGPR line."""
+    if not os.path.exists(_build.RESOURCES) or "agpr-audit:" not in open(_build.RESOURCES).read():
+        _build.build_hip(force=True)
+    txt = open(_build.RESOURCES).read()
+    audit = re.findall(r"^agpr-audit: (\S+) (\d+)$", txt, re.M)
+    assert len(audit) == 8, audit                                   # 4 register budgets x 2 cache-hint variants
+    assert all(int(n) == 0 for _, n in audit), audit
+    for sym, _ in audit:
+        blk = txt[txt.index("Function Name: " + sym):]
+        vgprs = int(re.search(r" VGPRs: (\d+)", blk).group(1))
+        assert vgprs <= 200, (sym, vgprs)

@@ -29,7 +29,8 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 case = json.loads(os.environ["LBFGS_CASE"])
 n = case["n"]
-ctx = D.sharded_context(n, kind=os.environ.get("LBFGS_COMM_KIND", "callback"))
+ctx = D.sharded_context(n, kind=os.environ.get("LBFGS_COMM_KIND", "callback"),
+                        exclusive_device=os.environ.get("LBFGS_TEST_EXCLUSIVE_DEVICE") == "1")
 lo, hi = D.shard_range(n, rank, world)
 assert ctx.n_local == hi - lo and ctx.shard.offset == lo
 b = R.lbfgs().with_m(case["m"]).with_max_iterations(case["iters"]).with_epsilon(0.0)
@@ -71,11 +72,13 @@ try:
 except R.LbfgsError as e:
     err = e.code
     xs = x
+ctx_resident = ctx.resident_two_loops()
 nred, _ = ctx.prof_read(_ffi.K_COMM)   # the test double counts its all-reduces here
 if os.environ.get("LBFGS_WORKER_PRODUCT") == "1":
     nred = 1
 ctx.close()
-out = dict(rank=rank, lo=lo, hi=hi, rows=rows, x=xs.tolist(), allreduces=nred, err=err)
+out = dict(rank=rank, lo=lo, hi=hi, rows=rows, x=xs.tolist(), allreduces=nred, err=err,
+           resident=ctx_resident)
 json.dump(out, open(os.path.join(os.environ["LBFGS_OUT"], f"rank{rank}.json"), "w"))
 dist.barrier()
 dist.destroy_process_group()

@@ -62,6 +62,34 @@ def test_rccl_single_rank_communicator():
         x.free(); y.free()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_resident_two_loop_with_the_p2p_exchange(world, tmp_path, monkeypatch):
+    """The on-chip-resident two-loop kernel (resident.h) under the P2P communicator: workgroup 0 of every rank closes
+    each of the kernel's 2m hand-offs across the ranks through the mailboxes and broadcasts the global total to its
+    other workgroups.  That path is meant for ranks that own their GPU (`exclusive_device`); here two / three ranks
+    share ONE, so each is given a third / a fifth of the CUs (LBFGS_HIP_RESIDENT_GRID) so that all of them are resident
+    together.  Checked against the single-rank oracle, and every rank must really have run the resident kernel."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs the GPU")
+    monkeypatch.setenv("LBFGS_WORKER_PRODUCT", "1")
+    monkeypatch.setenv("LBFGS_COMM_KIND", "p2p")
+    monkeypatch.setenv("LBFGS_TEST_EXCLUSIVE_DEVICE", "1")
+    monkeypatch.setenv("LBFGS_HIP_RESIDENT_GRID", "80" if world == 2 else "48")
+    case = dict(name="quadratic_resident", n=1_300_003 if world == 2 else 1_500_001, m=6, iters=14, objective="quadratic")
+    outs = run_world(case, world, tmp_path)
+    ref_rows, ref_x = oracle_rows(case)
+    for o in outs:
+        assert o["rows"] == outs[0]["rows"]
+        assert o["resident"] >= 10, o["resident"]
+    assert len(outs[0]["rows"]) == len(ref_rows)
+    for got, ref in zip(outs[0]["rows"], ref_rows):
+        assert got[:3] == ref[:3]
+        for a, b in zip(got[3:], ref[3:]):
+            assert abs(a - b) <= 1e-9 * max(abs(b), 1e-6), (got, ref)
+    x = np.concatenate([np.array(o["x"]) for o in outs])
+    assert np.max(np.abs(x - ref_x)) <= 1e-9 * max(np.max(np.abs(ref_x)), 1e-12)
+
+
 @pytest.mark.parametrize("seed,vector_free", [(3, False), (12, True), (33, False), (41, True)])
 def test_random_configurations_two_processes_p2p(seed, vector_free, tmp_path, monkeypatch):
     """Random configurations sharded over two processes on one GPU with the in-kernel P2P exchange."""

@@ -996,7 +996,12 @@ def test_two_loop_resident_kernel_vs_launch_per_step(n, m, k, end, monkeypatch):
             ctx.set_scalars(30, [hist.s(end).vecdot(tmp)])
             ne2 = hist.two_loop_from(d, g, k, end, 30, 7, 8, 13)
             res.append((ne2, d.to_numpy(), ctx.scalars(13, 2), hist.scalars()[1]))
-            assert ctx.resident_two_loops() == (3 if mode == "1" else 0)  # the path under test really ran
+            # OWL-QN: g plays pg; the projection of d onto the orthant of -pg on a sub-range is folded into the last step
+            ne3 = hist.two_loop_owlqn(d, g, k, end, n // 5, n - n // 7, 7, 8, 40)
+            four = ctx.scalars(40, 4)
+            res.append((ne3, d.to_numpy(), np.array([four[0], four[2], four[3]]), hist.scalars()[1]))
+            assert four[2] <= four[0]                      # the projection only removes components
+            assert ctx.resident_two_loops() == (4 if mode == "1" else 0)  # the path under test really ran
             out[mode] = res
             hist.free()
             for v in (g, d, tmp):
