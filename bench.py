@@ -346,17 +346,29 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
             nu, ms_upd = ctx.prof_read(_ffi.K_UPDATE)
             nv, ms_eval = ctx.prof_read(_ffi.K_EVAL)
             nc, ms_comm = ctx.prof_read(_ffi.K_COMM)
-            if ns:
+            nr, ms_res = ctx.prof_read(_ffi.K_TWOLOOP_RESIDENT)
+            if nr and not vector_free:
+                # The shard is small enough (<= ~1.25e7 elements) for the running vector to stay in registers + LDS:
+                # the whole recursion is ONE kernel that streams g once, every s and y twice and writes d once --
+                # (4m + 1) passes of 8 bytes per element instead of the launch-per-step path's 8m - 1.
+                avg_ms = ms_res / nr
+                passes_res = 4 * a.m + 1
+                ach = 8.0 * passes_res * n_local / (avg_ms * 1e-3) / 1e9
+                roof.update(achieved=ach, frac=ach / HBM_PEAK_GBPS, kernel="two_loop_resident_kernel<ER,NT>",
+                            launches=nr, avg_ms=avg_ms, bytes_per_launch=8 * passes_res * n_local,
+                            note="algorithmic bytes of THIS kernel: (4m+1) n-vectors (q never leaves the chip)")
+            elif ns:
                 avg_ms = ms_step / ns
                 ach = 32.0 * n_local / (avg_ms * 1e-3) / 1e9  # 3 reads + 1 write of f64 per element
                 roof.update(achieved=ach, frac=ach / HBM_PEAK_GBPS, kernel="stream_kernel<OpTwoLoopStep<*,false,0>>",
                             launches=ns, avg_ms=avg_ms, bytes_per_launch=32 * n_local)
+            if roof["achieved"]:
                 # HBM bytes per launch: rocprofv3 PMC counters cannot be collected from inside this process; the
                 # figure is taken from the committed counter passes of THIS command (tools/profile_round.sh) when
-                # they were made at this shard size, and the record names them -- otherwise the field stays null
+                # they were made at this shard size and for this kernel, and the record names them -- otherwise null
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-                    if pm["n_local"] == n_local:
+                    if pm["n_local"] == n_local and pm.get("kernel", "stream_kernel").split("<")[0] == roof["kernel"].split("<")[0]:
                         roof["traffic"] = pm["traffic_bytes_per_launch"] / 1e9
                         roof["traffic_unit"] = "GB per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)"
                         roof["traffic_source"] = pm.get("_source")
@@ -369,9 +381,13 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
                 # is charged 8*b - 2 passes (it actually moves 8*b - 1: the last step re-reads g for the next g.d)
                 passes = (4 * a.m + 3) if vector_free else (8 * a.m - 2)
                 gbps = 8.0 * passes * n_local / (t_tl * 1e-3) / 1e9
+                note = "per GPU: this rank's shard, incl. the all-reduces inside the recursion"
+                if nr and not vector_free:
+                    note += ("; priced at the launch-per-step minimum of 8m-2 passes for comparison across shard sizes --"
+                             " the resident kernel moves only 4m+1, so this figure may exceed what HBM delivers")
                 roof.update(two_loop={"ms": t_tl, "algorithmic_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS,
                                       "bytes": 8 * passes * n_local, "passes": passes, "calls": nt,
-                                      "note": "per GPU: this rank's shard, incl. the all-reduces inside the recursion"})
+                                      "resident_kernel": bool(nr) and not vector_free, "note": note})
             sampled = max(nt, 1)  # steps whose kernels were timed (every --prof-every-th step of the timed regions)
             roof["per_iteration_ms"] = {
                 "two_loop": ms_all / sampled, "history_update": ms_upd / sampled, "line_eval": ms_eval / sampled,

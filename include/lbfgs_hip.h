@@ -332,7 +332,8 @@ enum {
     LBFGS_HIP_K_BLAS1 = 6,
     LBFGS_HIP_K_COMM = 7,
     LBFGS_HIP_K_TWOLOOP_ALL = 8,  /* one event pair around a whole lbfgs_hip_two_loop call */
-    LBFGS_HIP_K_CLASSES = 9
+    LBFGS_HIP_K_TWOLOOP_RESIDENT = 9, /* the whole recursion as ONE kernel, q kept on chip (shards <= ~1.25e7 elements) */
+    LBFGS_HIP_K_CLASSES = 10
 };
 int lbfgs_hip_prof_enable(lbfgs_hip_ctx* ctx, int on);
 int lbfgs_hip_prof_reset(lbfgs_hip_ctx* ctx);

@@ -24,7 +24,8 @@ LS_MORETHUENTE, LS_BT_ARMIJO, LS_BT_STRONGWOLFE, LS_BT_WOLFE = 0, 1, 2, 3
 EVAL_HOST, EVAL_DEVICE, EVAL_BUILTIN = 0, 1, 2
 COMM_NONE, COMM_RCCL, COMM_CALLBACK, COMM_P2P = 0, 1, 2, 3
 OBJ_QUADRATIC, OBJ_LOGISTIC, OBJ_ROSENBROCK, OBJ_LJ_ALLPAIRS, OBJ_LJ_NEIGHBORS, OBJ_LJ_CELLS = 1, 2, 3, 4, 5, 6
-(K_TWOLOOP_STEP, K_TWOLOOP_EDGE, K_UPDATE, K_LINE, K_EVAL, K_OWLQN, K_BLAS1, K_COMM, K_TWOLOOP_ALL) = range(9)
+(K_TWOLOOP_STEP, K_TWOLOOP_EDGE, K_UPDATE, K_LINE, K_EVAL, K_OWLQN, K_BLAS1, K_COMM, K_TWOLOOP_ALL,
+ K_TWOLOOP_RESIDENT) = range(10)
 VEC_X, VEC_GX, VEC_XP, VEC_GP, VEC_PG, VEC_WP, VEC_D = range(7)
 VEC_S0, VEC_Y0 = 100, 200
 

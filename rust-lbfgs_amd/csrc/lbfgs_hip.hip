@@ -1649,7 +1649,7 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     const size_t lds_bytes = (size_t)el * BLOCK * sizeof(d2);
     int rc;
     {
-        ProfScope ps(ctx, LBFGS_HIP_K_TWOLOOP_STEP);
+        ProfScope ps(ctx, LBFGS_HIP_K_TWOLOOP_RESIDENT);
         switch (er) {
             case 8: rc = resident_launch<8>(ctx, ra, red, grid, lds_bytes, nt); break;
             case 24: rc = resident_launch<24>(ctx, ra, red, grid, lds_bytes, nt); break;

@@ -272,12 +272,15 @@ struct ResGroups {
             else vv[u] = uu[u];
         }
     }
+    // (`after`: called where the LAST group would fetch its successor -- the caller issues the first LDS round's loads there)
+    template <class After>
     static __device__ __forceinline__ void step_with(d2 (&uu)[RES_UNROLL], d2 (&vv)[RES_UNROLL], const uint32_t p_first,
                                                      const uint32_t p_stride, const double* up, const double* vp, const double c,
-                                                     const double gamma, double* acc) {
+                                                     const double gamma, double* acc, After&& after) {
         if constexpr (G < NG) {
             d2 nu[RES_UNROLL], nv[RES_UNROLL];
             if constexpr (G + 1 < NG) ResGroups<G + 1, NG, NT, MODE>::fetch(p_first, p_stride, up, vp, nu, nv);
+            else after();
             // a compiler barrier: without it every group's loads are hoisted to the top of the step and the kernel spills
             asm volatile("" ::: "memory");
             d2 q0 = acc_get<G * RES_UNROLL + 0>(), q1 = acc_get<G * RES_UNROLL + 1>(), q2 = acc_get<G * RES_UNROLL + 2>(),
@@ -291,14 +294,8 @@ struct ResGroups {
             acc_put<G * RES_UNROLL + 2>(q2);
             acc_put<G * RES_UNROLL + 3>(q3);
             res_pin_sums<(MODE == 2 ? 2 : 1)>(acc);
-            if constexpr (G + 1 < NG) ResGroups<G + 1, NG, NT, MODE>::step_with(nu, nv, p_first, p_stride, up, vp, c, gamma, acc);
+            if constexpr (G + 1 < NG) ResGroups<G + 1, NG, NT, MODE>::step_with(nu, nv, p_first, p_stride, up, vp, c, gamma, acc, after);
         }
-    }
-    static __device__ __forceinline__ void step(const uint32_t p_first, const uint32_t p_stride, const double* up, const double* vp,
-                                                const double c, const double gamma, double* acc) {
-        d2 uu[RES_UNROLL], vv[RES_UNROLL];
-        fetch(p_first, p_stride, up, vp, uu, vv);
-        step_with(uu, vv, p_first, p_stride, up, vp, c, gamma, acc);
     }
     // q = -g ; acc0 += s * (-g) when the first numerator is summed here
     template <bool NEED_FIRST>
@@ -368,31 +365,52 @@ struct ResGroups {
     }
 };
 
-// the LDS-resident rounds of one step (the ragged last round is among them: bounds-checked)
+// the LDS-resident rounds of one step (the ragged last round is among them: bounds-checked), software-pipelined like the
+// register rounds: the loads of round group e0+4 are in flight while group e0 is worked on
 template <int ER, bool NT, int MODE>
-__device__ __forceinline__ void res_step_lds(d2* q_lds, const uint32_t EL, const uint32_t p_first, const uint32_t p_stride,
-                                             const uint32_t n2, const double* up, const double* vp, const double c,
+__device__ __forceinline__ void res_lds_fetch(const uint32_t e0, const uint32_t p_first, const uint32_t p_stride, const uint32_t n2,
+                                              const double* up, const double* vp, d2 (&uu)[RES_UNROLL], d2 (&vv)[RES_UNROLL]) {
+#pragma unroll
+    for (int u = 0; u < RES_UNROLL; ++u) {
+        const uint32_t p = p_first + (ER + e0 + u) * p_stride;
+        const uint32_t pc = p < n2 ? p : 0u;  // (a valid address; the value is masked out in res_lds_work)
+        uu[u] = ld16<NT>(up, pc);
+        if constexpr (MODE != 1) vv[u] = ld16<NT>(vp, pc);
+        else vv[u] = uu[u];
+    }
+}
+template <int ER, int MODE>
+__device__ __forceinline__ void res_lds_work(d2* q_lds, const uint32_t e0, const uint32_t p_first, const uint32_t p_stride,
+                                             const uint32_t n2, d2 (&uu)[RES_UNROLL], d2 (&vv)[RES_UNROLL], const double c,
                                              const double gamma, double* acc) {
     const uint32_t tid = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < RES_UNROLL; ++u) {
+        const uint32_t p = p_first + (ER + e0 + u) * p_stride;
+        if (!(p < n2)) { uu[u] = d2{0.0, 0.0}; vv[u] = d2{0.0, 0.0}; }  // padding pairs stay 0 and add 0
+        d2 q = q_lds[(size_t)(e0 + u) * BLOCK + tid];
+        res_one<MODE>(q, uu[u], vv[u], c, gamma, acc);
+        q_lds[(size_t)(e0 + u) * BLOCK + tid] = q;
+    }
+}
+// one whole step: register rounds (first group's operands already loaded: pu, pv), then the LDS rounds
+template <int ER, bool NT, int MODE>
+__device__ __forceinline__ void res_step(d2 (&pu)[RES_UNROLL], d2 (&pv)[RES_UNROLL], d2* q_lds, const uint32_t EL,
+                                         const uint32_t p_first, const uint32_t p_stride, const uint32_t n2, const double* up,
+                                         const double* vp, const double c, const double gamma, double* acc) {
+    constexpr int NG = ER / RES_UNROLL;
+    d2 lu[RES_UNROLL], lv[RES_UNROLL];
+    ResGroups<0, NG, NT, MODE>::step_with(pu, pv, p_first * 16u, p_stride * 16u, up, vp, c, gamma, acc, [&]() {
+        if (EL > 0) res_lds_fetch<ER, NT, MODE>(0, p_first, p_stride, n2, up, vp, lu, lv);
+    });
     for (uint32_t e0 = 0; e0 < EL; e0 += RES_UNROLL) {
-        d2 uu[RES_UNROLL], vv[RES_UNROLL];
-        bool in[RES_UNROLL];
+        d2 nu[RES_UNROLL], nv[RES_UNROLL];
+        if (e0 + RES_UNROLL < EL) res_lds_fetch<ER, NT, MODE>(e0 + RES_UNROLL, p_first, p_stride, n2, up, vp, nu, nv);
+        asm volatile("" ::: "memory");
+        res_lds_work<ER, MODE>(q_lds, e0, p_first, p_stride, n2, lu, lv, c, gamma, acc);
+        res_pin_sums<(MODE == 2 ? 2 : 1)>(acc);
 #pragma unroll
-        for (int u = 0; u < RES_UNROLL; ++u) {
-            const uint32_t p = p_first + (ER + e0 + u) * p_stride;
-            in[u] = p < n2;
-            const uint32_t pc = in[u] ? p : 0u;  // (a valid address; the value is masked out below)
-            uu[u] = ld16<NT>(up, pc);
-            if constexpr (MODE != 1) vv[u] = ld16<NT>(vp, pc);
-            else vv[u] = uu[u];
-        }
-#pragma unroll
-        for (int u = 0; u < RES_UNROLL; ++u) {
-            if (!in[u]) { uu[u] = d2{0.0, 0.0}; vv[u] = d2{0.0, 0.0}; }  // padding pairs stay 0 and add 0
-            d2 q = q_lds[(size_t)(e0 + u) * BLOCK + tid];
-            res_one<MODE>(q, uu[u], vv[u], c, gamma, acc);
-            q_lds[(size_t)(e0 + u) * BLOCK + tid] = q;
-        }
+        for (int u = 0; u < RES_UNROLL; ++u) { lu[u] = nu[u]; lv[u] = nv[u]; }
     }
 }
 
@@ -448,6 +466,15 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
     unsigned int tag = c0.red_epoch, ptag = c0.p2p_epoch;
     int parity = 0;
     double dot;
+    // The operands of a step are known before its coefficient is: the first group's loads of the NEXT step are issued
+    // before the hand-off that yields the coefficient, so they travel while the partial sums are exchanged.
+    d2 pu[RES_UNROLL], pv[RES_UNROLL];
+    auto prefetch = [&](const int si) {
+        const double* up = a.step[si].u;
+        const double* vp = a.step[si].v ? a.step[si].v : up;  // (the gamma transition has no v: its loads are unused)
+        ResGroups<0, NG, NT, 0>::fetch(b_first, b_stride, up, vp, pu, pv);
+    };
+    prefetch(0);
     if (need_first) {
         double t1[1] = {acc[0]};
         res_exchange<1>(t1, red, tag, ptag, parity, lds, s_tot, s_bits);
@@ -476,16 +503,10 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         acc[1] = 0.0;
         acc[2] = 0.0;
         const int mode = st.last ? 2 : (st.v == nullptr ? 1 : 0);
-        if (mode == 0) {
-            ResGroups<0, NG, NT, 0>::step(b_first, b_stride, st.u, st.v, c, gamma, acc);
-            res_step_lds<ER, NT, 0>(q_lds, EL, p_first, p_stride, n2, st.u, st.v, c, gamma, acc);
-        } else if (mode == 1) {
-            ResGroups<0, NG, NT, 1>::step(b_first, b_stride, st.u, st.u, c, gamma, acc);
-            res_step_lds<ER, NT, 1>(q_lds, EL, p_first, p_stride, n2, st.u, st.u, c, gamma, acc);
-        } else {
-            ResGroups<0, NG, NT, 2>::step(b_first, b_stride, st.u, st.v, c, gamma, acc);
-            res_step_lds<ER, NT, 2>(q_lds, EL, p_first, p_stride, n2, st.u, st.v, c, gamma, acc);
-        }
+        if (mode == 0) res_step<ER, NT, 0>(pu, pv, q_lds, EL, p_first, p_stride, n2, st.u, st.v, c, gamma, acc);
+        else if (mode == 1) res_step<ER, NT, 1>(pu, pv, q_lds, EL, p_first, p_stride, n2, st.u, st.u, c, gamma, acc);
+        else res_step<ER, NT, 2>(pu, pv, q_lds, EL, p_first, p_stride, n2, st.u, st.v, c, gamma, acc);
+        if (si + 1 < a.nsteps) prefetch(si + 1);
         if (tail_owner) {
             const double ut = st.u[a.n - 1], vt = (mode == 1) ? ut : st.v[a.n - 1];
             q_tail = q_tail + c * ut;
