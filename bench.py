@@ -366,14 +366,18 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
                 # HBM bytes per launch: rocprofv3 PMC counters cannot be collected from inside this process; the
                 # figure is taken from the committed counter passes of THIS command (tools/profile_round.sh) when
                 # they were made at this shard size and for this kernel, and the record names them -- otherwise null
-                try:
-                    pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-                    if pm["n_local"] == n_local and pm.get("kernel", "stream_kernel").split("<")[0] == roof["kernel"].split("<")[0]:
-                        roof["traffic"] = pm["traffic_bytes_per_launch"] / 1e9
-                        roof["traffic_unit"] = "GB per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)"
-                        roof["traffic_source"] = pm.get("_source")
-                except Exception:  # noqa: BLE001
-                    pass
+                import glob
+
+                for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_traffic*.json"))):
+                    try:
+                        pm = json.load(open(path))
+                        if (pm["n_local"] == n_local and pm.get("m", 10) == a.m
+                                and pm.get("kernel", "stream_kernel").split("<")[0] == roof["kernel"].split("<")[0]):
+                            roof["traffic"] = pm["traffic_bytes_per_launch"] / 1e9
+                            roof["traffic_unit"] = "GB per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)"
+                            roof["traffic_source"] = pm.get("_source")
+                    except Exception:  # noqa: BLE001
+                        pass
             if nt:
                 t_tl = ms_all / nt
                 # 8*b passes of 8 bytes is the fused minimum that respects the dot->axpy dependency;

@@ -1574,20 +1574,21 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     if (!ctx->resident_on || !comm_ok || ctx->handoff_ticket || bound < 1 || ctx->capturing || ctx->grid_override > 0 ||
         2 * bound > RES_MAX_STEPS)
         return 0;
-    // one workgroup per CU: all of them resident at once (fewer only on request: tests run two ranks on one GPU)
-    const int grid = ctx->resident_grid > 0 ? std::min(ctx->resident_grid, ctx->cu_count) : ctx->cu_count;
-    if (grid < 1 || grid > BLOCK || grid > MAX_GRID) return 0;  // (every thread polls one workgroup's granules)
+    // one workgroup per CU: all of them resident at once (fewer on request -- tests run two ranks on one GPU -- and for
+    // vectors of a few MB, where a hand-off among fewer workgroups is worth more than the idle CUs' bandwidth: >= 8 pairs per
+    // thread, at least 64 workgroups; measured at n = 1e5 / 3e5 / 1e6, profiles/r02_resident_small_n.log)
     const uint64_t n = ctx->shard.n_local;
+    const int grid_auto = (int)std::min<uint64_t>((uint64_t)ctx->cu_count, std::max<uint64_t>(64, ((n >> 1) + BLOCK * 8 - 1) / (BLOCK * 8)));
+    const int grid = ctx->resident_grid > 0 ? std::min(ctx->resident_grid, ctx->cu_count) : grid_auto;
+    if (grid < 1 || grid > BLOCK || grid > MAX_GRID) return 0;  // (every thread polls one workgroup's granules)
     const uint64_t per_round = (uint64_t)grid * BLOCK;
     const uint64_t E = ((n >> 1) + per_round - 1) / per_round;  // 16-byte pairs per thread
     constexpr int ER_MAX = 60;
     if (E == 0 || E > ER_MAX + RES_LDS_PAIRS_MAX || (n >> 1) + per_round * 4 >= (1ull << 28)) return 0;
     if (ctx->red_count % 0xFFFFFFFFull + 2ull * (uint64_t)bound + 4ull >= 0xFFFFFFFFull) return 0;  // tag wrap: eager path
     // Rounds 0 .. E-2 are full for every thread, round E-1 is the ragged one.  The register rounds carry no bounds checks,
-    // so ER <= E-1; the rest (the ragged round included) lives in LDS.
-    if (E < 2) return 0;
+    // so ER <= E-1; the rest (the ragged round included) lives in LDS -- everything, for the smallest vectors (ER = 0).
     const int er = E - 1 >= ER_MAX ? ER_MAX : E - 1 >= 40 ? 40 : E - 1 >= 24 ? 24 : E - 1 >= 8 ? 8 : 0;
-    if (er == 0) return 0;  // (vectors of < 1.2 MB: the launch-per-step path)
     const uint32_t el = (uint32_t)((E - er + RES_UNROLL - 1) / RES_UNROLL * RES_UNROLL);
     if (el > (uint32_t)RES_LDS_PAIRS_MAX) return 0;
     if (ctx->resident_ok < 0) {  // once: can this device hold one such workgroup per CU?
@@ -1651,6 +1652,7 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     {
         ProfScope ps(ctx, LBFGS_HIP_K_TWOLOOP_RESIDENT);
         switch (er) {
+            case 0: rc = resident_launch<0>(ctx, ra, red, grid, lds_bytes, nt); break;
             case 8: rc = resident_launch<8>(ctx, ra, red, grid, lds_bytes, nt); break;
             case 24: rc = resident_launch<24>(ctx, ra, red, grid, lds_bytes, nt); break;
             case 40: rc = resident_launch<40>(ctx, ra, red, grid, lds_bytes, nt); break;

@@ -34,7 +34,12 @@ namespace lh {
 constexpr int RES_MAX_STEPS = 2 * 24;  // 2 * bound for bound <= 24 (the step table travels as a kernel argument: < 4 KiB)
 constexpr int RES_LDS_PAIRS_MAX = 36;  // 160 KiB / (256 threads x 16 B) = 40, less the kernel's static arrays (4.3 KiB),
                                        // rounded down to a multiple of RES_UNROLL
-constexpr int RES_UNROLL = 4;          // pairs whose loads are issued together
+constexpr int RES_UNROLL = 4;          // pairs whose loads are issued together (one group)
+#ifndef LH_RES_AHEAD
+#define LH_RES_AHEAD 1
+#endif
+constexpr int RES_AHEAD = LH_RES_AHEAD;  // groups whose loads are in flight ahead of the group being worked on (2 was measured:
+                                         // no faster at 1.25e7 elements, 4 % slower at 3e6 -- the hand-off is latency, not bandwidth)
 
 struct ResStep {
     const double* u;     // the vector added to q:   q += c * u
@@ -260,43 +265,6 @@ __device__ __forceinline__ void res_pin_sums(double* acc) {
 // groups of RES_UNROLL pairs, unrolled by template recursion (the AGPR numbers must be compile-time constants)
 template <int G, int NG, bool NT, int MODE>
 struct ResGroups {
-    // loads of group G (issued one group AHEAD of their use: two groups = 16 loads of 16 bytes in flight per thread)
-    static __device__ __forceinline__ void fetch(const uint32_t p_first, const uint32_t p_stride, const double* up, const double* vp,
-                                                 d2 (&uu)[RES_UNROLL], d2 (&vv)[RES_UNROLL]) {
-        const uint32_t o0 = res_opaque(p_first);  // (p_first / p_stride are BYTE offsets here)
-#pragma unroll
-        for (int u = 0; u < RES_UNROLL; ++u) {
-            const uint32_t o = o0 + (uint32_t)(G * RES_UNROLL + u) * p_stride;
-            uu[u] = ld16_at<NT>(up, o);
-            if constexpr (MODE != 1) vv[u] = ld16_at<NT>(vp, o);
-            else vv[u] = uu[u];
-        }
-    }
-    // (`after`: called where the LAST group would fetch its successor -- the caller issues the first LDS round's loads there)
-    template <class After>
-    static __device__ __forceinline__ void step_with(d2 (&uu)[RES_UNROLL], d2 (&vv)[RES_UNROLL], const uint32_t p_first,
-                                                     const uint32_t p_stride, const double* up, const double* vp, const double c,
-                                                     const double gamma, double* acc, After&& after) {
-        if constexpr (G < NG) {
-            d2 nu[RES_UNROLL], nv[RES_UNROLL];
-            if constexpr (G + 1 < NG) ResGroups<G + 1, NG, NT, MODE>::fetch(p_first, p_stride, up, vp, nu, nv);
-            else after();
-            // a compiler barrier: without it every group's loads are hoisted to the top of the step and the kernel spills
-            asm volatile("" ::: "memory");
-            d2 q0 = acc_get<G * RES_UNROLL + 0>(), q1 = acc_get<G * RES_UNROLL + 1>(), q2 = acc_get<G * RES_UNROLL + 2>(),
-               q3 = acc_get<G * RES_UNROLL + 3>();
-            res_one<MODE>(q0, uu[0], vv[0], c, gamma, acc);
-            res_one<MODE>(q1, uu[1], vv[1], c, gamma, acc);
-            res_one<MODE>(q2, uu[2], vv[2], c, gamma, acc);
-            res_one<MODE>(q3, uu[3], vv[3], c, gamma, acc);
-            acc_put<G * RES_UNROLL + 0>(q0);
-            acc_put<G * RES_UNROLL + 1>(q1);
-            acc_put<G * RES_UNROLL + 2>(q2);
-            acc_put<G * RES_UNROLL + 3>(q3);
-            res_pin_sums<(MODE == 2 ? 2 : 1)>(acc);
-            if constexpr (G + 1 < NG) ResGroups<G + 1, NG, NT, MODE>::step_with(nu, nv, p_first, p_stride, up, vp, c, gamma, acc, after);
-        }
-    }
     // q = -g ; acc0 += s * (-g) when the first numerator is summed here
     template <bool NEED_FIRST>
     static __device__ __forceinline__ void init(const uint32_t p_first, const uint32_t p_stride, const double* gp, const double* sp,
@@ -365,52 +333,115 @@ struct ResGroups {
     }
 };
 
-// the LDS-resident rounds of one step (the ragged last round is among them: bounds-checked), software-pipelined like the
-// register rounds: the loads of round group e0+4 are in flight while group e0 is worked on
-template <int ER, bool NT, int MODE>
-__device__ __forceinline__ void res_lds_fetch(const uint32_t e0, const uint32_t p_first, const uint32_t p_stride, const uint32_t n2,
-                                              const double* up, const double* vp, d2 (&uu)[RES_UNROLL], d2 (&vv)[RES_UNROLL]) {
+// ---- one step = a sequence of GROUPS of RES_UNROLL pairs: NG = ER/RES_UNROLL register groups (compile-time: the AGPR
+// numbers are constants), then EL/RES_UNROLL LDS groups (run-time count; the ragged last round is among them:
+// bounds-checked).  The operands (u, v) of the next RES_AHEAD groups are always in flight while a group is worked on:
+// a window of RES_AHEAD loaded groups travels through the step -- and ACROSS the hand-off: a step's operands are known
+// before its coefficient is, so the window of the next step is filled before the partial sums are exchanged and HBM
+// keeps streaming while the workgroups wait for each other.
+struct ResWin {
+    d2 u[RES_AHEAD][RES_UNROLL], v[RES_AHEAD][RES_UNROLL];
+};
+struct ResPos {
+    uint32_t p_first, p_stride, n2, EL;  // first pair / pair stride of this thread, pairs in the shard, pairs in LDS
+};
+template <int ER, bool NT, bool NEEDV>
+struct ResFetch {
+    static constexpr int NG = ER / RES_UNROLL;
+    template <int GI>
+    static __device__ __forceinline__ void reg(const ResPos& ps, const double* up, const double* vp, d2 (&uu)[RES_UNROLL],
+                                               d2 (&vv)[RES_UNROLL]) {
+        const uint32_t o0 = res_opaque(ps.p_first * 16u);  // byte offsets (shards of < 2^28 pairs: < 2^32 bytes)
 #pragma unroll
-    for (int u = 0; u < RES_UNROLL; ++u) {
-        const uint32_t p = p_first + (ER + e0 + u) * p_stride;
-        const uint32_t pc = p < n2 ? p : 0u;  // (a valid address; the value is masked out in res_lds_work)
-        uu[u] = ld16<NT>(up, pc);
-        if constexpr (MODE != 1) vv[u] = ld16<NT>(vp, pc);
-        else vv[u] = uu[u];
+        for (int u = 0; u < RES_UNROLL; ++u) {
+            const uint32_t o = o0 + (uint32_t)(GI * RES_UNROLL + u) * (ps.p_stride * 16u);
+            uu[u] = ld16_at<NT>(up, o);
+            if constexpr (NEEDV) vv[u] = ld16_at<NT>(vp, o);
+            else vv[u] = uu[u];
+        }
     }
-}
-template <int ER, int MODE>
-__device__ __forceinline__ void res_lds_work(d2* q_lds, const uint32_t e0, const uint32_t p_first, const uint32_t p_stride,
-                                             const uint32_t n2, d2 (&uu)[RES_UNROLL], d2 (&vv)[RES_UNROLL], const double c,
-                                             const double gamma, double* acc) {
-    const uint32_t tid = threadIdx.x;
+    static __device__ __forceinline__ void lds(const uint32_t j, const ResPos& ps, const double* up, const double* vp,
+                                               d2 (&uu)[RES_UNROLL], d2 (&vv)[RES_UNROLL]) {
 #pragma unroll
-    for (int u = 0; u < RES_UNROLL; ++u) {
-        const uint32_t p = p_first + (ER + e0 + u) * p_stride;
-        if (!(p < n2)) { uu[u] = d2{0.0, 0.0}; vv[u] = d2{0.0, 0.0}; }  // padding pairs stay 0 and add 0
-        d2 q = q_lds[(size_t)(e0 + u) * BLOCK + tid];
-        res_one<MODE>(q, uu[u], vv[u], c, gamma, acc);
-        q_lds[(size_t)(e0 + u) * BLOCK + tid] = q;
+        for (int u = 0; u < RES_UNROLL; ++u) {
+            const uint32_t p = ps.p_first + (ER + j * RES_UNROLL + u) * ps.p_stride;
+            const uint32_t pc = p < ps.n2 ? p : 0u;  // (a valid address; the value is masked out where it is used)
+            uu[u] = ld16<NT>(up, pc);
+            if constexpr (NEEDV) vv[u] = ld16<NT>(vp, pc);
+            else vv[u] = uu[u];
+        }
     }
+    // group GI of the step, whichever kind it is.  (Past the step's last group the LDS form loads pair 0 -- in cache,
+    // unused -- rather than nothing: an unconditional fetch keeps the window free of merges of loaded and unloaded values.)
+    template <int GI>
+    static __device__ __forceinline__ void any(const ResPos& ps, const double* up, const double* vp, d2 (&uu)[RES_UNROLL],
+                                               d2 (&vv)[RES_UNROLL]) {
+        if constexpr (GI < NG) reg<GI>(ps, up, vp, uu, vv);
+        else lds((uint32_t)(GI - NG), ps, up, vp, uu, vv);
+    }
+    template <int K = 0>
+    static __device__ __forceinline__ void window(ResWin& w, const ResPos& ps, const double* up, const double* vp) {
+        if constexpr (K < RES_AHEAD) {
+            any<K>(ps, up, vp, w.u[K], w.v[K]);
+            window<K + 1>(w, ps, up, vp);
+        }
+    }
+};
+__device__ __forceinline__ void res_shift(ResWin& w, const d2 (&fu)[RES_UNROLL], const d2 (&fv)[RES_UNROLL]) {
+#pragma unroll
+    for (int k = 0; k + 1 < RES_AHEAD; ++k)
+#pragma unroll
+        for (int u = 0; u < RES_UNROLL; ++u) { w.u[k][u] = w.u[k + 1][u]; w.v[k][u] = w.v[k + 1][u]; }
+#pragma unroll
+    for (int u = 0; u < RES_UNROLL; ++u) { w.u[RES_AHEAD - 1][u] = fu[u]; w.v[RES_AHEAD - 1][u] = fv[u]; }
 }
-// one whole step: register rounds (first group's operands already loaded: pu, pv), then the LDS rounds
+template <int G, int ER, bool NT, int MODE>
+struct ResRegStep {
+    static constexpr int NG = ER / RES_UNROLL;
+    static __device__ __forceinline__ void run(ResWin& w, const ResPos& ps, const double* up, const double* vp, const double c,
+                                               const double gamma, double* acc) {
+        if constexpr (G < NG) {
+            d2 fu[RES_UNROLL], fv[RES_UNROLL];
+            ResFetch<ER, NT, MODE != 1>::template any<G + RES_AHEAD>(ps, up, vp, fu, fv);
+            // a compiler barrier: without it every group's loads are hoisted to the top of the step and the kernel spills
+            asm volatile("" ::: "memory");
+            d2 q0 = acc_get<G * RES_UNROLL + 0>(), q1 = acc_get<G * RES_UNROLL + 1>(), q2 = acc_get<G * RES_UNROLL + 2>(),
+               q3 = acc_get<G * RES_UNROLL + 3>();
+            res_one<MODE>(q0, w.u[0][0], w.v[0][0], c, gamma, acc);
+            res_one<MODE>(q1, w.u[0][1], w.v[0][1], c, gamma, acc);
+            res_one<MODE>(q2, w.u[0][2], w.v[0][2], c, gamma, acc);
+            res_one<MODE>(q3, w.u[0][3], w.v[0][3], c, gamma, acc);
+            acc_put<G * RES_UNROLL + 0>(q0);
+            acc_put<G * RES_UNROLL + 1>(q1);
+            acc_put<G * RES_UNROLL + 2>(q2);
+            acc_put<G * RES_UNROLL + 3>(q3);
+            res_pin_sums<(MODE == 2 ? 2 : 1)>(acc);
+            res_shift(w, fu, fv);
+            ResRegStep<G + 1, ER, NT, MODE>::run(w, ps, up, vp, c, gamma, acc);
+        }
+    }
+};
+// one whole step; on entry the window holds the operands of groups 0 .. RES_AHEAD-1, on exit nothing
 template <int ER, bool NT, int MODE>
-__device__ __forceinline__ void res_step(d2 (&pu)[RES_UNROLL], d2 (&pv)[RES_UNROLL], d2* q_lds, const uint32_t EL,
-                                         const uint32_t p_first, const uint32_t p_stride, const uint32_t n2, const double* up,
-                                         const double* vp, const double c, const double gamma, double* acc) {
-    constexpr int NG = ER / RES_UNROLL;
-    d2 lu[RES_UNROLL], lv[RES_UNROLL];
-    ResGroups<0, NG, NT, MODE>::step_with(pu, pv, p_first * 16u, p_stride * 16u, up, vp, c, gamma, acc, [&]() {
-        if (EL > 0) res_lds_fetch<ER, NT, MODE>(0, p_first, p_stride, n2, up, vp, lu, lv);
-    });
-    for (uint32_t e0 = 0; e0 < EL; e0 += RES_UNROLL) {
-        d2 nu[RES_UNROLL], nv[RES_UNROLL];
-        if (e0 + RES_UNROLL < EL) res_lds_fetch<ER, NT, MODE>(e0 + RES_UNROLL, p_first, p_stride, n2, up, vp, nu, nv);
+__device__ __forceinline__ void res_step(ResWin& w, d2* q_lds, const ResPos& ps, const double* up, const double* vp, const double c,
+                                         const double gamma, double* acc) {
+    ResRegStep<0, ER, NT, MODE>::run(w, ps, up, vp, c, gamma, acc);
+    const uint32_t tid = threadIdx.x, NL = ps.EL / RES_UNROLL;
+    for (uint32_t j = 0; j < NL; ++j) {
+        d2 fu[RES_UNROLL], fv[RES_UNROLL];
+        ResFetch<ER, NT, MODE != 1>::lds(j + RES_AHEAD, ps, up, vp, fu, fv);
         asm volatile("" ::: "memory");
-        res_lds_work<ER, MODE>(q_lds, e0, p_first, p_stride, n2, lu, lv, c, gamma, acc);
-        res_pin_sums<(MODE == 2 ? 2 : 1)>(acc);
 #pragma unroll
-        for (int u = 0; u < RES_UNROLL; ++u) { lu[u] = nu[u]; lv[u] = nv[u]; }
+        for (int u = 0; u < RES_UNROLL; ++u) {
+            const uint32_t p = ps.p_first + (ER + j * RES_UNROLL + u) * ps.p_stride;
+            d2 uu = w.u[0][u], vv = w.v[0][u];
+            if (!(p < ps.n2)) { uu = d2{0.0, 0.0}; vv = d2{0.0, 0.0}; }  // padding pairs stay 0 and add 0
+            d2 q = q_lds[(size_t)(j * RES_UNROLL + u) * BLOCK + tid];
+            res_one<MODE>(q, uu, vv, c, gamma, acc);
+            q_lds[(size_t)(j * RES_UNROLL + u) * BLOCK + tid] = q;
+        }
+        res_pin_sums<(MODE == 2 ? 2 : 1)>(acc);
+        res_shift(w, fu, fv);
     }
 }
 
@@ -418,7 +449,7 @@ __device__ __forceinline__ void res_step(d2 (&pu)[RES_UNROLL], d2 (&pv)[RES_UNRO
 template <int ER, bool NT>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
-    static_assert(ER % RES_UNROLL == 0 && ER >= RES_UNROLL && 4 * ER <= 256, "pairs in AGPRs");
+    static_assert(ER % RES_UNROLL == 0 && ER >= 0 && 4 * ER <= 256, "pairs in AGPRs (ER = 0: everything in LDS)");
     asm volatile("" ::: "a255");  // this kernel owns the whole accumulation register file (the wave gets 512 registers)
     extern __shared__ d2 q_lds[];  // [lds_pairs][BLOCK]
     __shared__ double lds[3][WAVES];
@@ -466,13 +497,13 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
     unsigned int tag = c0.red_epoch, ptag = c0.p2p_epoch;
     int parity = 0;
     double dot;
-    // The operands of a step are known before its coefficient is: the first group's loads of the NEXT step are issued
-    // before the hand-off that yields the coefficient, so they travel while the partial sums are exchanged.
-    d2 pu[RES_UNROLL], pv[RES_UNROLL];
+    // (see ResWin: the next step's first groups are loaded BEFORE the hand-off that yields its coefficient)
+    ResWin win;
+    const ResPos ps{p_first, p_stride, n2, EL};
     auto prefetch = [&](const int si) {
         const double* up = a.step[si].u;
-        const double* vp = a.step[si].v ? a.step[si].v : up;  // (the gamma transition has no v: its loads are unused)
-        ResGroups<0, NG, NT, 0>::fetch(b_first, b_stride, up, vp, pu, pv);
+        const double* vp = a.step[si].v ? a.step[si].v : up;  // (the gamma transition has no v: those loads go unused)
+        ResFetch<ER, NT, true>::window(win, ps, up, vp);
     };
     prefetch(0);
     if (need_first) {
@@ -503,9 +534,9 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         acc[1] = 0.0;
         acc[2] = 0.0;
         const int mode = st.last ? 2 : (st.v == nullptr ? 1 : 0);
-        if (mode == 0) res_step<ER, NT, 0>(pu, pv, q_lds, EL, p_first, p_stride, n2, st.u, st.v, c, gamma, acc);
-        else if (mode == 1) res_step<ER, NT, 1>(pu, pv, q_lds, EL, p_first, p_stride, n2, st.u, st.u, c, gamma, acc);
-        else res_step<ER, NT, 2>(pu, pv, q_lds, EL, p_first, p_stride, n2, st.u, st.v, c, gamma, acc);
+        if (mode == 0) res_step<ER, NT, 0>(win, q_lds, ps, st.u, st.v, c, gamma, acc);
+        else if (mode == 1) res_step<ER, NT, 1>(win, q_lds, ps, st.u, st.u, c, gamma, acc);
+        else res_step<ER, NT, 2>(win, q_lds, ps, st.u, st.v, c, gamma, acc);
         if (si + 1 < a.nsteps) prefetch(si + 1);
         if (tail_owner) {
             const double ut = st.u[a.n - 1], vt = (mode == 1) ? ut : st.v[a.n - 1];

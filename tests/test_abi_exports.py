@@ -171,7 +171,7 @@ def test_resident_kernels_own_their_accumulation_registers(libs):
         _build.build_hip(force=True)
     txt = open(_build.RESOURCES).read()
     audit = re.findall(r"^agpr-audit: (\S+) (\d+)$", txt, re.M)
-    assert len(audit) == 8, audit                                   # 4 register budgets x 2 cache-hint variants
+    assert len(audit) == 10, audit                                  # 5 register budgets x 2 cache-hint variants
     assert all(int(n) == 0 for _, n in audit), audit
     for sym, _ in audit:
         blk = txt[txt.index("Function Name: " + sym):]

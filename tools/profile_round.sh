@@ -1,6 +1,8 @@
 #!/bin/bash
 # The round's judged profile of `python bench.py` (n=1e8, m=10, one MI355X).  Run on the GPU box from the repo root:
 #     bash tools/profile_round.sh r01
+# The same at another size -- e.g. the per-rank shard of the 8-GPU run, where the two-loop is the resident kernel:
+#     DIM=12500000 bash tools/profile_round.sh r02_shard      (pmc_traffic.json -> profiles/pmc_traffic_shard.json)
 # Writes gpurun_out/prof_<tag>/{bench.json, kernel_stats.csv, pmc_*_counter_collection.csv, pmc_traffic.json, summary.md}:
 # copy them into profiles/ (pmc_traffic.json as profiles/pmc_traffic.json: bench.py's roofline.traffic reads it and names
 # the raw CSVs it was derived from).  PMC counters are collected in their own passes, with --kernel-trace only.
@@ -10,11 +12,14 @@ root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
-python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --steps 30 --warmup 12 --no-cpu-baseline --no-vector-free > "$out/stats.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 4 --warmup 12 --no-cpu-baseline --no-prof --no-vector-free > "$out/pmc_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 4 --warmup 12 --no-cpu-baseline --no-prof --no-vector-free > "$out/pmc_write.log" 2>&1
-python3 tools/summarize_profile.py "$out/stats" "$out/pmc_fetch" "$out/pmc_write" 100000000 "$out/summary.md" "$tag" > /dev/null
+dim=${DIM:-100000000}
+hist=${HIST:-10}
+if [ "$dim" = 100000000 ] && [ "$hist" = 10 ]; then size=""; else size="--dim $dim --hist $hist --no-cpu-baseline"; fi
+python3 bench.py $size > "$out/bench.json" 2> "$out/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py $size --steps 30 --warmup 12 --no-cpu-baseline --no-vector-free > "$out/stats.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- python3 bench.py $size --steps 4 --warmup 12 --no-cpu-baseline --no-prof --no-vector-free > "$out/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- python3 bench.py $size --steps 4 --warmup 12 --no-cpu-baseline --no-prof --no-vector-free > "$out/pmc_write.log" 2>&1
+python3 tools/summarize_profile.py "$out/stats" "$out/pmc_fetch" "$out/pmc_write" $dim "$out/summary.md" "$tag" $hist > /dev/null
 cp "$out"/stats/*/*_kernel_stats.csv "$out/kernel_stats.csv"
 # the RAW counter rows behind roofline.traffic (one row per dispatch; a few hundred KB) are kept and committed
 cat "$out"/pmc_fetch/*/*_counter_collection.csv > "$out/pmc_fetch_counter_collection.csv"
