@@ -348,15 +348,18 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
             nc, ms_comm = ctx.prof_read(_ffi.K_COMM)
             nr, ms_res = ctx.prof_read(_ffi.K_TWOLOOP_RESIDENT)
             if nr and not vector_free:
-                # The shard is small enough (<= ~1.25e7 elements) for the running vector to stay in registers + LDS:
-                # the whole recursion is ONE kernel that streams g once, every s and y twice and writes d once --
-                # (4m + 1) passes of 8 bytes per element instead of the launch-per-step path's 8m - 1.
+                # The running vector (or, for shards larger than the chip, the first n_res elements of it: "hybrid") stays
+                # in registers + LDS and the whole recursion is ONE kernel: the on-chip part streams g once, every s and
+                # y twice and writes d once -- (4m + 1) passes of 8 bytes per element; the part of q that stays in HBM
+                # costs the kernel-per-step path's 8m - 1.
                 avg_ms = ms_res / nr
-                passes_res = 4 * a.m + 1
-                ach = 8.0 * passes_res * n_local / (avg_ms * 1e-3) / 1e9
+                n_res = min(ctx.resident_elements(), n_local)
+                nbytes = 8 * ((4 * a.m + 1) * n_res + (8 * a.m - 1) * (n_local - n_res))
+                ach = nbytes / (avg_ms * 1e-3) / 1e9
                 roof.update(achieved=ach, frac=ach / HBM_PEAK_GBPS, kernel="two_loop_resident_kernel<ER,NT>",
-                            launches=nr, avg_ms=avg_ms, bytes_per_launch=8 * passes_res * n_local,
-                            note="algorithmic bytes of THIS kernel: (4m+1) n-vectors (q never leaves the chip)")
+                            launches=nr, avg_ms=avg_ms, bytes_per_launch=nbytes, resident_elements=n_res,
+                            note="algorithmic bytes of THIS kernel: (4m+1) n-vector passes over the elements of q it keeps "
+                                 "on the chip, (8m-1) over the rest (hybrid: shards larger than ~1.25e7 elements)")
             elif ns:
                 avg_ms = ms_step / ns
                 ach = 32.0 * n_local / (avg_ms * 1e-3) / 1e9  # 3 reads + 1 write of f64 per element
@@ -388,7 +391,8 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
                 note = "per GPU: this rank's shard, incl. the all-reduces inside the recursion"
                 if nr and not vector_free:
                     note += ("; priced at the launch-per-step minimum of 8m-2 passes for comparison across shard sizes --"
-                             " the resident kernel moves only 4m+1, so this figure may exceed what HBM delivers")
+                             " the resident kernel moves fewer bytes (roofline.bytes_per_launch), so this figure"
+                             " overstates what HBM delivered")
                 roof.update(two_loop={"ms": t_tl, "algorithmic_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS,
                                       "bytes": 8 * passes * n_local, "passes": passes, "calls": nt,
                                       "resident_kernel": bool(nr) and not vector_free, "note": note})

@@ -114,8 +114,10 @@ int lbfgs_hip_get_shard(const lbfgs_hip_ctx* ctx, lbfgs_hip_shard* out);
 /* launch geometry override for tuning (0 = default): blocks, i.e. workgroups per launch */
 int lbfgs_hip_set_grid(lbfgs_hip_ctx* ctx, int blocks);
 /* which code path the two-loop recursions of this context took so far: how many ran as the single on-chip-resident
- * kernel (rust-lbfgs_amd/csrc/resident.h) rather than as one launch per step (diagnostics, tests, bench) */
-int lbfgs_hip_path_stats(lbfgs_hip_ctx* ctx, uint64_t* resident_two_loops);
+ * kernel (rust-lbfgs_amd/csrc/resident.h) rather than as one launch per step, and how many elements of this rank's
+ * shard the last such launch kept on the chip (= n_local unless the shard is larger than the chip: "hybrid")
+ * (diagnostics, tests, bench; either pointer may be NULL) */
+int lbfgs_hip_path_stats(lbfgs_hip_ctx* ctx, uint64_t* resident_two_loops, uint64_t* resident_elements);
 
 /* ------------------------------------------------------------------------- */
 /* vectors: Vec<f64> of the reference (core.rs:24-39, lbfgs.rs:611-613)        */

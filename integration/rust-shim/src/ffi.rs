@@ -166,7 +166,7 @@ extern "C" {
     pub fn lbfgs_hip_vecncpy(y: *mut lbfgs_hip_vec, x: *const lbfgs_hip_vec) -> c_int;
     pub fn lbfgs_hip_vecdiff(z: *mut lbfgs_hip_vec, x: *const lbfgs_hip_vec, y: *const lbfgs_hip_vec) -> c_int;
     pub fn lbfgs_hip_vec2norm_sq(x: *const lbfgs_hip_vec, out_slot: c_int) -> c_int;
-    pub fn lbfgs_hip_path_stats(ctx: *mut lbfgs_hip_ctx, resident_two_loops: *mut u64) -> c_int;
+    pub fn lbfgs_hip_path_stats(ctx: *mut lbfgs_hip_ctx, resident_two_loops: *mut u64, resident_elements: *mut u64) -> c_int;
     pub fn lbfgs_hip_vec2norm(x: *const lbfgs_hip_vec, scratch_slot: c_int, out: *mut f64) -> c_int;
     pub fn lbfgs_hip_vec2norminv(x: *const lbfgs_hip_vec, scratch_slot: c_int, out: *mut f64) -> c_int;
     // ---- fused hot path ------------------------------------------------------------------------

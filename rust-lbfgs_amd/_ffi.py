@@ -138,7 +138,7 @@ def declare(L):
         "lbfgs_hip_stream": (vp, [vp]),
         "lbfgs_hip_get_shard": (i, [vp, C.POINTER(Shard)]),
         "lbfgs_hip_set_grid": (i, [vp, i]),
-        "lbfgs_hip_path_stats": (i, [vp, C.POINTER(u64)]),
+        "lbfgs_hip_path_stats": (i, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "lbfgs_hip_vec_alloc": (i, [vp, C.POINTER(vp)]),
         "lbfgs_hip_vec_free": (None, [vp]),
         "lbfgs_hip_vec_upload": (i, [vp, dp, u64]),

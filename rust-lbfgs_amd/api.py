@@ -119,8 +119,14 @@ class Context:
     def resident_two_loops(self):
         """How many two-loop recursions of this context ran as the single on-chip-resident kernel."""
         r = C.c_uint64()
-        self.check(self._L.lbfgs_hip_path_stats(self._h, C.byref(r)))
+        self.check(self._L.lbfgs_hip_path_stats(self._h, C.byref(r), None))
         return r.value
+
+    def resident_elements(self):
+        """Elements of this rank's shard the last resident two-loop launch kept on the chip (n_local unless hybrid)."""
+        e = C.c_uint64()
+        self.check(self._L.lbfgs_hip_path_stats(self._h, None, C.byref(e)))
+        return e.value
 
     def set_grid(self, blocks):
         self.check(self._L.lbfgs_hip_set_grid(self._h, blocks))

@@ -161,6 +161,8 @@ struct lbfgs_hip_ctx {
     struct LjCells* lj_cells = nullptr;   // LJ_CELLS: the rebuildable neighbour structure (allocated on demand)
     unsigned long long* gran = nullptr;   // tagged partial granules [MAX_RED][MAX_GRID][2] (stream.h)
     bool p2p_exclusive = false;           // lbfgs_hip_comm.exclusive_device: no other rank shares this GPU
+    int resident_hybrid = 1;              // LBFGS_HIP_RESIDENT_HYBRID=0: shards that do not fit the chip take the kernel-per-step path
+    uint64_t resident_elements = 0;       // elements of q the last resident launch kept on the chip (all of them unless hybrid)
     int resident_grid = 0;                // LBFGS_HIP_RESIDENT_GRID: workgroups of the resident kernel (0 = one per CU); tests
     bool resident_on = true;              // LBFGS_HIP_RESIDENT=0: never use the on-chip-resident two-loop kernel (resident.h)
     unsigned long long resident_launches = 0;  // two-loops that ran as the resident kernel (tests / bench read it)
@@ -995,6 +997,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     if (const char* e = getenv("LBFGS_HIP_DEFER_SUMS")) ctx->defer_inner_sums = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT")) ctx->resident_on = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_GRID")) ctx->resident_grid = std::max(0, atoi(e));
+    if (const char* e = getenv("LBFGS_HIP_RESIDENT_HYBRID")) ctx->resident_hybrid = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_GRAPH")) ctx->graph_max_bytes = atoi(e) ? ~(size_t)0 : 0;
     if (const char* e = getenv("LBFGS_HIP_GRAPH_MAX_MB")) ctx->graph_max_bytes = (size_t)atoll(e) << 20;
     if (const char* e = getenv("LBFGS_HIP_NT_STORE_THRESHOLD_MB")) ctx->nt_store_threshold_bytes = (size_t)atoll(e) << 20;
@@ -1145,9 +1148,10 @@ int lbfgs_hip_get_shard(const lbfgs_hip_ctx* ctx, lbfgs_hip_shard* out) {
     return LBFGS_HIP_OK;
 }
 
-int lbfgs_hip_path_stats(lbfgs_hip_ctx* ctx, uint64_t* resident_two_loops) {
+int lbfgs_hip_path_stats(lbfgs_hip_ctx* ctx, uint64_t* resident_two_loops, uint64_t* resident_elements) {
     if (!ctx) return LBFGS_HIP_ERR_ARG;
     if (resident_two_loops) *resident_two_loops = ctx->resident_launches;
+    if (resident_elements) *resident_elements = ctx->resident_elements;
     return LBFGS_HIP_OK;
 }
 
@@ -1578,18 +1582,28 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     // vectors of a few MB, where a hand-off among fewer workgroups is worth more than the idle CUs' bandwidth: >= 8 pairs per
     // thread, at least 64 workgroups; measured at n = 1e5 / 3e5 / 1e6, profiles/r02_resident_small_n.log)
     const uint64_t n = ctx->shard.n_local;
-    const int grid_auto = (int)std::min<uint64_t>((uint64_t)ctx->cu_count, std::max<uint64_t>(64, ((n >> 1) + BLOCK * 8 - 1) / (BLOCK * 8)));
+    // ... and 27/32 of the CUs, the streaming kernels' grid, once less than a fifth of a shard fits the chip and
+    // the kernel is a streaming kernel above all (n = 1e8: 9.73 ms against 9.83 with 256; at 2.5e7 256 wins by 4 %)
+    const bool mostly_streaming = (n >> 1) > 5ull * (uint64_t)(60 + RES_LDS_PAIRS_MAX) * (uint64_t)ctx->cu_count * BLOCK;
+    const int grid_auto = mostly_streaming ? std::max(1, ctx->cu_count * 27 / 32)
+        : (int)std::min<uint64_t>((uint64_t)ctx->cu_count, std::max<uint64_t>(64, ((n >> 1) + BLOCK * 8 - 1) / (BLOCK * 8)));
     const int grid = ctx->resident_grid > 0 ? std::min(ctx->resident_grid, ctx->cu_count) : grid_auto;
     if (grid < 1 || grid > BLOCK || grid > MAX_GRID) return 0;  // (every thread polls one workgroup's granules)
     const uint64_t per_round = (uint64_t)grid * BLOCK;
     const uint64_t E = ((n >> 1) + per_round - 1) / per_round;  // 16-byte pairs per thread
     constexpr int ER_MAX = 60;
-    if (E == 0 || E > ER_MAX + RES_LDS_PAIRS_MAX || (n >> 1) + per_round * 4 >= (1ull << 28)) return 0;
+    // Larger shards: HYBRID -- the first 60 + 36 rounds of every thread stay on the chip, the rest of q lives in `d` and is
+    // streamed by every step as on the kernel-per-step path (resident.h).  Not under OWL-QN (the projection is applied
+    // where the on-chip part is written out; configs with OWL-QN fit the chip).
+    const bool hybrid = E > (uint64_t)(ER_MAX + RES_LDS_PAIRS_MAX);
+    if (hybrid && (!ctx->resident_hybrid || owl)) return 0;
+    if (E == 0 || (n >> 1) + per_round * 4 >= (1ull << 28)) return 0;
     if (ctx->red_count % 0xFFFFFFFFull + 2ull * (uint64_t)bound + 4ull >= 0xFFFFFFFFull) return 0;  // tag wrap: eager path
     // Rounds 0 .. E-2 are full for every thread, round E-1 is the ragged one.  The register rounds carry no bounds checks,
     // so ER <= E-1; the rest (the ragged round included) lives in LDS -- everything, for the smallest vectors (ER = 0).
     const int er = E - 1 >= ER_MAX ? ER_MAX : E - 1 >= 40 ? 40 : E - 1 >= 24 ? 24 : E - 1 >= 8 ? 8 : 0;
-    const uint32_t el = (uint32_t)((E - er + RES_UNROLL - 1) / RES_UNROLL * RES_UNROLL);
+    const uint32_t eh = hybrid ? (uint32_t)(E - ER_MAX - RES_LDS_PAIRS_MAX) : 0u;  // rounds whose q stays in HBM
+    const uint32_t el = hybrid ? (uint32_t)RES_LDS_PAIRS_MAX : (uint32_t)((E - er + RES_UNROLL - 1) / RES_UNROLL * RES_UNROLL);
     if (el > (uint32_t)RES_LDS_PAIRS_MAX) return 0;
     if (ctx->resident_ok < 0) {  // once: can this device hold one such workgroup per CU?
         int nb = 0;
@@ -1624,6 +1638,7 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     ra.owl_end = owl_end;
     ra.pairs_per_thread = (uint32_t)E;
     ra.lds_pairs = el;
+    ra.hbm_pairs = eh;
     int ns = 0;
     auto add = [&](const double* u, const double* v, int j, int mode_b, int scale, int aidx, int last) {
         ResStep& st = ra.step[ns++];
@@ -1661,6 +1676,7 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     }
     if (rc != LBFGS_HIP_OK) return rc;
     ctx->resident_launches += 1;
+    ctx->resident_elements = hybrid ? 2ull * per_round * (uint64_t)(er + el) : n;
     *new_end = e1;
     return 1;
 }

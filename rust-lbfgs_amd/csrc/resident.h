@@ -38,6 +38,10 @@ constexpr int RES_UNROLL = 4;          // pairs whose loads are issued together 
 #ifndef LH_RES_AHEAD
 #define LH_RES_AHEAD 1
 #endif
+#ifndef LH_RES_HBM_UNROLL
+#define LH_RES_HBM_UNROLL 4
+#endif
+constexpr int RES_HBM_UNROLL = LH_RES_HBM_UNROLL;  // hybrid: rounds per group of the part of q that stays in HBM
 constexpr int RES_AHEAD = LH_RES_AHEAD;  // groups whose loads are in flight ahead of the group being worked on (2 was measured:
                                          // no faster at 1.25e7 elements, 4 % slower at 3e6 -- the hand-off is latency, not bandwidth)
 
@@ -64,8 +68,9 @@ struct ResArgs {
     uint64_t gofs;           // global index of this shard's first element (OWL-QN's range is global)
     uint64_t owl_start, owl_end;  // OWL-QN: the last step also projects d onto the orthant of -pg on [start, end)
     int owl;                      //   (orthantwise.rs:140-161; then v of the last step is pg) and leaves 3 sums
-    uint32_t pairs_per_thread;  // E: 16-byte pairs each thread owns (registers first, then LDS)
+    uint32_t pairs_per_thread;  // E: 16-byte pairs each thread owns (registers first, then LDS, then -- hybrid -- HBM)
     uint32_t lds_pairs;         // of which in LDS (a multiple of RES_UNROLL)
+    uint32_t hbm_pairs;         // hybrid: the rounds beyond registers + LDS, whose part of q lives in `d` itself (0: none)
     int nsteps;
     ResStep step[RES_MAX_STEPS];
 };
@@ -445,6 +450,87 @@ __device__ __forceinline__ void res_step(ResWin& w, d2* q_lds, const ResPos& ps,
     }
 }
 
+// ---- hybrid: shards too large for the chip.  Rounds e >= ER + EL of a thread keep their part of q in HBM -- in `d`,
+// as the kernel-per-step path does -- and every step streams them 3r + 1w; the first ER + EL rounds stay on the chip
+// (2r).  The same thread reads and rewrites the same pairs of `d` in every step, so nothing new crosses workgroups.
+// In the FIRST step the source of q is g (negated on the fly: the kernel-per-step path's fused first step), so `d` is
+// never initialised by a pass of its own.  Loads of the next group of RES_UNROLL pairs are in flight while one is
+// worked on (2 x 12 loads of 16 bytes per thread).
+struct ResHbmGroup {
+    d2 q[RES_HBM_UNROLL], u[RES_HBM_UNROLL], v[RES_HBM_UNROLL];
+};
+// (full rounds only: no bounds checks, no branches)
+template <bool NT, bool NEEDV>
+__device__ __forceinline__ void res_hbm_fetch(ResHbmGroup& g, const uint32_t e, const ResPos& ps, const double* qsrc,
+                                              const double* up, const double* vp) {
+    const uint32_t p0 = res_opaque(ps.p_first + e * ps.p_stride);
+#pragma unroll
+    for (int k = 0; k < RES_HBM_UNROLL; ++k) {
+        const uint32_t p = p0 + (uint32_t)k * ps.p_stride;
+        g.q[k] = ld16<NT>(qsrc, p);
+        g.u[k] = ld16<NT>(up, p);
+        if constexpr (NEEDV) g.v[k] = ld16<NT>(vp, p);
+        else g.v[k] = g.u[k];
+    }
+}
+template <bool NT, int MODE>
+__device__ __forceinline__ void res_hbm_work(ResHbmGroup& g, const uint32_t e, const ResPos& ps, const double qsign, double* d,
+                                             const double c, const double gamma, double* acc) {
+    const uint32_t p0 = res_opaque(ps.p_first + e * ps.p_stride);
+#pragma unroll
+    for (int k = 0; k < RES_HBM_UNROLL; ++k) {
+        d2 q = g.q[k];
+        q.x = q.x * qsign;  // +1.0, or -1.0 in the first step (q = -g: exact)
+        q.y = q.y * qsign;
+        res_one<MODE>(q, g.u[k], g.v[k], c, gamma, acc);
+        st16<NT>(d, p0 + (uint32_t)k * ps.p_stride, q);
+    }
+    res_pin_sums<(MODE == 2 ? 2 : 1)>(acc);
+}
+// rounds [e_begin, e_end) of this thread; every round before the shard's last one is full for every thread, so groups of
+// RES_HBM_UNROLL rounds below `e_full` run without checks and the (at most RES_HBM_UNROLL + 1) rounds after them one at a time
+template <bool NT, int MODE>
+__device__ __forceinline__ void res_step_hbm(const uint32_t e_begin, const uint32_t e_end, const ResPos& ps, const double* qsrc,
+                                             const double qsign, double* d, const double* up, const double* vp, const double c,
+                                             const double gamma, double* acc) {
+    if (e_begin >= e_end) return;
+    asm volatile("" ::: "memory");
+    const uint32_t ngroups = (e_end - 1 - e_begin) / RES_HBM_UNROLL;  // groups made of full rounds only
+    const uint32_t e_full = e_begin + ngroups * RES_HBM_UNROLL;
+    if (ngroups > 0) {
+        ResHbmGroup ga, gb;  // two buffers, used alternately: the next group's 12 loads fly while one is worked on
+        const uint32_t e_last = e_full - RES_HBM_UNROLL;
+        res_hbm_fetch<NT, MODE != 1>(ga, e_begin, ps, qsrc, up, vp);
+        uint32_t e = e_begin;
+        for (;;) {
+            res_hbm_fetch<NT, MODE != 1>(gb, min(e + RES_HBM_UNROLL, e_last), ps, qsrc, up, vp);  // (past the end: the last group again, unused)
+            asm volatile("" ::: "memory");
+            res_hbm_work<NT, MODE>(ga, e, ps, qsign, d, c, gamma, acc);
+            e += RES_HBM_UNROLL;
+            if (e >= e_full) break;
+            res_hbm_fetch<NT, MODE != 1>(ga, min(e + RES_HBM_UNROLL, e_last), ps, qsrc, up, vp);
+            asm volatile("" ::: "memory");
+            res_hbm_work<NT, MODE>(gb, e, ps, qsign, d, c, gamma, acc);
+            e += RES_HBM_UNROLL;
+            if (e >= e_full) break;
+        }
+    }
+    for (uint32_t e = e_full; e < e_end; ++e) {  // the last few rounds, the ragged one among them
+        const uint32_t p = ps.p_first + e * ps.p_stride;
+        if (p < ps.n2) {
+            d2 q = ld16<NT>(qsrc, p);
+            const d2 uu = ld16<NT>(up, p);
+            d2 vv = uu;
+            if constexpr (MODE != 1) vv = ld16<NT>(vp, p);
+            q.x = q.x * qsign;
+            q.y = q.y * qsign;
+            res_one<MODE>(q, uu, vv, c, gamma, acc);
+            st16<NT>(d, p, q);
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+
 // ER = pairs per thread held in (accumulation) registers: a multiple of RES_UNROLL, at most 60.
 template <int ER, bool NT>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -488,6 +574,18 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
             acc[0] += sv.x * q.x;
             acc[0] += sv.y * q.y;
             q_lds[(size_t)(e0 + u) * BLOCK + tid] = q;
+        }
+    }
+    // hybrid rounds: q stays in HBM (the first step reads it from g); only the first numerator needs them here
+    const uint32_t EH0 = ER + EL, EH1 = ER + EL + a.hbm_pairs;
+    if (need_first) {
+        for (uint32_t e = EH0; e < EH1; ++e) {
+            const uint32_t p = p_first + e * p_stride;
+            if (p < n2) {
+                const d2 gv = ld16<NT>(a.g, p), sv = ld16<NT>(a.first_s, p);
+                acc[0] += sv.x * (-gv.x);
+                acc[0] += sv.y * (-gv.y);
+            }
         }
     }
     if (tail_owner) {
@@ -534,9 +632,18 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         acc[1] = 0.0;
         acc[2] = 0.0;
         const int mode = st.last ? 2 : (st.v == nullptr ? 1 : 0);
-        if (mode == 0) res_step<ER, NT, 0>(win, q_lds, ps, st.u, st.v, c, gamma, acc);
-        else if (mode == 1) res_step<ER, NT, 1>(win, q_lds, ps, st.u, st.u, c, gamma, acc);
-        else res_step<ER, NT, 2>(win, q_lds, ps, st.u, st.v, c, gamma, acc);
+        const double* qsrc = si == 0 ? a.g : a.d;  // (hybrid rounds only)
+        const double qsign = si == 0 ? -1.0 : 1.0;
+        if (mode == 0) {
+            res_step<ER, NT, 0>(win, q_lds, ps, st.u, st.v, c, gamma, acc);
+            res_step_hbm<NT, 0>(EH0, EH1, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc);
+        } else if (mode == 1) {
+            res_step<ER, NT, 1>(win, q_lds, ps, st.u, st.u, c, gamma, acc);
+            res_step_hbm<NT, 1>(EH0, EH1, ps, qsrc, qsign, a.d, st.u, st.u, c, gamma, acc);
+        } else {
+            res_step<ER, NT, 2>(win, q_lds, ps, st.u, st.v, c, gamma, acc);
+            res_step_hbm<NT, 2>(EH0, EH1, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc);
+        }
         if (si + 1 < a.nsteps) prefetch(si + 1);
         if (tail_owner) {
             const double ut = st.u[a.n - 1], vt = (mode == 1) ? ut : st.v[a.n - 1];

@@ -348,7 +348,7 @@ static int eval_obj(const lbfgs_hip_objective* obj, lbfgs_hip_ctx* c, const doub
     }
     return LBFGS_HIP_OK;
 }
-int lbfgs_hip_path_stats(lbfgs_hip_ctx*, uint64_t* r) { if (r) *r = 0; return LBFGS_HIP_OK; }
+int lbfgs_hip_path_stats(lbfgs_hip_ctx*, uint64_t* r, uint64_t* e) { if (r) *r = 0; if (e) *e = 0; return LBFGS_HIP_OK; }
 int lbfgs_hip_lj_cells_stats(lbfgs_hip_ctx*, uint64_t* rebuilds, uint64_t* evaluations, uint32_t* longest) {
     if (rebuilds) *rebuilds = 0;
     if (evaluations) *evaluations = 0;

@@ -73,12 +73,13 @@ except R.LbfgsError as e:
     err = e.code
     xs = x
 ctx_resident = ctx.resident_two_loops()
+ctx_resident_elements = ctx.resident_elements()
 nred, _ = ctx.prof_read(_ffi.K_COMM)   # the test double counts its all-reduces here
 if os.environ.get("LBFGS_WORKER_PRODUCT") == "1":
     nred = 1
 ctx.close()
 out = dict(rank=rank, lo=lo, hi=hi, rows=rows, x=xs.tolist(), allreduces=nred, err=err,
-           resident=ctx_resident)
+           resident=ctx_resident, resident_elements=ctx_resident_elements)
 json.dump(out, open(os.path.join(os.environ["LBFGS_OUT"], f"rank{rank}.json"), "w"))
 dist.barrier()
 dist.destroy_process_group()

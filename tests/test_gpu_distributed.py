@@ -62,25 +62,31 @@ def test_rccl_single_rank_communicator():
         x.free(); y.free()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_resident_two_loop_with_the_p2p_exchange(world, tmp_path, monkeypatch):
+@pytest.mark.parametrize("world,n,grid", [(2, 1_300_003, 80), (3, 1_500_001, 48), (2, 3_400_001, 32)])
+def test_resident_two_loop_with_the_p2p_exchange(world, n, grid, tmp_path, monkeypatch):
     """The on-chip-resident two-loop kernel (resident.h) under the P2P communicator: workgroup 0 of every rank closes
     each of the kernel's 2m hand-offs across the ranks through the mailboxes and broadcasts the global total to its
     other workgroups.  That path is meant for ranks that own their GPU (`exclusive_device`); here two / three ranks
     share ONE, so each is given a third / a fifth of the CUs (LBFGS_HIP_RESIDENT_GRID) so that all of them are resident
-    together.  Checked against the single-rank oracle, and every rank must really have run the resident kernel."""
+    together.  Checked against the single-rank oracle, and every rank must really have run the resident kernel.  The
+    third case is HYBRID: each rank's shard exceeds what its 32 workgroups hold, so part of q stays in
+    HBM (the form that shards of more than 1.25e7 elements take on a whole GPU)."""
     if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
         pytest.skip("needs the GPU")
     monkeypatch.setenv("LBFGS_WORKER_PRODUCT", "1")
     monkeypatch.setenv("LBFGS_COMM_KIND", "p2p")
     monkeypatch.setenv("LBFGS_TEST_EXCLUSIVE_DEVICE", "1")
-    monkeypatch.setenv("LBFGS_HIP_RESIDENT_GRID", "80" if world == 2 else "48")
-    case = dict(name="quadratic_resident", n=1_300_003 if world == 2 else 1_500_001, m=6, iters=14, objective="quadratic")
+    monkeypatch.setenv("LBFGS_HIP_RESIDENT_GRID", str(grid))
+    case = dict(name="quadratic_resident", n=n, m=6, iters=14, objective="quadratic")
     outs = run_world(case, world, tmp_path)
     ref_rows, ref_x = oracle_rows(case)
     for o in outs:
         assert o["rows"] == outs[0]["rows"]
         assert o["resident"] >= 10, o["resident"]
+        if n > 3_000_000:
+            assert 0 < o["resident_elements"] < o["hi"] - o["lo"], o["resident_elements"]   # hybrid
+        else:
+            assert o["resident_elements"] == o["hi"] - o["lo"]
     assert len(outs[0]["rows"]) == len(ref_rows)
     for got, ref in zip(outs[0]["rows"], ref_rows):
         assert got[:3] == ref[:3]

@@ -973,7 +973,8 @@ def test_two_loop_launch_forms_are_bitwise_equal(knob, owl, monkeypatch):
         assert np.array_equal(rows["0"][1], rows["1"][1])
 
 
-@pytest.mark.parametrize("n", [3, 1000, 100_003, 600_001, 1_200_001, 2_097_152, 3_000_017, 8_000_000, 12_500_224])
+@pytest.mark.parametrize("n", [3, 1000, 100_003, 600_001, 1_200_001, 2_097_152, 3_000_017, 8_000_000, 12_500_224,
+                               12_582_913, 12_582_915, 13_000_001, 20_000_000])
 @pytest.mark.parametrize("m,k,end", [(10, 37, 3), (10, 4, 3), (6, 1, 0), (7, 7, 6)])
 def test_two_loop_resident_kernel_vs_launch_per_step(n, m, k, end, monkeypatch):
     """The recursion as ONE kernel with the running vector resident in registers + LDS (resident.h) against the
@@ -1014,7 +1015,12 @@ def test_two_loop_resident_kernel_vs_launch_per_step(n, m, k, end, monkeypatch):
             four = ctx.scalars(40, 4)
             res.append((ne3, d.to_numpy(), np.array([four[0], four[2], four[3]]), hist.scalars()[1]))
             assert four[2] <= four[0]                      # the projection only removes components
-            assert ctx.resident_two_loops() == (4 if mode == "1" else 0)  # the path under test really ran
+            # the path under test really ran.  Shards larger than the chip (> 96 pairs per thread) run HYBRID: the first
+            # 96 rounds of q on the chip, the rest streamed from d -- except under OWL-QN, which takes the per-step path
+            hybrid = (n >> 1) > 96 * 65536
+            assert ctx.resident_two_loops() == (0 if mode == "0" else 3 if hybrid else 4)
+            if mode == "1":
+                assert ctx.resident_elements() == (2 * 96 * 65536 if hybrid else n)
             out[mode] = res
             hist.free()
             for v in (g, d, tmp):

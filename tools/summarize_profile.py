@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 outputs of `bench.py` into profiles/ (kernel stats + PMC HBM traffic).
 
-    python tools/summarize_profile.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir> <n_local> <out.md> [tag] [m]
+    python tools/summarize_profile.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir> <n_local> <out.md> [tag] [m] [bench.json]
+(bench.json: the un-profiled line of the same command; its roofline.bytes_per_launch prices the resident kernel, whose
+on-chip share of q depends on the shard size)
 
 PMC handling follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE
 are collected in SEPARATE passes (TCC slots), both are in KiB; on gfx950 FETCH_SIZE reports exactly
@@ -84,6 +86,15 @@ def main():
     tag = sys.argv[6] if len(sys.argv) > 6 else "rXX"
     global M
     M = int(sys.argv[7]) if len(sys.argv) > 7 else 10
+    resident_bytes = None
+    if len(sys.argv) > 8:
+        try:
+            import json as _json
+            roof = _json.loads(open(sys.argv[8]).read().strip().splitlines()[-1])["roofline"]
+            if "two_loop_resident_kernel" in roof.get("kernel", ""):
+                resident_bytes = roof["bytes_per_launch"]
+        except Exception:  # noqa: BLE001
+            pass
     n_local = int(n_local)
     fetch = pmc(fdir, "FETCH_SIZE")
     write = pmc(wdir, "WRITE_SIZE")
@@ -110,15 +121,20 @@ def main():
             lines.append(f"| `{nm}` | {r['Calls']} | {avg_us:.1f} | - | - | - | - | - | - | - |")
             continue
         gb = (rw[0] + rw[1]) * 8 * n_local / 1e9
+        rwtxt = f"{rw[0]}r+{rw[1]}w"
+        if "two_loop_resident_kernel" in nm and resident_bytes:
+            gb = resident_bytes / 1e9
+            rwtxt = "(see left)"
+            label += f"; {gb:.2f} GB = 4m+1 passes over the on-chip part of q, 8m-1 over the rest"
         gbps = gb / (avg_us * 1e-6)
         fr = fetch.get(nm)
         wr = write.get(nm)
         fr_gb = fr * 1024 * 2 / 1e9 if fr is not None else None
         wr_gb = wr * 1024 / 1e9 if wr is not None else None
         ratio = (fr_gb + wr_gb) / gb if fr_gb is not None and wr_gb is not None else None
-        lines.append(f"| `{nm}` ({label}) | {r['Calls']} | {avg_us:.1f} | {rw[0]}r+{rw[1]}w | {gb:.2f} | {gbps:.0f} | "
+        lines.append(f"| `{nm}` ({label}) | {r['Calls']} | {avg_us:.1f} | {rwtxt} | {gb:.2f} | {gbps:.0f} | "
                      f"{gbps / 80:.1f} | {fr_gb:.3f} | {wr_gb:.3f} | {ratio:.3f} |" if ratio is not None else
-                     f"| `{nm}` ({label}) | {r['Calls']} | {avg_us:.1f} | {rw[0]}r+{rw[1]}w | {gb:.2f} | {gbps:.0f} | "
+                     f"| `{nm}` ({label}) | {r['Calls']} | {avg_us:.1f} | {rwtxt} | {gb:.2f} | {gbps:.0f} | "
                      f"{gbps / 80:.1f} | - | - | - |")
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
