@@ -38,6 +38,9 @@ constexpr int RES_UNROLL = 4;          // pairs whose loads are issued together 
 #ifndef LH_RES_AHEAD
 #define LH_RES_AHEAD 1
 #endif
+#ifndef LH_RES_HBM_ALTERNATE
+#define LH_RES_HBM_ALTERNATE 0  // hybrid: odd steps sweep the HBM rounds from the top down (what a step wrote last, the next reads first)
+#endif
 #ifndef LH_RES_HBM_UNROLL
 #define LH_RES_HBM_UNROLL 4
 #endif
@@ -488,33 +491,12 @@ __device__ __forceinline__ void res_hbm_work(ResHbmGroup& g, const uint32_t e, c
     res_pin_sums<(MODE == 2 ? 2 : 1)>(acc);
 }
 // rounds [e_begin, e_end) of this thread; every round before the shard's last one is full for every thread, so groups of
-// RES_HBM_UNROLL rounds below `e_full` run without checks and the (at most RES_HBM_UNROLL + 1) rounds after them one at a time
+// RES_HBM_UNROLL rounds below `e_full` run without checks and the (at most RES_HBM_UNROLL) rounds after them one at a
+// time.  `rev`: sweep from the high addresses down (the groups in descending order, the last rounds first).
 template <bool NT, int MODE>
-__device__ __forceinline__ void res_step_hbm(const uint32_t e_begin, const uint32_t e_end, const ResPos& ps, const double* qsrc,
+__device__ __forceinline__ void res_hbm_tail(const uint32_t e_full, const uint32_t e_end, const ResPos& ps, const double* qsrc,
                                              const double qsign, double* d, const double* up, const double* vp, const double c,
                                              const double gamma, double* acc) {
-    if (e_begin >= e_end) return;
-    asm volatile("" ::: "memory");
-    const uint32_t ngroups = (e_end - 1 - e_begin) / RES_HBM_UNROLL;  // groups made of full rounds only
-    const uint32_t e_full = e_begin + ngroups * RES_HBM_UNROLL;
-    if (ngroups > 0) {
-        ResHbmGroup ga, gb;  // two buffers, used alternately: the next group's 12 loads fly while one is worked on
-        const uint32_t e_last = e_full - RES_HBM_UNROLL;
-        res_hbm_fetch<NT, MODE != 1>(ga, e_begin, ps, qsrc, up, vp);
-        uint32_t e = e_begin;
-        for (;;) {
-            res_hbm_fetch<NT, MODE != 1>(gb, min(e + RES_HBM_UNROLL, e_last), ps, qsrc, up, vp);  // (past the end: the last group again, unused)
-            asm volatile("" ::: "memory");
-            res_hbm_work<NT, MODE>(ga, e, ps, qsign, d, c, gamma, acc);
-            e += RES_HBM_UNROLL;
-            if (e >= e_full) break;
-            res_hbm_fetch<NT, MODE != 1>(ga, min(e + RES_HBM_UNROLL, e_last), ps, qsrc, up, vp);
-            asm volatile("" ::: "memory");
-            res_hbm_work<NT, MODE>(gb, e, ps, qsign, d, c, gamma, acc);
-            e += RES_HBM_UNROLL;
-            if (e >= e_full) break;
-        }
-    }
     for (uint32_t e = e_full; e < e_end; ++e) {  // the last few rounds, the ragged one among them
         const uint32_t p = ps.p_first + e * ps.p_stride;
         if (p < ps.n2) {
@@ -528,6 +510,37 @@ __device__ __forceinline__ void res_step_hbm(const uint32_t e_begin, const uint3
             st16<NT>(d, p, q);
         }
     }
+}
+template <bool NT, int MODE>
+__device__ __forceinline__ void res_step_hbm(const uint32_t e_begin, const uint32_t e_end, const bool rev, const ResPos& ps,
+                                             const double* qsrc, const double qsign, double* d, const double* up, const double* vp,
+                                             const double c, const double gamma, double* acc) {
+    if (e_begin >= e_end) return;
+    asm volatile("" ::: "memory");
+    const uint32_t ngroups = (e_end - 1 - e_begin) / RES_HBM_UNROLL;  // groups made of full rounds only
+    const uint32_t e_full = e_begin + ngroups * RES_HBM_UNROLL;
+    if (rev) res_hbm_tail<NT, MODE>(e_full, e_end, ps, qsrc, qsign, d, up, vp, c, gamma, acc);
+    if (ngroups > 0) {
+        ResHbmGroup ga, gb;  // two buffers, used alternately: the next group's 12 loads fly while one is worked on
+        const uint32_t last = ngroups - 1;
+        auto first_round = [&](const uint32_t i) {  // of the i-th group in sweep order (past the end: the last one again, unused)
+            const uint32_t k = min(i, last);
+            return e_begin + (rev ? last - k : k) * RES_HBM_UNROLL;
+        };
+        res_hbm_fetch<NT, MODE != 1>(ga, first_round(0), ps, qsrc, up, vp);
+        uint32_t i = 0;
+        for (;;) {
+            res_hbm_fetch<NT, MODE != 1>(gb, first_round(i + 1), ps, qsrc, up, vp);
+            asm volatile("" ::: "memory");
+            res_hbm_work<NT, MODE>(ga, first_round(i), ps, qsign, d, c, gamma, acc);
+            if (++i >= ngroups) break;
+            res_hbm_fetch<NT, MODE != 1>(ga, first_round(i + 1), ps, qsrc, up, vp);
+            asm volatile("" ::: "memory");
+            res_hbm_work<NT, MODE>(gb, first_round(i), ps, qsign, d, c, gamma, acc);
+            if (++i >= ngroups) break;
+        }
+    }
+    if (!rev) res_hbm_tail<NT, MODE>(e_full, e_end, ps, qsrc, qsign, d, up, vp, c, gamma, acc);
     asm volatile("" ::: "memory");
 }
 
@@ -634,15 +647,16 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         const int mode = st.last ? 2 : (st.v == nullptr ? 1 : 0);
         const double* qsrc = si == 0 ? a.g : a.d;  // (hybrid rounds only)
         const double qsign = si == 0 ? -1.0 : 1.0;
+        const bool rev = LH_RES_HBM_ALTERNATE && (si & 1);  // (see LH_RES_HBM_ALTERNATE)
         if (mode == 0) {
             res_step<ER, NT, 0>(win, q_lds, ps, st.u, st.v, c, gamma, acc);
-            res_step_hbm<NT, 0>(EH0, EH1, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc);
+            res_step_hbm<NT, 0>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc);
         } else if (mode == 1) {
             res_step<ER, NT, 1>(win, q_lds, ps, st.u, st.u, c, gamma, acc);
-            res_step_hbm<NT, 1>(EH0, EH1, ps, qsrc, qsign, a.d, st.u, st.u, c, gamma, acc);
+            res_step_hbm<NT, 1>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.u, c, gamma, acc);
         } else {
             res_step<ER, NT, 2>(win, q_lds, ps, st.u, st.v, c, gamma, acc);
-            res_step_hbm<NT, 2>(EH0, EH1, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc);
+            res_step_hbm<NT, 2>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc);
         }
         if (si + 1 < a.nsteps) prefetch(si + 1);
         if (tail_owner) {

@@ -13,12 +13,15 @@ import tests.test_gpu_parity as T  # noqa: E402
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 bad = []
 for seed in range(lo, hi):
+    # both launch forms of the two-loop in turn (tests/test_gpu_parity.py two_loop_path): one resident kernel / a kernel per step
+    path = "resident" if seed % 2 == 0 else "per_step"
+    os.environ["LBFGS_HIP_RESIDENT"] = "1" if path == "resident" else "0"
     try:
-        T.test_random_configurations_match_oracle(seed)
+        T.test_random_configurations_match_oracle(seed, path)
     except Exception:  # noqa: BLE001
         bad.append(seed)
         print("FAIL seed", seed, traceback.format_exc().splitlines()[-1][:600], flush=True)
     if seed % 100 == 0:
         print("... seed", seed, "failures so far", len(bad), flush=True)
-print("seeds", lo, "..", hi - 1, "failures:", bad)
+print("seeds", lo, "..", hi - 1, "failures:", len(bad), bad[:40])
 sys.exit(1 if bad else 0)
