@@ -1,5 +1,5 @@
-// rust-lbfgs_amd/csrc/resident.h -- the two-loop recursion (lbfgs.rs:569-604) as ONE kernel that keeps the running
-// vector q ON THE CHIP for the whole recursion.
+// rust-lbfgs_amd/csrc/resident.h -- the two-loop recursion (lbfgs.rs:569-604) as ONE persistent kernel that keeps the
+// running vector q ON THE CHIP for the whole recursion -- all of it when the shard fits, the first part of it otherwise.
 //
 // MI355X has 128 MiB of vector registers (256 CUs x 4 SIMD x 512 x 64 lanes x 4 B) and 40 MiB of LDS.  The running
 // vector of the recursion -- read and rewritten by every one of its 2*bound steps -- fits there whenever a rank's shard
@@ -8,19 +8,23 @@
 // reads and a write, and the steps are separated by a grid-wide hand-off of the partial sums instead of a kernel
 // boundary:
 //      launch-per-step path   8*bound - 1 passes of an n-vector, 2*bound kernel boundaries
-//      this kernel            4*bound + 1 passes (g once, every s and y once... twice over both loops, d written once),
-//                             one launch
+//      this kernel            4*bound + 1 passes (g at the start, every s and y in both loops, g again in the last step,
+//                             d written once), one launch
 // That is the per-rank regime of the 8-GPU run of BASELINE.json's metric (n = 1e8 / 8), and of its configs 2 and 3.
+// HYBRID: a larger shard keeps the first ER + EL = 96 rounds of every thread on the chip and leaves the rest of q in
+// HBM (in `d`), streamed 3r + 1w by every step as on the launch-per-step path -- (4b+1) passes over the on-chip
+// elements, (8b-1) over the others, still one launch (n = 1e8 on one GPU: 10.6 % of q on chip; res_step_hbm below).
 //
-// Synchronisation between steps.  Nothing but the partial sums crosses workgroups: q never leaves its thread, u / v / g
-// were written by earlier kernels.  After a step every workgroup publishes its partial sum(s) as tagged 8-byte
+// Synchronisation between steps.  Nothing but the partial sums crosses workgroups: q never leaves its thread (the HBM
+// part of a hybrid shard is read and rewritten by the same thread every step), u / v / g were written by earlier
+// kernels.  After a step every workgroup publishes its partial sum(s) as tagged 8-byte
 // granules (tag = the step's sequence number; agent-scope atomics on both sides, no fence: stream.h) into a double
 // buffer indexed by the step's parity, and then EVERY workgroup collects all G partials -- thread t polls workgroup t's
 // granules -- and adds them up in the fixed order of stream.h's reducer (wave tree, waves in order).  All workgroups
 // therefore hold the same bits for the total and form the same coefficient; no broadcast step is needed.  A workgroup can
 // be at most one step ahead of any other (it needs everybody's partial of step s to leave step s), so two buffers
-// suffice.  All G workgroups must be resident at once: the grid is one workgroup per CU (the LDS share makes it exactly
-// one), the kernel is launched alone on its stream, and every spin is bounded by a wall-clock timeout that raises
+// suffice.  All G workgroups must be resident at once: the grid is at most one workgroup per CU (the LDS share makes it
+// exactly one), the kernel is launched alone on its stream, and every spin is bounded by a wall-clock timeout that raises
 // *red.err (surfaced at the next scalar read) -- a missing workgroup ends as an error, not as a hang.
 //
 // Arithmetic is the reference's, operation by operation (q + c*u: a multiply then an add, math.rs:35; dot products as
