@@ -22,8 +22,9 @@ child job per communicator ("leg"), each under a wall-clock timeout:
     rank 0 picks a fresh rendezvous port per leg and each rank starts ITS child
     `python bench.py --_rank-mode --comm <leg>` with the same RANK / LOCAL_RANK / WORLD_SIZE.
 Legs, in this order: "p2p" (direct xGMI mailbox exchange inside the reducing kernels -- the path the
-multi-process tests cover), then "rccl" (ncclAllReduce on the compute stream); "callback" (host-staged
-all-reduce through gloo) only if neither produced a result.  A leg that fails or hangs is reported in
+multi-process tests cover; the two-loop runs as one persistent kernel), "p2p-per-step" (the same
+communicator with a kernel per two-loop step) only if the p2p leg failed, then "rccl" (ncclAllReduce on
+the compute stream); "callback" (host-staged all-reduce through gloo) only if none produced a result.  A leg that fails or hangs is reported in
 `config.legs`; the run prints ONE JSON line with the best leg as `value` and exits 0 if any leg
 succeeded.
 
@@ -541,7 +542,7 @@ def free_port():
 def passthrough(a, leg):
     args = ["--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup), "--dim", str(a.n), "--hist",
             str(a.m), "--repeats", str(a.repeats), "--prof-every", str(a.prof_every), "--line-eval", str(a.line_eval),
-            "--pg-backend", a.pg_backend, "--comm", leg, "--no-cpu-baseline", "--_rank-mode"]
+            "--pg-backend", a.pg_backend, "--comm", leg.split("-")[0], "--no-cpu-baseline", "--_rank-mode"]
     if a.no_prof:
         args.append("--no-prof")
     if a.no_vector_free:
@@ -628,16 +629,19 @@ def supervisor_main(a):
             # (LBFGS_BENCH_WORKER: the CPU suite runs the rank processes on the test double of the C-ABI)
             cmd_tail = [os.environ.get("LBFGS_BENCH_WORKER") or os.path.join(ROOT, "bench.py")] + passthrough(a, leg)
             child = None
+        leg_env = dict(base_env)
+        if leg == "p2p-per-step":  # the p2p communicator with one kernel per two-loop step (no persistent kernel)
+            leg_env["LBFGS_HIP_RESIDENT"] = "0"
         if under_launcher:
             port = [free_port() if rank == 0 else 0]
             dist.broadcast_object_list(port, src=0)
-            env = dict(base_env, MASTER_PORT=str(port[0]))
+            env = dict(leg_env, MASTER_PORT=str(port[0]))
             for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
                       "TORCHELASTIC_USE_AGENT_STORE"):
                 env.pop(k, None)  # the child does its own env:// rendezvous on the fresh port
             cmd = child or [sys.executable] + cmd_tail
         else:
-            env = base_env
+            env = leg_env
             cmd = child or [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                             "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + cmd_tail
         status, out = run_child(cmd, env, a.leg_timeout)
@@ -656,6 +660,14 @@ def supervisor_main(a):
             if j:
                 lines.append((leg, j))
             print(f"[bench] leg {leg}: {report[leg]}", file=sys.stderr)
+        if leg == "p2p" and a.comm == "auto":
+            # The p2p leg runs the two-loop as ONE persistent kernel whose hand-offs include the xGMI exchange.  If that
+            # leg did not produce a result, the same communicator is tried with a kernel per step before RCCL is.
+            retry = [report.get("p2p", {}).get("iters_per_sec") is None] if rank == 0 else [False]
+            if under_launcher:
+                dist.broadcast_object_list(retry, src=0)
+            if retry[0]:
+                legs.insert(i, "p2p-per-step")
         if i == len(legs) and a.comm == "auto" and not tried_callback:
             # last resort: the host-staged all-reduce through gloo, only if nothing has produced a result
             have = [len(lines)]

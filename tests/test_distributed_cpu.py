@@ -291,6 +291,18 @@ def test_bench_supervisor_survives_a_hung_and_a_failed_leg(launcher):
     assert "timed out" in legs["hang"]["status"] and legs["rccl"]["status"] != "ok" and legs["callback"]["status"] == "ok"
 
 
+def test_bench_supervisor_default_leg_order():
+    """No --comm: p2p (persistent two-loop kernel), then -- because it failed: the test double has no P2P -- the same
+    communicator with a kernel per step, then rccl, and the host-staged callback only because none of them worked."""
+    p = _run_bench(["--leg-timeout", "60"], False)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    legs = json.loads(lines[0])["config"]["legs"]
+    assert list(legs) == ["p2p", "p2p-per-step", "rccl", "callback"]
+    assert [legs[k]["status"] == "ok" for k in legs] == [False, False, False, True]
+
+
 def test_bench_supervisor_reports_failure_when_no_leg_works():
     p = _run_bench(["--leg-timeout", "60", "--comm", "rccl"], False)  # the test double has no RCCL; no fallback when a leg is forced
     assert p.returncode != 0 and not p.stdout.strip()
