@@ -1658,7 +1658,10 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     double* outs2[4] = {ra.out_dn, ra.out_dn + 1, ra.out_dn + 2, ra.out_dn + 3};
     const int rc_p = prep_red(ctx, red, owl ? 4 : 2, outs2, nullptr, 0, &in_kernel_exchange);
     if (rc_p != LBFGS_HIP_OK) return rc_p;
-    const unsigned long long handoffs = (unsigned long long)(ns + (ra.first_dot ? 0 : 1) + (owl ? 1 : 0));
+    // (one hand-off per step -- under OWL-QN the last step's travels after the projection, with four values -- plus one
+    // for the first numerator if it is summed here: the SAME sequence of reductions as the launch-per-step path, so under
+    // P2P ranks whose eligibility differs -- an empty shard, a shard one round larger -- still meet in every exchange)
+    const unsigned long long handoffs = (unsigned long long)(ns + (ra.first_dot ? 0 : 1));
     ctx->red_count += handoffs - 1ull;  // one tag per hand-off (prep_red counted one)
     if (in_kernel_exchange) ctx->p2p_count += handoffs - 1ull;  // ... and one P2P epoch each (prep_red counted one)
     const bool nt = n * sizeof(double) >= ctx->nt_store_threshold_bytes;  // the history vectors are read once per step either way

@@ -555,8 +555,8 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
     static_assert(ER % RES_UNROLL == 0 && ER >= 0 && 4 * ER <= 256, "pairs in AGPRs (ER = 0: everything in LDS)");
     asm volatile("" ::: "a255");  // this kernel owns the whole accumulation register file (the wave gets 512 registers)
     extern __shared__ d2 q_lds[];  // [lds_pairs][BLOCK]
-    __shared__ double lds[3][WAVES];
-    __shared__ double s_tot[3];
+    __shared__ double lds[4][WAVES];
+    __shared__ double s_tot[4];
     __shared__ double s_alpha[RES_MAX_STEPS / 2];
     __shared__ unsigned int s_bits[P2P_MAX_WORLD][MAX_RED][2];  // (p2p_exchange's staging: 4 KiB; unused with one rank)
     constexpr int NG = ER / RES_UNROLL;
@@ -671,6 +671,10 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
             else acc[0] += vt * q_tail;
         }
         if (mode == 2) {
+            // OWL-QN: the last step's sums feed no coefficient -- they travel with the projected direction's sums in ONE
+            // hand-off of four values after the write-out below (the launch-per-step path's last kernel also closes
+            // its four sums in one reduction: ranks that take different paths still exchange the same sequence)
+            if (a.owl) break;
             double t2[2] = {acc[0], acc[1]};
             res_exchange<2>(t2, red, tag, ptag, parity, lds, s_tot, s_bits);
             acc[0] = t2[0];
@@ -688,7 +692,7 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
     // ---- d = q (OWL-QN: projected, with the sums of the projected direction) ; totals
     if (a.owl) {
         const double* pgp = a.step[a.nsteps - 1].v;  // the last step's v is pg
-        const double pre = acc[0];                     // ||d||^2 before the projection (global)
+        const double pre = acc[0];                     // ||d||^2 before the projection (this thread's share)
         acc[1] = 0.0;
         acc[2] = 0.0;
         ResGroups<0, NG, NT, 0>::store_owl(b_first, b_stride, a.d, pgp, ow, acc);
@@ -711,13 +715,13 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
             acc[1] += q_tail * q_tail; acc[2] += pgt * q_tail;
             a.d[a.n - 1] = q_tail;
         }
-        double t2[2] = {acc[1], acc[2]};
-        res_exchange<2>(t2, red, tag, ptag, parity, lds, s_tot, s_bits);
+        double t4[4] = {pre, 0.0, acc[1], acc[2]};  // (the layout of ops.h VMODE 3: slot 1 is unused there too)
+        res_exchange<4>(t4, red, tag, ptag, parity, lds, s_tot, s_bits);
         tag = next_epoch(tag);
         ptag = next_epoch(ptag);
-        acc[0] = pre;
-        acc[1] = t2[0];
-        acc[2] = t2[1];
+        acc[0] = t4[0];
+        acc[1] = t4[2];
+        acc[2] = t4[3];
     } else {
         ResGroups<0, NG, NT, 0>::store(b_first, b_stride, a.d);
         for (uint32_t e = 0; e < EL; ++e) {

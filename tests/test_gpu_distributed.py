@@ -96,6 +96,34 @@ def test_resident_two_loop_with_the_p2p_exchange(world, n, grid, tmp_path, monke
     assert np.max(np.abs(x - ref_x)) <= 1e-9 * max(np.max(np.abs(ref_x)), 1e-12)
 
 
+@pytest.mark.parametrize("case", [
+    dict(name="quadratic3_mixed", n=1000, m=4, iters=15, objective="quadratic"),
+    dict(name="owlqn3_mixed", n=1000, m=5, iters=15, objective="logistic", owl=[0.5, 100, 900]),
+], ids=lambda c: c["name"])
+def test_ranks_may_take_different_two_loop_paths(case, tmp_path, monkeypatch):
+    """Whether a rank runs the two-loop as the persistent resident kernel or as a kernel per step is decided per rank
+    (an EMPTY shard, for one, has nothing to keep on the chip).  Both forms close the same sequence of reductions with
+    the same number of values each -- under OWL-QN too, where the last four sums travel together in either form -- so
+    ranks that decide differently still meet in every P2P exchange.  world = 3 on one GPU, shards of 512, 488 and 0
+    elements: ranks 0 and 1 run the resident kernel (a few workgroups each), rank 2 the kernel-per-step path."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs the GPU")
+    monkeypatch.setenv("LBFGS_WORKER_PRODUCT", "1")
+    monkeypatch.setenv("LBFGS_COMM_KIND", "p2p")
+    monkeypatch.setenv("LBFGS_TEST_EXCLUSIVE_DEVICE", "1")
+    monkeypatch.setenv("LBFGS_HIP_RESIDENT_GRID", "48")
+    outs = run_world(case, 3, tmp_path)
+    ref_rows, ref_x = oracle_rows(case)
+    assert [o["hi"] - o["lo"] for o in outs] == [512, 488, 0]
+    assert outs[0]["resident"] >= 10 and outs[1]["resident"] >= 10 and outs[2]["resident"] == 0
+    assert outs[0]["rows"] == outs[1]["rows"] == outs[2]["rows"]
+    assert len(outs[0]["rows"]) == len(ref_rows)
+    for got, ref in zip(outs[0]["rows"], ref_rows):
+        assert got[:3] == ref[:3]
+        for a, b in zip(got[3:], ref[3:]):
+            assert abs(a - b) <= 1e-9 * max(abs(b), 1e-6), (got, ref)
+
+
 @pytest.mark.parametrize("seed,vector_free", [(3, False), (12, True), (33, False), (41, True)])
 def test_random_configurations_two_processes_p2p(seed, vector_free, tmp_path, monkeypatch):
     """Random configurations sharded over two processes on one GPU with the in-kernel P2P exchange."""
