@@ -1549,10 +1549,10 @@ int lbfgs_hip_two_loop_owlqn(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs
 
 // ---- the two-loop as ONE kernel with the running vector resident in registers + LDS (resident.h) ----------------
 namespace {
-template <int ER>
+template <int ER, bool HYB = false>
 int resident_launch(lbfgs_hip_ctx* ctx, const ResArgs& ra, const RedCtl& red, int grid, size_t lds_bytes, bool nt) {
-    auto kern_nt = two_loop_resident_kernel<ER, true>;
-    auto kern_pl = two_loop_resident_kernel<ER, false>;
+    auto kern_nt = two_loop_resident_kernel<ER, true, HYB>;
+    auto kern_pl = two_loop_resident_kernel<ER, false, HYB>;
     static bool attr_set[2] = {false, false};
     if (!attr_set[nt ? 1 : 0]) {  // more than 64 KiB of dynamic LDS has to be asked for
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(nt ? kern_nt : kern_pl),
@@ -1593,10 +1593,9 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     const uint64_t E = ((n >> 1) + per_round - 1) / per_round;  // 16-byte pairs per thread
     constexpr int ER_MAX = 60;
     // Larger shards: HYBRID -- the first 60 + 36 rounds of every thread stay on the chip, the rest of q lives in `d` and is
-    // streamed by every step as on the kernel-per-step path (resident.h).  Not under OWL-QN (the projection is applied
-    // where the on-chip part is written out; configs with OWL-QN fit the chip).
+    // streamed by every step as on the kernel-per-step path (resident.h).
     const bool hybrid = E > (uint64_t)(ER_MAX + RES_LDS_PAIRS_MAX);
-    if (hybrid && (!ctx->resident_hybrid || owl)) return 0;
+    if (hybrid && !ctx->resident_hybrid) return 0;
     if (E == 0 || (n >> 1) + per_round * 4 >= (1ull << 28)) return 0;
     if (ctx->red_count % 0xFFFFFFFFull + 2ull * (uint64_t)bound + 4ull >= 0xFFFFFFFFull) return 0;  // tag wrap: eager path
     // Rounds 0 .. E-2 are full for every thread, round E-1 is the ragged one.  The register rounds carry no bounds checks,
@@ -1608,10 +1607,10 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     if (ctx->resident_ok < 0) {  // once: can this device hold one such workgroup per CU?
         int nb = 0;
         const size_t lds_max = (size_t)RES_LDS_PAIRS_MAX * BLOCK * sizeof(d2);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(two_loop_resident_kernel<ER_MAX, false>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(two_loop_resident_kernel<ER_MAX, false, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, two_loop_resident_kernel<ER_MAX, false>, BLOCK, lds_max);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, two_loop_resident_kernel<ER_MAX, false, true>, BLOCK, lds_max);
         ctx->resident_ok = (e == hipSuccess && nb >= 1) ? 1 : 0;
         (void)hipGetLastError();
         if (getenv("LBFGS_HIP_VERBOSE"))
@@ -1674,7 +1673,10 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
             case 8: rc = resident_launch<8>(ctx, ra, red, grid, lds_bytes, nt); break;
             case 24: rc = resident_launch<24>(ctx, ra, red, grid, lds_bytes, nt); break;
             case 40: rc = resident_launch<40>(ctx, ra, red, grid, lds_bytes, nt); break;
-            default: rc = resident_launch<ER_MAX>(ctx, ra, red, grid, lds_bytes, nt); break;
+            default:
+                rc = hybrid ? resident_launch<ER_MAX, true>(ctx, ra, red, grid, lds_bytes, nt)
+                            : resident_launch<ER_MAX>(ctx, ra, red, grid, lds_bytes, nt);
+                break;
         }
     }
     if (rc != LBFGS_HIP_OK) return rc;

@@ -308,7 +308,7 @@ struct ResGroups {
             ResGroups<G + 1, NG, NT, MODE>::template init<NEED_FIRST>(p_first, p_stride, gp, sp, acc);
         }
     }
-    // d = project(q) ; acc1 += d.d ; acc2 += pg.d  (OWL-QN: see res_one's note)
+    // d = project(q) ; acc2 += d.d ; acc3 += pg.d  (OWL-QN: see res_one's note)
     static __device__ __forceinline__ void store_owl(const uint32_t p_first, const uint32_t p_stride, double* dp, const double* pgp,
                                                      const ResOwl& ow, double* acc) {
         if constexpr (G < NG) {
@@ -324,12 +324,12 @@ struct ResGroups {
                 const uint32_t o = o0 + (uint32_t)(G * RES_UNROLL + u) * p_stride;
                 const uint64_t gi = ow.gofs + 2ull * (o >> 4);
                 q[u].x = res_project(q[u].x, pg[u].x, gi, ow);
-                acc[1] += q[u].x * q[u].x; acc[2] += pg[u].x * q[u].x;
+                acc[2] += q[u].x * q[u].x; acc[3] += pg[u].x * q[u].x;
                 q[u].y = res_project(q[u].y, pg[u].y, gi + 1, ow);
-                acc[1] += q[u].y * q[u].y; acc[2] += pg[u].y * q[u].y;
+                acc[2] += q[u].y * q[u].y; acc[3] += pg[u].y * q[u].y;
                 st16_at<NT>(dp, o, q[u]);
             }
-            res_pin_sums<2>(acc + 1);
+            res_pin_sums<2>(acc + 2);
             ResGroups<G + 1, NG, NT, MODE>::store_owl(p_first, p_stride, dp, pgp, ow, acc);
         }
     }
@@ -463,6 +463,30 @@ __device__ __forceinline__ void res_step(ResWin& w, d2* q_lds, const ResPos& ps,
 // In the FIRST step the source of q is g (negated on the fly: the kernel-per-step path's fused first step), so `d` is
 // never initialised by a pass of its own.  Loads of the next group of RES_UNROLL pairs are in flight while one is
 // worked on (2 x 12 loads of 16 bytes per thread).
+// one pair of a hybrid round.  MODE 3: the last step under OWL-QN, projection included (ops.h VMODE 3, element by element:
+// acc0 += q.q before the projection -- lbfgs.rs:543 precedes :554 --, then acc2 += q.q and acc3 += pg.q after it)
+template <int MODE>
+__device__ __forceinline__ void res_hbm_one(d2& q, const d2 uu, const d2 vv, const double c, const double gamma, double* acc,
+                                            const ResOwl& ow, const uint32_t pair) {
+    if constexpr (MODE == 3) {
+        const uint64_t gi = ow.gofs + 2ull * pair;
+        q.x = q.x + c * uu.x;
+        q.y = q.y + c * uu.y;
+        acc[0] += q.x * q.x;
+        q.x = res_project(q.x, vv.x, gi, ow);
+        acc[2] += q.x * q.x; acc[3] += vv.x * q.x;
+        acc[0] += q.y * q.y;
+        q.y = res_project(q.y, vv.y, gi + 1, ow);
+        acc[2] += q.y * q.y; acc[3] += vv.y * q.y;
+    } else {
+        res_one<MODE>(q, uu, vv, c, gamma, acc);
+    }
+}
+template <int MODE>
+__device__ __forceinline__ void res_hbm_pin(double* acc) {
+    if constexpr (MODE == 3) { res_pin(acc[0]); res_pin(acc[2]); res_pin(acc[3]); }
+    else res_pin_sums<(MODE == 2 ? 2 : 1)>(acc);
+}
 struct ResHbmGroup {
     d2 q[RES_HBM_UNROLL], u[RES_HBM_UNROLL], v[RES_HBM_UNROLL];
 };
@@ -482,17 +506,18 @@ __device__ __forceinline__ void res_hbm_fetch(ResHbmGroup& g, const uint32_t e, 
 }
 template <bool NT, int MODE>
 __device__ __forceinline__ void res_hbm_work(ResHbmGroup& g, const uint32_t e, const ResPos& ps, const double qsign, double* d,
-                                             const double c, const double gamma, double* acc) {
+                                             const double c, const double gamma, double* acc, const ResOwl& ow) {
     const uint32_t p0 = res_opaque(ps.p_first + e * ps.p_stride);
 #pragma unroll
     for (int k = 0; k < RES_HBM_UNROLL; ++k) {
         d2 q = g.q[k];
         q.x = q.x * qsign;  // +1.0, or -1.0 in the first step (q = -g: exact)
         q.y = q.y * qsign;
-        res_one<MODE>(q, g.u[k], g.v[k], c, gamma, acc);
-        st16<NT>(d, p0 + (uint32_t)k * ps.p_stride, q);
+        const uint32_t p = p0 + (uint32_t)k * ps.p_stride;
+        res_hbm_one<MODE>(q, g.u[k], g.v[k], c, gamma, acc, ow, p);
+        st16<NT>(d, p, q);
     }
-    res_pin_sums<(MODE == 2 ? 2 : 1)>(acc);
+    res_hbm_pin<MODE>(acc);
 }
 // rounds [e_begin, e_end) of this thread; every round before the shard's last one is full for every thread, so groups of
 // RES_HBM_UNROLL rounds below `e_full` run without checks and the (at most RES_HBM_UNROLL) rounds after them one at a
@@ -500,7 +525,7 @@ __device__ __forceinline__ void res_hbm_work(ResHbmGroup& g, const uint32_t e, c
 template <bool NT, int MODE>
 __device__ __forceinline__ void res_hbm_tail(const uint32_t e_full, const uint32_t e_end, const ResPos& ps, const double* qsrc,
                                              const double qsign, double* d, const double* up, const double* vp, const double c,
-                                             const double gamma, double* acc) {
+                                             const double gamma, double* acc, const ResOwl& ow) {
     for (uint32_t e = e_full; e < e_end; ++e) {  // the last few rounds, the ragged one among them
         const uint32_t p = ps.p_first + e * ps.p_stride;
         if (p < ps.n2) {
@@ -510,7 +535,7 @@ __device__ __forceinline__ void res_hbm_tail(const uint32_t e_full, const uint32
             if constexpr (MODE != 1) vv = ld16<NT>(vp, p);
             q.x = q.x * qsign;
             q.y = q.y * qsign;
-            res_one<MODE>(q, uu, vv, c, gamma, acc);
+            res_hbm_one<MODE>(q, uu, vv, c, gamma, acc, ow, p);
             st16<NT>(d, p, q);
         }
     }
@@ -518,12 +543,12 @@ __device__ __forceinline__ void res_hbm_tail(const uint32_t e_full, const uint32
 template <bool NT, int MODE>
 __device__ __forceinline__ void res_step_hbm(const uint32_t e_begin, const uint32_t e_end, const bool rev, const ResPos& ps,
                                              const double* qsrc, const double qsign, double* d, const double* up, const double* vp,
-                                             const double c, const double gamma, double* acc) {
+                                             const double c, const double gamma, double* acc, const ResOwl& ow) {
     if (e_begin >= e_end) return;
     asm volatile("" ::: "memory");
     const uint32_t ngroups = (e_end - 1 - e_begin) / RES_HBM_UNROLL;  // groups made of full rounds only
     const uint32_t e_full = e_begin + ngroups * RES_HBM_UNROLL;
-    if (rev) res_hbm_tail<NT, MODE>(e_full, e_end, ps, qsrc, qsign, d, up, vp, c, gamma, acc);
+    if (rev) res_hbm_tail<NT, MODE>(e_full, e_end, ps, qsrc, qsign, d, up, vp, c, gamma, acc, ow);
     if (ngroups > 0) {
         ResHbmGroup ga, gb;  // two buffers, used alternately: the next group's 12 loads fly while one is worked on
         const uint32_t last = ngroups - 1;
@@ -536,20 +561,21 @@ __device__ __forceinline__ void res_step_hbm(const uint32_t e_begin, const uint3
         for (;;) {
             res_hbm_fetch<NT, MODE != 1>(gb, first_round(i + 1), ps, qsrc, up, vp);
             asm volatile("" ::: "memory");
-            res_hbm_work<NT, MODE>(ga, first_round(i), ps, qsign, d, c, gamma, acc);
+            res_hbm_work<NT, MODE>(ga, first_round(i), ps, qsign, d, c, gamma, acc, ow);
             if (++i >= ngroups) break;
             res_hbm_fetch<NT, MODE != 1>(ga, first_round(i + 1), ps, qsrc, up, vp);
             asm volatile("" ::: "memory");
-            res_hbm_work<NT, MODE>(gb, first_round(i), ps, qsign, d, c, gamma, acc);
+            res_hbm_work<NT, MODE>(gb, first_round(i), ps, qsign, d, c, gamma, acc, ow);
             if (++i >= ngroups) break;
         }
     }
-    if (!rev) res_hbm_tail<NT, MODE>(e_full, e_end, ps, qsrc, qsign, d, up, vp, c, gamma, acc);
+    if (!rev) res_hbm_tail<NT, MODE>(e_full, e_end, ps, qsrc, qsign, d, up, vp, c, gamma, acc, ow);
     asm volatile("" ::: "memory");
 }
 
 // ER = pairs per thread held in (accumulation) registers: a multiple of RES_UNROLL, at most 60.
-template <int ER, bool NT>
+// HYB: the shard is larger than the chip (a.hbm_pairs > 0; ER = 60 only): the hybrid rounds are compiled in.
+template <int ER, bool NT, bool HYB>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
     static_assert(ER % RES_UNROLL == 0 && ER >= 0 && 4 * ER <= 256, "pairs in AGPRs (ER = 0: everything in LDS)");
@@ -570,7 +596,7 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
     const bool tail_owner = (a.n & 1) && B == G - 1 && tid == 0;  // odd n: the last element, kept by one thread
     double q_tail = 0.0;
 
-    double acc[3] = {0.0, 0.0, 0.0};
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};  // (acc2, acc3: the projected direction's sums, OWL-QN's last step and write-out only)
     const ResOwl ow{a.gofs, a.owl_start, a.owl_end};
     // ---- q = -g ; optionally the first numerator s.(-g)
     const bool need_first = a.first_dot == nullptr;
@@ -594,8 +620,8 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         }
     }
     // hybrid rounds: q stays in HBM (the first step reads it from g); only the first numerator needs them here
-    const uint32_t EH0 = ER + EL, EH1 = ER + EL + a.hbm_pairs;
-    if (need_first) {
+    const uint32_t EH0 = ER + EL, EH1 = ER + EL + (HYB ? a.hbm_pairs : 0u);
+    if (HYB && need_first) {
         for (uint32_t e = EH0; e < EH1; ++e) {
             const uint32_t p = p_first + e * p_stride;
             if (p < n2) {
@@ -648,19 +674,23 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         acc[0] = 0.0;
         acc[1] = 0.0;
         acc[2] = 0.0;
+        acc[3] = 0.0;
         const int mode = st.last ? 2 : (st.v == nullptr ? 1 : 0);
         const double* qsrc = si == 0 ? a.g : a.d;  // (hybrid rounds only)
         const double qsign = si == 0 ? -1.0 : 1.0;
         const bool rev = LH_RES_HBM_ALTERNATE && (si & 1);  // (see LH_RES_HBM_ALTERNATE)
         if (mode == 0) {
             res_step<ER, NT, 0>(win, q_lds, ps, st.u, st.v, c, gamma, acc);
-            res_step_hbm<NT, 0>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc);
+            if constexpr (HYB) res_step_hbm<NT, 0>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc, ow);
         } else if (mode == 1) {
             res_step<ER, NT, 1>(win, q_lds, ps, st.u, st.u, c, gamma, acc);
-            res_step_hbm<NT, 1>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.u, c, gamma, acc);
+            if constexpr (HYB) res_step_hbm<NT, 1>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.u, c, gamma, acc, ow);
         } else {
             res_step<ER, NT, 2>(win, q_lds, ps, st.u, st.v, c, gamma, acc);
-            res_step_hbm<NT, 2>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc);
+            if constexpr (HYB) {
+                if (a.owl) res_step_hbm<NT, 3>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc, ow);  // (projected here)
+                else res_step_hbm<NT, 2>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc, ow);
+            }
         }
         if (si + 1 < a.nsteps) prefetch(si + 1);
         if (tail_owner) {
@@ -692,9 +722,7 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
     // ---- d = q (OWL-QN: projected, with the sums of the projected direction) ; totals
     if (a.owl) {
         const double* pgp = a.step[a.nsteps - 1].v;  // the last step's v is pg
-        const double pre = acc[0];                     // ||d||^2 before the projection (this thread's share)
-        acc[1] = 0.0;
-        acc[2] = 0.0;
+        // (acc0: ||d||^2 before the projection, complete; acc2, acc3: the hybrid rounds' share so far, 0 otherwise)
         ResGroups<0, NG, NT, 0>::store_owl(b_first, b_stride, a.d, pgp, ow, acc);
         for (uint32_t e = 0; e < EL; ++e) {
             const uint32_t p = p_first + (ER + e) * p_stride;
@@ -703,19 +731,19 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
                 d2 q = q_lds[(size_t)e * BLOCK + tid];
                 const uint64_t gi = a.gofs + 2ull * p;
                 q.x = res_project(q.x, pg.x, gi, ow);
-                acc[1] += q.x * q.x; acc[2] += pg.x * q.x;
+                acc[2] += q.x * q.x; acc[3] += pg.x * q.x;
                 q.y = res_project(q.y, pg.y, gi + 1, ow);
-                acc[1] += q.y * q.y; acc[2] += pg.y * q.y;
+                acc[2] += q.y * q.y; acc[3] += pg.y * q.y;
                 st16<NT>(a.d, p, q);
             }
         }
         if (tail_owner) {
             const double pgt = pgp[a.n - 1];
             q_tail = res_project(q_tail, pgt, a.gofs + a.n - 1, ow);
-            acc[1] += q_tail * q_tail; acc[2] += pgt * q_tail;
+            acc[2] += q_tail * q_tail; acc[3] += pgt * q_tail;
             a.d[a.n - 1] = q_tail;
         }
-        double t4[4] = {pre, 0.0, acc[1], acc[2]};  // (the layout of ops.h VMODE 3: slot 1 is unused there too)
+        double t4[4] = {acc[0], 0.0, acc[2], acc[3]};  // (the layout of ops.h VMODE 3: slot 1 is unused there too)
         res_exchange<4>(t4, red, tag, ptag, parity, lds, s_tot, s_bits);
         tag = next_epoch(tag);
         ptag = next_epoch(ptag);

@@ -171,9 +171,10 @@ def test_resident_kernels_own_their_accumulation_registers(libs):
         _build.build_hip(force=True)
     txt = open(_build.RESOURCES).read()
     audit = re.findall(r"^agpr-audit: (\S+) (\d+)$", txt, re.M)
-    assert len(audit) == 10, audit                                  # 5 register budgets x 2 cache-hint variants
+    assert len(audit) == 12, audit          # (5 register budgets + the hybrid form of the largest) x 2 cache-hint variants
     assert all(int(n) == 0 for _, n in audit), audit
     for sym, _ in audit:
         blk = txt[txt.index("Function Name: " + sym):]
         vgprs = int(re.search(r" VGPRs: (\d+)", blk).group(1))
-        assert vgprs <= 244, (sym, vgprs)   # (the audit above is the guarantee; this keeps some distance from the line)
+        hybrid = "ELb1EEEv" in sym          # two_loop_resident_kernel<ER, NT, HYB = true>
+        assert vgprs <= (244 if hybrid else 200), (sym, vgprs)   # (the audit above is the guarantee; this keeps a distance)

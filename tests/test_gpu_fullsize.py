@@ -115,7 +115,8 @@ def test_streaming_hint_kernels_equal_plain_kernels(monkeypatch):
             assert np.array_equal(a, b)
 
 
-def test_owlqn_properties_at_config3_size():
+@pytest.mark.parametrize("n_default", [10_000_000, 20_000_001], ids=["config3", "twice_config3_hybrid_two_loop"])
+def test_owlqn_properties_at_config3_size(n_default):
     """BASELINE.json config 3 at its own size (OWL-QN, L1 logistic, n = 1e7, m = 6, c = 0.5), through size-independent
     properties on the device:
       (a) the fused trial kernel (projected line step + evaluate + x1norm + pseudo-gradient + g.d in one pass,
@@ -124,8 +125,10 @@ def test_owlqn_properties_at_config3_size():
       (b) two_loop_owlqn (orthant projection folded into the last step) == two_loop + constrain_direction
           (orthantwise.rs:140-161): d bitwise, ||d||^2 and pg.d to 1e-12;
       (c) bitwise determinism of both;
-      (d) coordinates whose |g| <= c at x = 0 stay exactly 0 (the reason config 3 exercises the projection)."""
-    n, m, c = int(os.environ.get("LBFGS_TEST_CONFIG3_N", 10_000_000)), 6, 0.5
+      (d) coordinates whose |g| <= c at x = 0 stay exactly 0 (the reason config 3 exercises the projection).
+    Also at twice that size (odd n), where the two-loop is the HYBRID persistent kernel: part of q on the chip, the rest
+    streamed, the projection applied in both parts."""
+    n, m, c = int(os.environ.get("LBFGS_TEST_CONFIG3_N", n_default)), 6, 0.5
     q = objectives.Logistic()
     with R.Context(n) as ctx:
         hist = H.History(ctx, m)

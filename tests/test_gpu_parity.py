@@ -1014,11 +1014,12 @@ def test_two_loop_resident_kernel_vs_launch_per_step(n, m, k, end, monkeypatch):
             ne3 = hist.two_loop_owlqn(d, g, k, end, n // 5, n - n // 7, 7, 8, 40)
             four = ctx.scalars(40, 4)
             res.append((ne3, d.to_numpy(), np.array([four[0], four[2], four[3]]), hist.scalars()[1]))
-            assert four[2] <= four[0]                      # the projection only removes components
+            # the projection only removes components (to rounding: the hybrid form adds the two sums up in different orders)
+            assert four[2] <= four[0] * (1.0 + 1e-14)
             # the path under test really ran.  Shards larger than the chip (> 96 pairs per thread) run HYBRID: the first
-            # 96 rounds of q on the chip, the rest streamed from d -- except under OWL-QN, which takes the per-step path
+            # 96 rounds of q on the chip, the rest streamed from d
             hybrid = (n >> 1) > 96 * 65536
-            assert ctx.resident_two_loops() == (0 if mode == "0" else 3 if hybrid else 4)
+            assert ctx.resident_two_loops() == (0 if mode == "0" else 4)
             if mode == "1":
                 assert ctx.resident_elements() == (2 * 96 * 65536 if hybrid else n)
             out[mode] = res

@@ -46,7 +46,7 @@ def short(name):
     m = re.search(r"stream_kernel<lh::(.*?)(, \d+, \d+u, \d+u, \d+, \d+(, (true|false))?)?>\(", name)
     if m:
         return "stream_kernel<" + m.group(1) + ">"
-    m = re.search(r"(two_loop_resident_kernel<\d+, (true|false)>)", name)
+    m = re.search(r"(two_loop_resident_kernel<\d+, (true|false)(, (true|false))?>)", name)
     return m.group(1) if m else name[:60]
 
 
