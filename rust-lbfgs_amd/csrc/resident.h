@@ -181,7 +181,8 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
 // Register rounds are FULL by construction (the host picks ER <= E-1), so they carry no bounds checks at all.
 // Under OWL-QN the last step is MODE 2 with v = pg (acc0 = ||d||^2 BEFORE the projection: lbfgs.rs:543 precedes :554); the
 // projection d_i = 0 where signum(d_i) != signum(-pg_i) on [start, end) (orthantwise.rs:140-161) is applied where d is
-// written out, which sums ||d||^2 and pg.d of the projected direction (one more hand-off, pg read once more).
+// written out, which sums ||d||^2 and pg.d of the projected direction (pg read once more); all of these sums leave in
+// the kernel's last hand-off, four values together.
 struct ResOwl {
     uint64_t gofs, start, end;
 };
