@@ -230,6 +230,24 @@ def _random_history(n, m, seed):
                                        (70001, 3, 2, 1), (513, 1, 5, 0), (262145, 10, 11, 0)])
 def test_two_loop_fused_vs_oracle(n, m, k, end, two_loop_path):
     """lbfgs.rs:569-604 on identical inputs: direction within 1e-10 relative, alpha within 1e-10."""
+    _check_two_loop_vs_oracle(n, m, k, end, two_loop_path)
+
+
+@pytest.mark.parametrize("n,m,k,end,grid", [(60_001, 5, 9, 2, 1), (131_072, 3, 2, 1, 1), (250_000, 8, 8, 7, 2),
+                                            (98_306, 1, 4, 0, 1), (300_007, 6, 30, 4, 3), (197_000, 10, 3, 2, 2)])
+def test_hybrid_two_loop_vs_oracle(n, m, k, end, grid, monkeypatch):
+    """The HYBRID form of the persistent two-loop kernel (resident.h: the first 96 rounds of every thread on the chip,
+    the rest of q streamed from d) against the oracle at sizes the oracle handles in no time: one to three workgroups
+    instead of 256, so that a vector of 1e5 elements already exceeds "the chip".  Ragged and odd sizes, bound < m,
+    bound = 1 (the transition is the first step: q read from g), the first numerator summed in the kernel and handed in."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("a form of the HIP kernels")
+    monkeypatch.setenv("LBFGS_HIP_RESIDENT", "1")
+    monkeypatch.setenv("LBFGS_HIP_RESIDENT_GRID", str(grid))
+    _check_two_loop_vs_oracle(n, m, k, end, "resident", expect_resident_elements=2 * 96 * 256 * grid)
+
+
+def _check_two_loop_vs_oracle(n, m, k, end, two_loop_path, expect_resident_elements=None):
     S, Y, ys = _random_history(n, m, 100 + n + m)
     g = rnd(n, 21)
     gamma_num, gamma_den = ys[end], O.vecdot(Y[end], Y[end])
@@ -271,6 +289,8 @@ def test_two_loop_fused_vs_oracle(n, m, k, end, two_loop_path):
         assert hist.two_loop_unfused(d, k, end, 7, 8) == end_o
         assert rel(d.to_numpy(), d_o) <= RTOL
         assert rel(d.to_numpy(), d_f) <= 1e-12
+        if expect_resident_elements is not None:
+            assert ctx.resident_two_loops() >= 2 and ctx.resident_elements() == expect_resident_elements
         hist.free(); gv.free(); d.free()
 
 
@@ -977,6 +997,17 @@ def test_two_loop_launch_forms_are_bitwise_equal(knob, owl, monkeypatch):
                                12_582_913, 12_582_915, 13_000_001, 20_000_000])
 @pytest.mark.parametrize("m,k,end", [(10, 37, 3), (10, 4, 3), (6, 1, 0), (7, 7, 6)])
 def test_two_loop_resident_kernel_vs_launch_per_step(n, m, k, end, monkeypatch):
+    _resident_vs_per_step(n, m, k, end, monkeypatch)
+
+
+@pytest.mark.parametrize("n,m,k,end,grid", [(150_001, 6, 11, 5, 1), (260_000, 4, 3, 2, 2), (99_999, 2, 1, 0, 1)])
+def test_hybrid_two_loop_vs_launch_per_step_small_grids(n, m, k, end, grid, monkeypatch):
+    """The same comparison (plain, first numerator handed in, OWL-QN) for the HYBRID form on one or two workgroups."""
+    monkeypatch.setenv("LBFGS_HIP_RESIDENT_GRID", str(grid))
+    _resident_vs_per_step(n, m, k, end, monkeypatch, chip_pairs=96 * 256 * grid)
+
+
+def _resident_vs_per_step(n, m, k, end, monkeypatch, chip_pairs=96 * 65536):
     """The recursion as ONE kernel with the running vector resident in registers + LDS (resident.h) against the
     launch-per-step path on the same device data: direction within 1e-12 of each other (only the order of the dot
     products' partial sums differs), the two sums it leaves for the host, the alphas, the new ring position; with the
@@ -1018,10 +1049,10 @@ def test_two_loop_resident_kernel_vs_launch_per_step(n, m, k, end, monkeypatch):
             assert four[2] <= four[0] * (1.0 + 1e-14)
             # the path under test really ran.  Shards larger than the chip (> 96 pairs per thread) run HYBRID: the first
             # 96 rounds of q on the chip, the rest streamed from d
-            hybrid = (n >> 1) > 96 * 65536
+            hybrid = (n >> 1) > chip_pairs
             assert ctx.resident_two_loops() == (0 if mode == "0" else 4)
             if mode == "1":
-                assert ctx.resident_elements() == (2 * 96 * 65536 if hybrid else n)
+                assert ctx.resident_elements() == (2 * chip_pairs if hybrid else n)
             out[mode] = res
             hist.free()
             for v in (g, d, tmp):
