@@ -86,6 +86,9 @@ def parse(argv=None):
                     help="lbfgs_evaluator.fuse_line_eval: 2 = trials write no vectors (default), 1 = every trial writes x and g, "
                          "0 = separate passes")
     ap.add_argument("--device", type=int, default=-1, help="force a device index (testing: several ranks on one GPU)")
+    ap.add_argument("--exclusive-device", type=int, default=-1, choices=[-1, 0, 1],
+                    help="tell the communicator that every rank owns its GPU (-1: yes unless --device is given); experiments "
+                         "with several ranks on ONE GPU pass 1 together with LBFGS_HIP_RESIDENT_GRID = CUs / ranks")
     ap.add_argument("--_rank-mode", dest="rank_mode", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -232,7 +235,7 @@ def make_context(env, kind):
     ok, ctx = 1.0, None
     try:
         # one rank per GPU (the driver's launch) unless --device forces several ranks onto one card (tests)
-        ctx = sharded_context(a.n, device=env.dev, kind=kind, exclusive_device=a.device < 0)
+        ctx = sharded_context(a.n, device=env.dev, kind=kind, exclusive_device=(a.device < 0) if a.exclusive_device < 0 else bool(a.exclusive_device))
         # known-answer reductions through the real code path before trusting it
         tri = env.world * (env.world + 1) / 2.0
         for it in range(16):
@@ -551,6 +554,8 @@ def passthrough(a, leg):
         args += ["--grid", str(a.grid)]
     if a.device >= 0:
         args += ["--device", str(a.device)]
+    if a.exclusive_device >= 0:
+        args += ["--exclusive-device", str(a.exclusive_device)]
     return args
 
 
