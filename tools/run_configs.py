@@ -45,6 +45,8 @@ def gpu_run(n, builder, evaluate, warm, timed, m):
     dt = time.perf_counter() - t0
     ntl, ms_tl = ctx.prof_read(_ffi.K_TWOLOOP_ALL)
     nst, ms_st = ctx.prof_read(_ffi.K_TWOLOOP_STEP)
+    nres, _ = ctx.prof_read(_ffi.K_TWOLOOP_RESIDENT)
+    n_res = min(ctx.resident_elements(), n) if nres else 0
     rep = st.report()
     st.close()
     ctx.close()
@@ -52,7 +54,11 @@ def gpu_run(n, builder, evaluate, warm, timed, m):
                fx=rep.fx, gnorm=rep.gnorm)
     if ntl:
         t = ms_tl / ntl
-        out.update(two_loop_ms=t, two_loop_GBps=64.0 * m * n / (t * 1e-3) / 1e9, two_loop_frac=64.0 * m * n / (t * 1e-3) / 8e12)
+        # bytes the recursion has to move: 8m passes of an n-vector with a kernel per step; the persistent kernel
+        # keeps n_res elements of the running vector on the chip, which cost 4m+1 passes instead
+        nbytes = 8.0 * ((4 * m + 1) * n_res + 8 * m * (n - n_res)) if n_res else 64.0 * m * n
+        out.update(two_loop_ms=t, two_loop_bytes=nbytes, two_loop_GBps=nbytes / (t * 1e-3) / 1e9,
+                   two_loop_frac=nbytes / (t * 1e-3) / 8e12, two_loop_resident_elements=n_res)
     if nst:
         t = ms_st / nst
         out.update(step_kernel_ms=t, step_kernel_GBps=32.0 * n / (t * 1e-3) / 1e9)
