@@ -42,6 +42,9 @@ constexpr int RES_UNROLL = 4;          // pairs whose loads are issued together 
 #ifndef LH_RES_AHEAD
 #define LH_RES_AHEAD 1
 #endif
+#ifndef LH_RES_P2P_ONE_HOP
+#define LH_RES_P2P_ONE_HOP 0  // several ranks: every workgroup reads the ranks' totals from the mailbox itself (no local broadcast hop)
+#endif
 #ifndef LH_RES_HBM_ALTERNATE
 #define LH_RES_HBM_ALTERNATE 0  // hybrid: odd steps sweep the HBM rounds from the top down (what a step wrote last, the next reads first)
 #endif
@@ -140,6 +143,12 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
             for (int k = 0; k < NS; ++k) s_tot[k] = tot[k];
         }
         __syncthreads();
+#if LH_RES_P2P_ONE_HOP
+        if (multi) p2p_publish(red.p2p, p2p_tag, s_tot, NS);  // (workgroup 0 only) this rank's totals to every rank's mailbox
+    }
+    // every workgroup of every rank reads the P ranks' totals from its rank's mailbox and adds them up in rank order
+    if (multi) p2p_collect(red.p2p, p2p_tag, s_tot, NS, s_bits, red.timeout_ticks);
+#else
         if (multi) {  // (workgroup 0 only) this rank's totals -> the global totals, then tell the other workgroups
             p2p_exchange(red.p2p, p2p_tag, s_tot, NS, s_bits);
             if (threadIdx.x == 0) {
@@ -170,6 +179,7 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
         }
         __syncthreads();
     }
+#endif
 #pragma unroll
     for (int k = 0; k < NS; ++k) acc[k] = s_tot[k];
     __syncthreads();  // s_tot and lds are free again

@@ -119,27 +119,34 @@ __device__ __forceinline__ size_t p2p_word(unsigned epoch, int src_rank, int k, 
 // `epoch` = this exchange's sequence number (DevCounters::p2p_epoch as read in the kernel's prologue).  It is a separate
 // argument on purpose: a local copy of P2PCtl with the epoch patched in would be indexed dynamically (mbox[p]) and
 // land in scratch memory -- 176 bytes per lane and +12 us of dispatch cost on EVERY reducing kernel (measured).
-__device__ __forceinline__ void p2p_exchange(const P2PCtl& c, const unsigned int epoch, double* vals, int count,
-                                             unsigned int (*bits)[MAX_RED][2]) {
+// The two halves of the exchange (resident.h calls them from different workgroups):
+//   p2p_publish  store this rank's vals[0..count) into every rank's mailbox (own included); the first wave does it
+//   p2p_collect  wait for all ranks' values of this epoch in the OWN mailbox and add them up in rank order -> vals
+__device__ __forceinline__ void p2p_publish(const P2PCtl& c, const unsigned int epoch, const double* vals, int count) {
     const int per_rank = count * 2, total = c.world * per_rank;
     if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        for (int i = lane; i < total; i += 64) {  // publish to every peer (own mailbox included)
+        for (int i = threadIdx.x; i < total; i += 64) {
             const int p = i / per_rank, k = (i % per_rank) >> 1, h = i & 1;
             const unsigned long long b = (unsigned long long)__double_as_longlong(vals[k]);
             const unsigned int data = h ? (unsigned int)(b >> 32) : (unsigned int)b;
             __hip_atomic_store(c.mbox[p] + p2p_word(epoch, c.rank, k, h), ((unsigned long long)epoch << 32) | data,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+    }
+}
+__device__ __forceinline__ void p2p_collect(const P2PCtl& c, const unsigned int epoch, double* vals, int count,
+                                            unsigned int (*bits)[MAX_RED][2], const unsigned long long extra_ticks = 0) {
+    const int per_rank = count * 2, total = c.world * per_rank;
+    if (threadIdx.x < 64) {
         const long long t0 = wall_clock64();
-        for (int i = lane; i < total; i += 64) {  // collect what rank r stored for me
+        for (int i = threadIdx.x; i < total; i += 64) {  // what rank r stored for me
             const int r = i / per_rank, k = (i % per_rank) >> 1, h = i & 1;
             const unsigned long long* src = c.mbox[c.rank] + p2p_word(epoch, r, k, h);
             unsigned long long g;
             for (;;) {
                 g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if ((unsigned int)(g >> 32) == epoch) break;
-                if ((unsigned long long)(wall_clock64() - t0) > c.timeout_ticks) {
+                if ((unsigned long long)(wall_clock64() - t0) > c.timeout_ticks + extra_ticks) {
                     atomicExch(c.err, 1u);
                     break;
                 }
@@ -158,6 +165,11 @@ __device__ __forceinline__ void p2p_exchange(const P2PCtl& c, const unsigned int
         vals[threadIdx.x] = sum;
     }
     __syncthreads();
+}
+__device__ __forceinline__ void p2p_exchange(const P2PCtl& c, const unsigned int epoch, double* vals, int count,
+                                             unsigned int (*bits)[MAX_RED][2]) {
+    p2p_publish(c, epoch, vals, count);
+    p2p_collect(c, epoch, vals, count, bits);
 }
 
 // ---- agent-scope accesses for the cross-workgroup hand-off -------------------------------
