@@ -161,6 +161,7 @@ struct lbfgs_hip_ctx {
     struct LjCells* lj_cells = nullptr;   // LJ_CELLS: the rebuildable neighbour structure (allocated on demand)
     unsigned long long* gran = nullptr;   // tagged partial granules [MAX_RED][MAX_GRID][2] (stream.h)
     bool p2p_exclusive = false;           // lbfgs_hip_comm.exclusive_device: no other rank shares this GPU
+    unsigned int resident_attr_mask = 0;  // which resident kernels have had their dynamic-LDS limit raised on this device
     int resident_hybrid = 1;              // LBFGS_HIP_RESIDENT_HYBRID=0: shards that do not fit the chip take the kernel-per-step path
     uint64_t resident_elements = 0;       // elements of q the last resident launch kept on the chip (all of them unless hybrid)
     int resident_grid = 0;                // LBFGS_HIP_RESIDENT_GRID: workgroups of the resident kernel (0 = one per CU); tests
@@ -1553,11 +1554,12 @@ template <int ER, bool HYB = false>
 int resident_launch(lbfgs_hip_ctx* ctx, const ResArgs& ra, const RedCtl& red, int grid, size_t lds_bytes, bool nt) {
     auto kern_nt = two_loop_resident_kernel<ER, true, HYB>;
     auto kern_pl = two_loop_resident_kernel<ER, false, HYB>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[nt ? 1 : 0]) {  // more than 64 KiB of dynamic LDS has to be asked for
+    // more than 64 KiB of dynamic LDS has to be asked for, once per kernel AND device: remembered in the context
+    const unsigned int bit = 1u << ((ER / 8 + (HYB ? 8 : 0)) * 2 + (nt ? 1 : 0));  // ER/8 in {0, 1, 3, 5, 7}
+    if (!(ctx->resident_attr_mask & bit)) {
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(nt ? kern_nt : kern_pl),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, RES_LDS_PAIRS_MAX * BLOCK * (int)sizeof(d2)));
-        attr_set[nt ? 1 : 0] = true;
+        ctx->resident_attr_mask |= bit;
     }
     if (nt) hipLaunchKernelGGL(kern_nt, dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, ra, red);
     else hipLaunchKernelGGL(kern_pl, dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, ra, red);

@@ -288,6 +288,7 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_gather_kernel(const double* __
     }
 }
 
+constexpr int LJ_BUILD_UNROLL = 8;
 // Verlet list of atom i = sorted[t]: every j != i with |x_i - x_j| < rl, in the order (27 cells: z, y, x ascending; atoms
 // of a cell ascending).  One thread per atom IN CELL ORDER: the threads of a wave sit in the same few cells and walk the
 // same contiguous candidate segments of xs (the three cells of a row are adjacent in memory).
@@ -315,7 +316,24 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_build_kernel(const double* __r
                 if (ay < 0 || ay >= gr.ny) continue;
                 const int row = (az * gr.ny + ay) * gr.nx;
                 const int32_t u1 = starts[row + ax1 + 1];
-                for (int32_t u = starts[row + ax0]; u < u1; ++u) {
+                int32_t u = starts[row + ax0];
+                // LJ_BUILD_UNROLL candidates at a time: their positions are loaded together and tested in order
+                for (; u + LJ_BUILD_UNROLL <= u1; u += LJ_BUILD_UNROLL) {
+                    double px[LJ_BUILD_UNROLL], py[LJ_BUILD_UNROLL], pz[LJ_BUILD_UNROLL];
+#pragma unroll
+                    for (int w = 0; w < LJ_BUILD_UNROLL; ++w) {
+                        px[w] = xs[3 * (size_t)(u + w)]; py[w] = xs[3 * (size_t)(u + w) + 1]; pz[w] = xs[3 * (size_t)(u + w) + 2];
+                    }
+#pragma unroll
+                    for (int w = 0; w < LJ_BUILD_UNROLL; ++w) {
+                        const double dx = xi - px[w], dyy = yi - py[w], dzz = zi - pz[w];
+                        if (dx * dx + dyy * dyy + dzz * dzz < rl2 && (uint32_t)(u + w) != t) {
+                            if (k < max_nbr) nbr[(size_t)k * natoms + i] = sorted[u + w];
+                            ++k;
+                        }
+                    }
+                }
+                for (; u < u1; ++u) {
                     const double dx = xi - xs[3 * (size_t)u], dyy = yi - xs[3 * (size_t)u + 1], dzz = zi - xs[3 * (size_t)u + 2];
                     if (dx * dx + dyy * dyy + dzz * dzz < rl2 && (uint32_t)u != t) {
                         if (k < max_nbr) nbr[(size_t)k * natoms + i] = sorted[u];
@@ -352,10 +370,22 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_eval_kernel(const double* __re
         }
         double fx = 0.0, fy = 0.0, fz = 0.0;
         const uint32_t n4 = (uint32_t)cnt[i];
+        int32_t jn[4] = {-1, -1, -1, -1};  // the NEXT group's four list entries: loaded one group ahead of the gathers they feed
+        if (n4 > 0) {
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) jn[u] = nbr[(size_t)u * natoms + i];
+        }
         for (uint32_t k0 = 0; k0 < n4; k0 += 4) {
+            int32_t jc[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) jc[u] = jn[u];
+            if (k0 + 4 < n4) {
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) jn[u] = nbr[(size_t)(k0 + 4 + u) * natoms + i];
+            }
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) {  // four gathers in flight; an empty slot or a pair beyond rc adds selected zeros
-                const int32_t j = nbr[(size_t)(k0 + u) * natoms + i];
+                const int32_t j = jc[u];
                 const size_t jj = (j < 0) ? (size_t)i : (size_t)j;
                 const double dx = xi - x[3 * jj], dy = yi - x[3 * jj + 1], dz = zi - x[3 * jj + 2];
                 const double r2 = dx * dx + dy * dy + dz * dz;
