@@ -116,10 +116,11 @@ struct LjCells {
     uint32_t natoms = 0, max_nbr = 0;
     double cutoff = 0.0, skin = 0.0;
     size_t ncap = 0;                 // cells the count / start / cursor arrays can hold
+    int32_t* nbr_rows = nullptr;     // the list as the build kernel writes it: [natoms][max_nbr]
     int32_t *nbr = nullptr, *cnt = nullptr, *cell_of = nullptr, *sorted = nullptr, *counts = nullptr, *starts = nullptr,
             *cursor = nullptr;
     double* xref = nullptr;          // positions at build time
-    double* xs = nullptr;            // positions in cell order (build time only)
+    double* xs = nullptr;            // positions (+ atom index) in cell order, 32 bytes per atom (build time only)
     int32_t* tile_sums = nullptr;    // scan scratch, 1024 entries
     double* bbox_part = nullptr;     // [LJ_BBOX_GRID][6]
     unsigned int* overflow = nullptr;
@@ -129,7 +130,7 @@ struct LjCells {
     uint64_t rebuilds = 0, evals = 0;
     uint32_t longest = 0;
     void release() {
-        void* ptrs[] = {nbr, cnt, cell_of, sorted, counts, starts, cursor, xref, xs, tile_sums, bbox_part, overflow};
+        void* ptrs[] = {nbr, nbr_rows, cnt, cell_of, sorted, counts, starts, cursor, xref, xs, tile_sums, bbox_part, overflow};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (host) (void)hipHostFree(host);
@@ -590,6 +591,7 @@ int lj_cells_prepare(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, uint32_
     } while (0)
     const size_t na = natoms ? natoms : 1;
     LJ_ALLOC(lc->nbr, (size_t)max_nbr * na * sizeof(int32_t));
+    LJ_ALLOC(lc->nbr_rows, (size_t)max_nbr * na * sizeof(int32_t));
     LJ_ALLOC(lc->cnt, na * sizeof(int32_t));
     LJ_ALLOC(lc->cell_of, na * sizeof(int32_t));
     LJ_ALLOC(lc->sorted, na * sizeof(int32_t));
@@ -597,7 +599,7 @@ int lj_cells_prepare(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, uint32_
     LJ_ALLOC(lc->starts, (lc->ncap + 1) * sizeof(int32_t));
     LJ_ALLOC(lc->cursor, (lc->ncap + 1) * sizeof(int32_t));
     LJ_ALLOC(lc->xref, 3 * na * sizeof(double));
-    LJ_ALLOC(lc->xs, 3 * na * sizeof(double));
+    LJ_ALLOC(lc->xs, 4 * na * sizeof(double));  // 32-byte records: x, y, z, index
     LJ_ALLOC(lc->tile_sums, 1024 * sizeof(int32_t));
     LJ_ALLOC(lc->bbox_part, (size_t)LJ_BBOX_GRID * 6 * sizeof(double));
     LJ_ALLOC(lc->overflow, 64);
@@ -672,7 +674,9 @@ int lj_cells_rebuild(lbfgs_hip_ctx* ctx, const double* x) {
     hipLaunchKernelGGL(lj_cells_sort_kernel, dim3(cgrid), dim3(BLOCK), 0, ctx->stream, lc->starts, ncells, lc->sorted);
     hipLaunchKernelGGL(lj_cells_gather_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, x, natoms, lc->sorted, lc->xs);
     hipLaunchKernelGGL(lj_cells_build_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, lc->xs, natoms, gr, lc->cell_of, lc->starts,
-                       lc->sorted, rl * rl, lc->max_nbr, lc->nbr, lc->cnt, lc->xref, lc->overflow);
+                       lc->sorted, rl * rl, lc->max_nbr, lc->nbr_rows, lc->cnt, lc->xref, lc->overflow);
+    hipLaunchKernelGGL(lj_cells_transpose_kernel, dim3(std::min<uint32_t>(4096u, (natoms + 63) / 64)), dim3(BLOCK), 0, ctx->stream,
+                       lc->nbr_rows, lc->cnt, natoms, lc->max_nbr, lc->nbr);
     HIP_TRY(ctx, hipGetLastError());
     unsigned int over = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&over, lc->overflow, sizeof(over), hipMemcpyDeviceToHost, ctx->stream));

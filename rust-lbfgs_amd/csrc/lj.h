@@ -279,20 +279,41 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_sort_kernel(const int32_t* __r
     }
 }
 
-// positions in cell order: xs[t] = x[sorted[t]] (the list kernel then reads its candidates sequentially)
+// positions in cell order, one 32-byte record per atom: xs[4t .. 4t+2] = x[sorted[t]], and the low word of xs[4t+3] =
+// sorted[t] (the list kernel reads its candidates sequentially: two aligned 16-byte loads bring position AND index)
 __global__ __launch_bounds__(BLOCK) void lj_cells_gather_kernel(const double* __restrict__ x, const uint32_t natoms,
                                                                  const int32_t* __restrict__ sorted, double* __restrict__ xs) {
     for (uint32_t t = blockIdx.x * BLOCK + threadIdx.x; t < natoms; t += gridDim.x * BLOCK) {
         const size_t j = (size_t)sorted[t];
-        xs[3 * (size_t)t] = x[3 * j]; xs[3 * (size_t)t + 1] = x[3 * j + 1]; xs[3 * (size_t)t + 2] = x[3 * j + 2];
+        d2* rec = reinterpret_cast<d2*>(xs + 4 * (size_t)t);
+        rec[0] = d2{x[3 * j], x[3 * j + 1]};
+        rec[1] = d2{x[3 * j + 2], __hiloint2double(0, (int)j)};
     }
 }
 
 constexpr int LJ_BUILD_UNROLL = 8;
+// entry number k of an atom's list: four entries are collected in registers and leave as ONE 16-byte store (a 4-byte
+// store per hit costs the memory pipeline a cache-line access per lane and hit: 0.4 ms of the kernel at 1e6 atoms)
+__device__ __forceinline__ void lj_list_push(int32_t* __restrict__ mine, const uint32_t max_nbr, uint32_t& k, int4& q4, const int32_t v) {
+    const uint32_t slot = k & 3u;
+    q4.x = slot == 0u ? v : q4.x;
+    q4.y = slot == 1u ? v : q4.y;
+    q4.z = slot == 2u ? v : q4.z;
+    q4.w = slot == 3u ? v : q4.w;
+    if (slot == 3u) {
+        if (k < max_nbr) *reinterpret_cast<int4*>(mine + (k - 3u)) = q4;  // (max_nbr is a multiple of 4: the group fits or not as a whole)
+        q4 = make_int4(-1, -1, -1, -1);
+    }
+    ++k;
+}
 // Verlet list of atom i = sorted[t]: every j != i with |x_i - x_j| < rl, in the order (27 cells: z, y, x ascending; atoms
 // of a cell ascending).  One thread per atom IN CELL ORDER: the threads of a wave sit in the same few cells and walk the
 // same contiguous candidate segments of xs (the three cells of a row are adjacent in memory).
 // cnt[i] = entries used (a multiple of 4, the tail padded with -1); *overflow = the largest list that did not fit.
+// The list is written ROW-major here (nbr[i * max_nbr + k]: a thread's hits go to consecutive addresses) and turned into
+// the column-major table the evaluation reads coalesced by lj_cells_transpose_kernel: a thread finds its k-th neighbour
+// at a data-dependent moment, and column-major stores from here put every 4-byte entry into a cache line of its own --
+// 0.7 of this kernel's 1.13 ms at 1e6 atoms went into those (measured by compiling the stores out).
 __global__ __launch_bounds__(BLOCK) void lj_cells_build_kernel(const double* __restrict__ xs, const uint32_t natoms,
                                                                 const LjGrid gr, const int32_t* __restrict__ cell_of,
                                                                 const int32_t* __restrict__ starts,
@@ -302,8 +323,10 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_build_kernel(const double* __r
                                                                 unsigned int* __restrict__ overflow) {
     for (uint32_t t = blockIdx.x * BLOCK + threadIdx.x; t < natoms; t += gridDim.x * BLOCK) {
         const uint32_t i = (uint32_t)sorted[t];
-        const double xi = xs[3 * (size_t)t], yi = xs[3 * (size_t)t + 1], zi = xs[3 * (size_t)t + 2];
+        const double xi = xs[4 * (size_t)t], yi = xs[4 * (size_t)t + 1], zi = xs[4 * (size_t)t + 2];
         xref[3 * (size_t)i] = xi; xref[3 * (size_t)i + 1] = yi; xref[3 * (size_t)i + 2] = zi;
+        int32_t* __restrict__ mine = nbr + (size_t)i * max_nbr;
+        int4 q4 = make_int4(-1, -1, -1, -1);  // the group of four entries being filled (stored 16 bytes at a time)  // this atom's list, contiguous (lj_cells_transpose_kernel turns the table)
         const int c = cell_of[i];
         const int cx = c % gr.nx, cy = (c / gr.nx) % gr.ny, cz = c / (gr.nx * gr.ny);
         const int ax0 = max(cx - 1, 0), ax1 = min(cx + 1, gr.nx - 1);
@@ -320,24 +343,26 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_build_kernel(const double* __r
                 // LJ_BUILD_UNROLL candidates at a time: their positions are loaded together and tested in order
                 for (; u + LJ_BUILD_UNROLL <= u1; u += LJ_BUILD_UNROLL) {
                     double px[LJ_BUILD_UNROLL], py[LJ_BUILD_UNROLL], pz[LJ_BUILD_UNROLL];
+                    int32_t sj[LJ_BUILD_UNROLL];  // (the candidates' atom indices travel with their positions: no load behind a hit)
 #pragma unroll
                     for (int w = 0; w < LJ_BUILD_UNROLL; ++w) {
-                        px[w] = xs[3 * (size_t)(u + w)]; py[w] = xs[3 * (size_t)(u + w) + 1]; pz[w] = xs[3 * (size_t)(u + w) + 2];
+                        const d2* rec = reinterpret_cast<const d2*>(xs + 4 * (size_t)(u + w));
+                        const d2 r0 = rec[0], r1 = rec[1];
+                        px[w] = r0.x; py[w] = r0.y; pz[w] = r1.x;
+                        sj[w] = __double2loint(r1.y);
                     }
 #pragma unroll
                     for (int w = 0; w < LJ_BUILD_UNROLL; ++w) {
                         const double dx = xi - px[w], dyy = yi - py[w], dzz = zi - pz[w];
                         if (dx * dx + dyy * dyy + dzz * dzz < rl2 && (uint32_t)(u + w) != t) {
-                            if (k < max_nbr) nbr[(size_t)k * natoms + i] = sorted[u + w];
-                            ++k;
+                            lj_list_push(mine, max_nbr, k, q4, sj[w]);
                         }
                     }
                 }
                 for (; u < u1; ++u) {
-                    const double dx = xi - xs[3 * (size_t)u], dyy = yi - xs[3 * (size_t)u + 1], dzz = zi - xs[3 * (size_t)u + 2];
+                    const double dx = xi - xs[4 * (size_t)u], dyy = yi - xs[4 * (size_t)u + 1], dzz = zi - xs[4 * (size_t)u + 2];
                     if (dx * dx + dyy * dyy + dzz * dzz < rl2 && (uint32_t)u != t) {
-                        if (k < max_nbr) nbr[(size_t)k * natoms + i] = sorted[u];
-                        ++k;
+                        lj_list_push(mine, max_nbr, k, q4, sorted[u]);
                     }
                 }
             }
@@ -347,8 +372,43 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_build_kernel(const double* __r
             k = max_nbr;
         }
         const uint32_t k4 = (k + 3u) & ~3u;  // max_nbr is a multiple of 4
-        for (uint32_t q = k; q < k4; ++q) nbr[(size_t)q * natoms + i] = -1;
+        if (k & 3u) {  // the last, partly filled group: its empty slots hold -1 already
+            *reinterpret_cast<int4*>(mine + (k & ~3u)) = q4;
+        }
         cnt[i] = (int32_t)k4;
+    }
+}
+
+// rows[i * max_nbr + k] -> table[k * natoms + i] for k < cnt[i], in tiles of 64 atoms x 64 entries through LDS: reads
+// run along an atom's list (256 contiguous bytes per wave), writes along the atoms (256 contiguous bytes per wave and k)
+__global__ __launch_bounds__(BLOCK) void lj_cells_transpose_kernel(const int32_t* __restrict__ rows, const int32_t* __restrict__ cnt,
+                                                                    const uint32_t natoms, const uint32_t max_nbr,
+                                                                    int32_t* __restrict__ table) {
+    __shared__ int32_t tile[64][65];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t ntiles = (natoms + 63) / 64;
+    for (uint32_t tb = blockIdx.x; tb < ntiles; tb += gridDim.x) {
+        const uint32_t i0 = tb * 64;
+        // the longest list of the tile (lists are padded to a multiple of 4 with -1 and read up to cnt only)
+        uint32_t kmax = (i0 + lane < natoms) ? (uint32_t)cnt[i0 + lane] : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+        for (uint32_t k0 = 0; k0 < kmax; k0 += 64) {
+            __syncthreads();
+#pragma unroll
+            for (uint32_t r = 0; r < 4; ++r) {  // 16 lanes x 16 bytes = 64 consecutive entries of one atom's list; 16 atoms per pass
+                const uint32_t idx = threadIdx.x + BLOCK * r, a = idx >> 4, c = idx & 15u;
+                const uint32_t i = i0 + a, k = k0 + 4u * c;
+                int4 v = make_int4(-1, -1, -1, -1);
+                if (i < natoms && k < max_nbr) v = *reinterpret_cast<const int4*>(rows + (size_t)i * max_nbr + k);  // (max_nbr % 4 == 0)
+                tile[a][4 * c] = v.x; tile[a][4 * c + 1] = v.y; tile[a][4 * c + 2] = v.z; tile[a][4 * c + 3] = v.w;
+            }
+            __syncthreads();
+            for (uint32_t kk = wave; kk < 64; kk += WAVES) {  // entry k0 + kk of 64 consecutive atoms
+                const uint32_t i = i0 + lane, k = k0 + kk;
+                if (i < natoms && k < kmax) table[(size_t)k * natoms + i] = tile[lane][kk];
+            }
+        }
     }
 }
 
