@@ -11,6 +11,6 @@ for spec in $1; do
 import json, sys
 j = json.loads(open("gpurun_out/sa.json").read())
 r = j["roofline"]
-print(f"{sys.argv[1]:>14}: {j['value']:7.1f} it/s  step kernel {r['avg_ms']*1e3:6.1f} us = {r['achieved']:.0f} GB/s  two-loop {r['two_loop']['ms']:.3f} ms = {100*r['two_loop']['frac']:.1f} %  per-iter {r['per_iteration_ms']}")
+print(f"{sys.argv[1]:>14}: {j['value']:7.1f} it/s  step kernel {r['avg_ms']*1e3:6.1f} us = {r['achieved']:.0f} GB/s  two-loop {r["two_loop"]["ms"]:.3f} ms = {100*r["two_loop"]["frac"]:.1f} %  per-iter {r['per_iteration_ms']}")
 PY
 done
