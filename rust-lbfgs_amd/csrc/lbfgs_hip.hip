@@ -706,8 +706,13 @@ int lj_cells_eval(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, const lbfg
         if ((rc = fill_handoff(ctx, red)) != LBFGS_HIP_OK) return rc;
         red.out[0] = out;
         red.out[1] = lc->host_dev;  // the "moved too far" count goes straight to host-mapped memory
+        // a cheap look first: has the list gone stale?  (then the evaluation kernel returns at once and the list is rebuilt)
+        unsigned int* moved_flag = lc->overflow + 1;  // (a word of the 64-byte scratch next to the overflow counter)
+        HIP_TRY(ctx, hipMemsetAsync(moved_flag, 0, sizeof(unsigned int), ctx->stream));
+        hipLaunchKernelGGL(lj_cells_check_kernel, dim3(std::min(grid, 1024u)), dim3(BLOCK), 0, ctx->stream, x->p, lc->xref, natoms,
+                           half_skin2, moved_flag);
         hipLaunchKernelGGL(lj_cells_eval_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, x->p, g->p, lc->nbr, lc->cnt, lc->xref,
-                           natoms, rc2, eshift, half_skin2, red);
+                           natoms, rc2, eshift, half_skin2, moved_flag, red);
         HIP_TRY(ctx, hipGetLastError());
         lc->evals += 1;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

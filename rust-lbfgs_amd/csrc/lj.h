@@ -412,16 +412,36 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_transpose_kernel(const int32_t
     }
 }
 
+// Has any atom left its skin/2 sphere since the list was built?  (*moved |= 1; NaN counts as moved.)  48 bytes per atom,
+// run BEFORE every evaluation: an evaluation over a stale list is thrown away, and at 1e6 atoms it costs 0.41 ms
+// against this kernel's ~15 us -- in a relaxing system every third evaluation was such a throw-away.
+__global__ __launch_bounds__(BLOCK) void lj_cells_check_kernel(const double* __restrict__ x, const double* __restrict__ xref,
+                                                                const uint32_t natoms, const double half_skin2,
+                                                                unsigned int* __restrict__ moved) {
+    bool any = false;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < natoms; i += gridDim.x * BLOCK) {
+        const double ux = x[3 * (size_t)i] - xref[3 * (size_t)i], uy = x[3 * (size_t)i + 1] - xref[3 * (size_t)i + 1],
+                     uz = x[3 * (size_t)i + 2] - xref[3 * (size_t)i + 2];
+        any |= !(ux * ux + uy * uy + uz * uz <= half_skin2);
+    }
+    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(moved, 1u);
+}
+
 // The cutoff sum over the Verlet list, and (second total) the number of atoms that have left their skin/2 sphere.
+// `moved_flag` (lj_cells_check_kernel, same stream, just before): non-zero = the list is stale -- nothing is evaluated,
+// the second total is reported as 1 and the host rebuilds; the reduction still runs (the launch's tags are spoken for).
 __global__ __launch_bounds__(BLOCK) void lj_cells_eval_kernel(const double* __restrict__ x, double* __restrict__ g,
                                                                const int32_t* __restrict__ nbr,
                                                                const int32_t* __restrict__ cnt,
                                                                const double* __restrict__ xref, const uint32_t natoms,
                                                                const double rc2, const double eshift,
-                                                               const double half_skin2, const RedCtl red) {
+                                                               const double half_skin2,
+                                                               const unsigned int* __restrict__ moved_flag, const RedCtl red) {
     const DevCounters c0 = load_counters(red);
     double e = 0.0, stale = 0.0;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < natoms; i += gridDim.x * BLOCK) {
+    const bool skip = *moved_flag != 0u;
+    if (skip) stale = (blockIdx.x == 0 && threadIdx.x == 0) ? 1.0 : 0.0;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < (skip ? 0u : natoms); i += gridDim.x * BLOCK) {
         const double xi = x[3 * (size_t)i], yi = x[3 * (size_t)i + 1], zi = x[3 * (size_t)i + 2];
         {
             const double ux = xi - xref[3 * (size_t)i], uy = yi - xref[3 * (size_t)i + 1], uz = zi - xref[3 * (size_t)i + 2];

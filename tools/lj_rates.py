@@ -69,7 +69,8 @@ with R.Context(len(x)) as ctx:
 
     dt2 = timed(ctx, rebuild_eval, 10)
     print(json.dumps(dict(kernel="lj_cells", natoms=1_000_000, cutoff=2.5, skin=0.3, longest_list=longest,
-                          eval_ms_list_valid=dt * 1e3, stale_eval_plus_rebuild_plus_eval_ms=dt2 * 1e3,
-                          rebuild_ms=(dt2 - 2 * dt) * 1e3)), flush=True)
+                          eval_ms_list_valid=dt * 1e3, stale_check_plus_rebuild_plus_eval_ms=dt2 * 1e3,
+                          # (the staleness check runs before the evaluation: a stale list costs the check, not an evaluation)
+                          rebuild_ms=(dt2 - dt) * 1e3)), flush=True)
     for v in (xv, gv, xa, xb):
         v.free()
