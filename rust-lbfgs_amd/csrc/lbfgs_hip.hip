@@ -154,6 +154,7 @@ struct lbfgs_hip_ctx {
     unsigned long long p2p_count = 0;     // P2P exchanges enqueued so far (shadow of DevCounters::p2p_epoch)
     unsigned int* p2p_err = nullptr;      // device error flag: 1 = a P2P spin timed out, 2 = a workgroup's partials never arrived
     unsigned long long p2p_timeout_ticks = 0;
+    unsigned long long handoff_timeout_ticks = 1000000000ULL;  // bound on every cross-workgroup spin (wall_clock64: 100 MHz)
     double* board = nullptr;         // LBFGS_HIP_BOARD_SLOTS doubles + 2 ping-pong dots
     double* partials = nullptr;      // MAX_RED * MAX_GRID
     unsigned int* ticket = nullptr;
@@ -286,7 +287,7 @@ int fill_handoff(lbfgs_hip_ctx* ctx, RedCtl& red) {
     red.ticket = ctx->ticket;
     red.gran = ctx->gran;
     red.err = ctx->p2p_err;
-    red.timeout_ticks = 1000000000ULL;  // 10 s of the 100 MHz wall clock
+    red.timeout_ticks = ctx->handoff_timeout_ticks;  // (10 s of the 100 MHz wall clock unless LBFGS_HIP_HANDOFF_TIMEOUT_MS says otherwise)
     red.ctr = ctx->dev_ctr;
     red.tagged = ctx->handoff_ticket ? 0u : 1u;
     if (red.tagged) {
@@ -1007,6 +1008,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     if (const char* e = getenv("LBFGS_HIP_DEFER_SUMS")) ctx->defer_inner_sums = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT")) ctx->resident_on = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_GRID")) ctx->resident_grid = std::max(0, atoi(e));
+    if (const char* e = getenv("LBFGS_HIP_HANDOFF_TIMEOUT_MS")) ctx->handoff_timeout_ticks = (unsigned long long)std::max(1, atoi(e)) * 100000ULL;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_HYBRID")) ctx->resident_hybrid = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_GRAPH")) ctx->graph_max_bytes = atoi(e) ? ~(size_t)0 : 0;
     if (const char* e = getenv("LBFGS_HIP_GRAPH_MAX_MB")) ctx->graph_max_bytes = (size_t)atoll(e) << 20;

@@ -128,7 +128,10 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
 #pragma unroll
                 for (int k = 0; k < NS; ++k) ok = ok && (unsigned int)(lo[k] >> 32) == tag && (unsigned int)(hi[k] >> 32) == tag;
                 if (ok) break;
-                if ((unsigned long long)(wall_clock64() - t0) > red.timeout_ticks) {
+                // (slow path only) give up after the timeout -- or at once if somebody already has: one missing workgroup must
+                // cost ONE timeout, not one per hand-off and workgroup
+                if ((unsigned long long)(wall_clock64() - t0) > red.timeout_ticks ||
+                    __hip_atomic_load(red.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                     atomicExch(red.err, 2u);
                     break;
                 }
@@ -169,7 +172,8 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
                 lo = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 hi = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned int)(lo >> 32) == tag && (unsigned int)(hi >> 32) == tag) break;
-                if ((unsigned long long)(wall_clock64() - t0) > red.timeout_ticks + red.p2p.timeout_ticks) {
+                if ((unsigned long long)(wall_clock64() - t0) > red.timeout_ticks + red.p2p.timeout_ticks ||
+                    __hip_atomic_load(red.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                     atomicExch(red.err, 2u);
                     break;
                 }
