@@ -164,6 +164,7 @@ struct lbfgs_hip_ctx {
     unsigned long long* gran = nullptr;   // tagged partial granules [MAX_RED][MAX_GRID][2] (stream.h)
     bool p2p_exclusive = false;           // lbfgs_hip_comm.exclusive_device: no other rank shares this GPU
     unsigned int resident_attr_mask = 0;  // which resident kernels have had their dynamic-LDS limit raised on this device
+    int lj_build_fp32 = 1;                // LBFGS_HIP_LJ_BUILD_FP32=0: the LJ_CELLS list from double-precision candidate tests
     int resident_hybrid = 1;              // LBFGS_HIP_RESIDENT_HYBRID=0: shards that do not fit the chip take the kernel-per-step path
     uint64_t resident_elements = 0;       // elements of q the last resident launch kept on the chip (all of them unless hybrid)
     int resident_grid = 0;                // LBFGS_HIP_RESIDENT_GRID: workgroups of the resident kernel (0 = one per CU); tests
@@ -673,9 +674,24 @@ int lj_cells_rebuild(lbfgs_hip_ctx* ctx, const double* x) {
                        lc->starts, lc->cursor);
     hipLaunchKernelGGL(lj_cells_fill_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, lc->cell_of, natoms, lc->cursor, lc->sorted);
     hipLaunchKernelGGL(lj_cells_sort_kernel, dim3(cgrid), dim3(BLOCK), 0, ctx->stream, lc->starts, ncells, lc->sorted);
-    hipLaunchKernelGGL(lj_cells_gather_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, x, natoms, lc->sorted, lc->xs);
-    hipLaunchKernelGGL(lj_cells_build_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, lc->xs, natoms, gr, lc->cell_of, lc->starts,
-                       lc->sorted, rl * rl, lc->max_nbr, lc->nbr_rows, lc->cnt, lc->xref, lc->overflow);
+    // The candidate tests run in single precision on origin-relative positions against rl^2 + a margin that covers their
+    // rounding: |x - o| <= extent, so each fp32 coordinate is off by <= extent * 2^-24, a difference by twice that, and
+    // r^2 by <= 2 * sqrt(3) * rl * extent * 2^-23 (+ the fp32 arithmetic's own 1e-6 relative) -- a slightly larger list, the
+    // same results (lj.h).  Boxes so large that the margin would exceed 1 % of rl^2 take the double-precision kernel.
+    const double extent = std::fmax(std::fmax(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]) + rl;
+    const double margin = 8.0 * rl * extent * std::ldexp(1.0, -23) + 2e-6 * rl * rl;
+    if (ctx->lj_build_fp32 && margin <= 0.01 * rl * rl) {
+        HIP_TRY(ctx, hipMemcpyAsync(lc->xref, x, 3 * (size_t)natoms * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(lj_cells_gather32_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, x, natoms, lc->sorted, gr,
+                           reinterpret_cast<LjRec32*>(lc->xs));
+        hipLaunchKernelGGL(lj_cells_build32_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream,
+                           reinterpret_cast<const LjRec32*>(lc->xs), natoms, gr, lc->cell_of, lc->starts, (float)(rl * rl + margin),
+                           lc->max_nbr, lc->nbr_rows, lc->cnt, lc->overflow);
+    } else {
+        hipLaunchKernelGGL(lj_cells_gather_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, x, natoms, lc->sorted, lc->xs);
+        hipLaunchKernelGGL(lj_cells_build_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, lc->xs, natoms, gr, lc->cell_of,
+                           lc->starts, lc->sorted, rl * rl, lc->max_nbr, lc->nbr_rows, lc->cnt, lc->xref, lc->overflow);
+    }
     hipLaunchKernelGGL(lj_cells_transpose_kernel, dim3(std::min<uint32_t>(4096u, (natoms + 63) / 64)), dim3(BLOCK), 0, ctx->stream,
                        lc->nbr_rows, lc->cnt, natoms, lc->max_nbr, lc->nbr);
     HIP_TRY(ctx, hipGetLastError());
@@ -1008,6 +1024,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     if (const char* e = getenv("LBFGS_HIP_DEFER_SUMS")) ctx->defer_inner_sums = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT")) ctx->resident_on = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_GRID")) ctx->resident_grid = std::max(0, atoi(e));
+    if (const char* e = getenv("LBFGS_HIP_LJ_BUILD_FP32")) ctx->lj_build_fp32 = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_HANDOFF_TIMEOUT_MS")) ctx->handoff_timeout_ticks = (unsigned long long)std::max(1, atoi(e)) * 100000ULL;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_HYBRID")) ctx->resident_hybrid = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_GRAPH")) ctx->graph_max_bytes = atoi(e) ? ~(size_t)0 : 0;

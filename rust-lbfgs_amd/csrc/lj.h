@@ -291,7 +291,10 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_gather_kernel(const double* __
     }
 }
 
-constexpr int LJ_BUILD_UNROLL = 8;
+#ifndef LH_LJ_BUILD_UNROLL
+#define LH_LJ_BUILD_UNROLL 8
+#endif
+constexpr int LJ_BUILD_UNROLL = LH_LJ_BUILD_UNROLL;
 // entry number k of an atom's list: four entries are collected in registers and leave as ONE 16-byte store (a 4-byte
 // store per hit costs the memory pipeline a cache-line access per lane and hit: 0.4 ms of the kernel at 1e6 atoms)
 __device__ __forceinline__ void lj_list_push(int32_t* __restrict__ mine, const uint32_t max_nbr, uint32_t& k, int4& q4, const int32_t v) {
@@ -375,6 +378,89 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_build_kernel(const double* __r
         if (k & 3u) {  // the last, partly filled group: its empty slots hold -1 already
             *reinterpret_cast<int4*>(mine + (k & ~3u)) = q4;
         }
+        cnt[i] = (int32_t)k4;
+    }
+}
+
+// ---- the same list from SINGLE-precision candidate tests (the default) ---------------------------------------------
+// What the list has to be is a SUPERSET: every pair that can come within the cutoff before the next rebuild -- every
+// pair closer than rl at build time -- must be in it; what else is in it does not matter, because the evaluation tests
+// every entry against the cutoff in double precision and adds exact zeros for the rest (as it does for all the entries
+// between rc and rl).  Entries keep their enumeration order either way, so every sum is formed in the same order from
+// the same non-zero terms: the evaluation's results are bit-identical to those over the double-precision list (tested).
+// So the candidate test runs in fp32 on positions relative to the grid origin, against rl^2 plus a margin that covers
+// the rounding of those positions (host: lj_cells_rebuild); 16-byte records (x, y, z, atom index) instead of 32, half the
+// loads, and single-precision arithmetic that the compiler packs two candidates at a time.
+typedef float lj_f2 __attribute__((ext_vector_type(2)));
+struct LjRec32 {
+    float x, y, z;
+    int32_t idx;
+};
+__global__ __launch_bounds__(BLOCK) void lj_cells_gather32_kernel(const double* __restrict__ x, const uint32_t natoms,
+                                                                   const int32_t* __restrict__ sorted, const LjGrid gr,
+                                                                   LjRec32* __restrict__ xs32) {
+    for (uint32_t t = blockIdx.x * BLOCK + threadIdx.x; t < natoms; t += gridDim.x * BLOCK) {
+        const size_t j = (size_t)sorted[t];
+        LjRec32 r;
+        r.x = (float)(x[3 * j] - gr.ox); r.y = (float)(x[3 * j + 1] - gr.oy); r.z = (float)(x[3 * j + 2] - gr.oz);
+        r.idx = (int32_t)j;
+        *reinterpret_cast<int4*>(xs32 + t) = *reinterpret_cast<const int4*>(&r);
+    }
+}
+__global__ __launch_bounds__(BLOCK) void lj_cells_build32_kernel(const LjRec32* __restrict__ xs32, const uint32_t natoms,
+                                                                  const LjGrid gr, const int32_t* __restrict__ cell_of,
+                                                                  const int32_t* __restrict__ starts, const float rl2m,
+                                                                  const uint32_t max_nbr, int32_t* __restrict__ nbr,
+                                                                  int32_t* __restrict__ cnt, unsigned int* __restrict__ overflow) {
+    static_assert(LJ_BUILD_UNROLL % 2 == 0, "candidates are tested two at a time");
+    for (uint32_t t = blockIdx.x * BLOCK + threadIdx.x; t < natoms; t += gridDim.x * BLOCK) {
+        LjRec32 me;
+        *reinterpret_cast<int4*>(&me) = *reinterpret_cast<const int4*>(xs32 + t);
+        const uint32_t i = (uint32_t)me.idx;
+        int32_t* __restrict__ mine = nbr + (size_t)i * max_nbr;
+        int4 q4 = make_int4(-1, -1, -1, -1);
+        const int c = cell_of[i];
+        const int cx = c % gr.nx, cy = (c / gr.nx) % gr.ny, cz = c / (gr.nx * gr.ny);
+        const int ax0 = max(cx - 1, 0), ax1 = min(cx + 1, gr.nx - 1);
+        const lj_f2 xi = {me.x, me.x}, yi = {me.y, me.y}, zi = {me.z, me.z};
+        uint32_t k = 0;
+        for (int dz = -1; dz <= 1; ++dz) {
+            const int az = cz + dz;
+            if (az < 0 || az >= gr.nz) continue;
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int ay = cy + dy;
+                if (ay < 0 || ay >= gr.ny) continue;
+                const int row = (az * gr.ny + ay) * gr.nx;
+                const int32_t u1 = starts[row + ax1 + 1];
+                int32_t u = starts[row + ax0];
+                for (; u + LJ_BUILD_UNROLL <= u1; u += LJ_BUILD_UNROLL) {
+                    LjRec32 cnd[LJ_BUILD_UNROLL];
+#pragma unroll
+                    for (int w = 0; w < LJ_BUILD_UNROLL; ++w)
+                        *reinterpret_cast<int4*>(&cnd[w]) = *reinterpret_cast<const int4*>(xs32 + u + w);
+#pragma unroll
+                    for (int w = 0; w < LJ_BUILD_UNROLL; w += 2) {
+                        const lj_f2 dx = xi - lj_f2{cnd[w].x, cnd[w + 1].x}, dyy = yi - lj_f2{cnd[w].y, cnd[w + 1].y},
+                                    dzz = zi - lj_f2{cnd[w].z, cnd[w + 1].z};
+                        const lj_f2 r2 = dx * dx + dyy * dyy + dzz * dzz;
+                        if (r2.x < rl2m && (uint32_t)(u + w) != t) lj_list_push(mine, max_nbr, k, q4, cnd[w].idx);
+                        if (r2.y < rl2m && (uint32_t)(u + w + 1) != t) lj_list_push(mine, max_nbr, k, q4, cnd[w + 1].idx);
+                    }
+                }
+                for (; u < u1; ++u) {
+                    LjRec32 cd;
+                    *reinterpret_cast<int4*>(&cd) = *reinterpret_cast<const int4*>(xs32 + u);
+                    const float dx = me.x - cd.x, dyy = me.y - cd.y, dzz = me.z - cd.z;
+                    if (dx * dx + dyy * dyy + dzz * dzz < rl2m && (uint32_t)u != t) lj_list_push(mine, max_nbr, k, q4, cd.idx);
+                }
+            }
+        }
+        if (k > max_nbr) {
+            atomicMax(overflow, k);
+            k = max_nbr;
+        }
+        const uint32_t k4 = (k + 3u) & ~3u;
+        if (k & 3u) *reinterpret_cast<int4*>(mine + (k & ~3u)) = q4;
         cnt[i] = (int32_t)k4;
     }
 }

@@ -180,3 +180,37 @@ def test_lj_cells_errors():
         fo, _ = O.eval_builtin(O.lj_cells(2.5), x)
         assert abs(ctx.scalars(0)[0] - fo) <= RTOL * abs(fo)
         xv.free(); gv.free()
+
+
+def test_lj_cells_single_precision_list_gives_the_same_bits(monkeypatch):
+    """The list is built from single-precision candidate tests with a safety margin (a slight superset of the
+    double-precision list: lj.h).  The evaluation tests every entry against the cutoff in double precision, so energy
+    and gradient must be BIT-identical between the two builds, at every point of a run with rebuilds -- also for a block
+    far from the origin (large coordinates are what single precision is worst at)."""
+    if ON_MOCK:
+        pytest.skip("a property of the HIP kernels")
+    rc, skin = 2.5, 0.3
+    obj = objectives.LennardJonesCells(rc, skin)
+    rng = np.random.default_rng(11)
+    for shift in (0.0, 3.0e3):
+        x0 = _jittered_lattice(9, 1.15, 0.08, 4) + shift
+        pts = [x0, x0 + rng.uniform(-0.05, 0.05, len(x0)), x0 + rng.uniform(-0.4, 0.4, len(x0)),
+               (x0.reshape(-1, 3)[rng.permutation(len(x0) // 3)]).reshape(-1)]
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("LBFGS_HIP_LJ_BUILD_FP32", mode)
+            out = []
+            with R.Context(len(x0)) as ctx:
+                xv, gv = DeviceVec(ctx), DeviceVec(ctx)
+                for p in pts:
+                    H.objective_eval(obj, xv.upload(p), gv, 0)
+                    out.append((ctx.scalars(0)[0], gv.to_numpy()))
+                out.append(ctx.lj_cells_stats())
+                xv.free(); gv.free()
+            res[mode] = out
+        for a, b in zip(res["1"][:-1], res["0"][:-1]):
+            assert a[0] == b[0] and np.array_equal(a[1], b[1])
+        assert res["1"][-1][:2] == res["0"][-1][:2]                  # the same rebuilds and evaluations
+        assert res["1"][-1][2] >= res["0"][-1][2]                    # the single-precision list is a superset
+        fo, go = O.eval_builtin(O.lj_cells(rc), np.ascontiguousarray(pts[2]))
+        assert abs(res["1"][2][0] - fo) <= RTOL * abs(fo) and rel(res["1"][2][1], go) <= RTOL
