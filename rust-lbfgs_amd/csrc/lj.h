@@ -516,11 +516,12 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_check_kernel(const double* __r
 // The cutoff sum over the Verlet list, and (second total) the number of atoms that have left their skin/2 sphere.
 // `moved_flag` (lj_cells_check_kernel, same stream, just before): non-zero = the list is stale -- nothing is evaluated,
 // the second total is reported as 1 and the host rebuilds; the reduction still runs (the launch's tags are spoken for).
+template <bool ROWS>
 __global__ __launch_bounds__(BLOCK) void lj_cells_eval_kernel(const double* __restrict__ x, double* __restrict__ g,
                                                                const int32_t* __restrict__ nbr,
                                                                const int32_t* __restrict__ cnt,
                                                                const double* __restrict__ xref, const uint32_t natoms,
-                                                               const double rc2, const double eshift,
+                                                               const uint32_t max_nbr, const double rc2, const double eshift,
                                                                const double half_skin2,
                                                                const unsigned int* __restrict__ moved_flag, const RedCtl red) {
     const DevCounters c0 = load_counters(red);
@@ -537,17 +538,26 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_eval_kernel(const double* __re
         double fx = 0.0, fy = 0.0, fz = 0.0;
         const uint32_t n4 = (uint32_t)cnt[i];
         int32_t jn[4] = {-1, -1, -1, -1};  // the NEXT group's four list entries: loaded one group ahead of the gathers they feed
+        // ROWS: the table as the list kernel wrote it, nbr[i * max_nbr + k] -- one 16-byte load brings four entries, but every
+        // lane reads a line of its own (+12 % on this kernel); else the transposed table, nbr[k * natoms + i], read coalesced
+        const int4* __restrict__ mine = reinterpret_cast<const int4*>(nbr + (ROWS ? (size_t)i * max_nbr : 0));
         if (n4 > 0) {
+            if constexpr (ROWS) { const int4 v = mine[0]; jn[0] = v.x; jn[1] = v.y; jn[2] = v.z; jn[3] = v.w; }
+            else {
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) jn[u] = nbr[(size_t)u * natoms + i];
+                for (uint32_t u = 0; u < 4; ++u) jn[u] = nbr[(size_t)u * natoms + i];
+            }
         }
         for (uint32_t k0 = 0; k0 < n4; k0 += 4) {
             int32_t jc[4];
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) jc[u] = jn[u];
             if (k0 + 4 < n4) {
+                if constexpr (ROWS) { const int4 v = mine[(k0 >> 2) + 1]; jn[0] = v.x; jn[1] = v.y; jn[2] = v.z; jn[3] = v.w; }
+                else {
 #pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) jn[u] = nbr[(size_t)(k0 + 4 + u) * natoms + i];
+                    for (uint32_t u = 0; u < 4; ++u) jn[u] = nbr[(size_t)(k0 + 4 + u) * natoms + i];
+                }
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) {  // four gathers in flight; an empty slot or a pair beyond rc adds selected zeros
