@@ -117,6 +117,7 @@ struct LjCells {
     double cutoff = 0.0, skin = 0.0;
     size_t ncap = 0;                 // cells the count / start / cursor arrays can hold
     int32_t* nbr_rows = nullptr;     // the list as the build kernel writes it: [natoms][max_nbr]
+    int32_t* slot_of = nullptr;      // an atom's place within its cell (from the count kernel's atomicAdd)
     int32_t *nbr = nullptr, *cnt = nullptr, *cell_of = nullptr, *sorted = nullptr, *counts = nullptr, *starts = nullptr,
             *cursor = nullptr;
     double* xref = nullptr;          // positions at build time
@@ -132,7 +133,7 @@ struct LjCells {
     uint64_t rebuilds = 0, evals = 0;
     uint32_t longest = 0;
     void release() {
-        void* ptrs[] = {nbr, nbr_rows, cnt, cell_of, sorted, counts, starts, cursor, xref, xs, tile_sums, bbox_part, overflow};
+        void* ptrs[] = {nbr, nbr_rows, slot_of, cnt, cell_of, sorted, counts, starts, cursor, xref, xs, tile_sums, bbox_part, overflow};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (host) (void)hipHostFree(host);
@@ -598,6 +599,7 @@ int lj_cells_prepare(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, uint32_
     LJ_ALLOC(lc->nbr_rows, (size_t)max_nbr * na * sizeof(int32_t));
     LJ_ALLOC(lc->cnt, na * sizeof(int32_t));
     LJ_ALLOC(lc->cell_of, na * sizeof(int32_t));
+    LJ_ALLOC(lc->slot_of, na * sizeof(int32_t));
     LJ_ALLOC(lc->sorted, na * sizeof(int32_t));
     LJ_ALLOC(lc->counts, (lc->ncap + 1) * sizeof(int32_t));
     LJ_ALLOC(lc->starts, (lc->ncap + 1) * sizeof(int32_t));
@@ -675,13 +677,15 @@ int lj_cells_rebuild(lbfgs_hip_ctx* ctx, const double* x) {
     const int cgrid = (int)std::min<uint32_t>(4096u, std::max(1u, (ncells + BLOCK - 1) / BLOCK));
     HIP_TRY(ctx, hipMemsetAsync(lc->counts, 0, ((size_t)ncells + 1) * sizeof(int32_t), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(lc->overflow, 0, sizeof(unsigned int), ctx->stream));
-    hipLaunchKernelGGL(lj_cells_count_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, x, natoms, gr, lc->cell_of, lc->counts);
+    hipLaunchKernelGGL(lj_cells_count_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, x, natoms, gr, lc->cell_of, lc->slot_of,
+                       lc->counts);
     const uint32_t ntiles = (ncells + LJ_SCAN_TILE - 1) / LJ_SCAN_TILE;  // <= 1024 by the choice of ncap
     hipLaunchKernelGGL(lj_scan_tile_sums_kernel, dim3(ntiles), dim3(BLOCK), 0, ctx->stream, lc->counts, ncells, lc->tile_sums);
     hipLaunchKernelGGL(lj_scan_tile_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, lc->tile_sums, ntiles);
     hipLaunchKernelGGL(lj_scan_apply_kernel, dim3(ntiles), dim3(BLOCK), 0, ctx->stream, lc->counts, ncells, lc->tile_sums,
                        lc->starts, lc->cursor);
-    hipLaunchKernelGGL(lj_cells_fill_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, lc->cell_of, natoms, lc->cursor, lc->sorted);
+    hipLaunchKernelGGL(lj_cells_fill_kernel, dim3(agrid), dim3(BLOCK), 0, ctx->stream, lc->cell_of, lc->slot_of, natoms, lc->starts,
+                       lc->sorted);
     hipLaunchKernelGGL(lj_cells_sort_kernel, dim3(cgrid), dim3(BLOCK), 0, ctx->stream, lc->starts, ncells, lc->sorted);
     // The candidate tests run in single precision on origin-relative positions against rl^2 + a margin that covers their
     // rounding: |x - o| <= extent, so each fp32 coordinate is off by <= extent * 2^-24, a difference by twice that, and
