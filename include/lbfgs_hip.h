@@ -273,7 +273,7 @@ typedef struct lbfgs_hip_objective {
      * lbfgs_hip_device_buffer_create; cutoff rc */
     const void* nbr_index;
     uint32_t max_nbr;   /* LJ_NEIGHBORS: rows of the table.  LJ_CELLS: capacity of an atom's list (rounded up to a multiple
-                           of 4; 0 = 128); an atom with more neighbours within cutoff + skin fails the evaluation */
+                           of 16; 0 = 128); an atom with more neighbours within cutoff + skin fails the evaluation */
     uint32_t _pad2;
     double cutoff;
     double skin;        /* LJ_CELLS: list radius = cutoff + skin (> 0) */

@@ -575,7 +575,7 @@ int lj_cells_prepare(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, uint32_
     if (!(obj->cutoff > 0.0) || !(obj->skin > 0.0))
         return fail(ctx, LBFGS_HIP_ERR_ARG, "LJ_CELLS needs cutoff > 0 and skin > 0");
     uint32_t max_nbr = obj->max_nbr ? obj->max_nbr : 128u;
-    max_nbr = (max_nbr + 3u) & ~3u;
+    max_nbr = (max_nbr + LJ_EVAL_GROUP - 1u) / LJ_EVAL_GROUP * LJ_EVAL_GROUP;  // lists are padded to whole groups of the evaluation
     if (!ctx->lj_cells) ctx->lj_cells = new (std::nothrow) LjCells();
     LjCells* lc = ctx->lj_cells;
     if (!lc) return fail(ctx, LBFGS_HIP_ERR_NOMEM, "out of host memory");

@@ -309,6 +309,18 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_gather_kernel(const double* __
     }
 }
 
+#ifndef LH_LJ_EVAL_GROUP
+#define LH_LJ_EVAL_GROUP 16
+#endif
+constexpr uint32_t LJ_EVAL_GROUP = LH_LJ_EVAL_GROUP;  // list entries the evaluation takes at a time (a multiple of 4; 16 measured best of 4 ... 32: more gathers in flight): lists are padded to it with -1
+// close an atom's list of k entries (k <= max_nbr, a multiple of LJ_EVAL_GROUP): flush the partly filled group of four, pad
+// with -1 up to the next multiple of LJ_EVAL_GROUP; -> the padded length
+__device__ __forceinline__ uint32_t lj_list_finish(int32_t* __restrict__ mine, const uint32_t k, const int4 q4) {
+    uint32_t kk = (k + 3u) & ~3u;
+    if (k & 3u) *reinterpret_cast<int4*>(mine + (k & ~3u)) = q4;  // (its empty slots hold -1 already)
+    for (; kk % LJ_EVAL_GROUP != 0u; kk += 4u) *reinterpret_cast<int4*>(mine + kk) = make_int4(-1, -1, -1, -1);
+    return kk;
+}
 #ifndef LH_LJ_BUILD_UNROLL
 #define LH_LJ_BUILD_UNROLL 8
 #endif
@@ -392,11 +404,7 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_build_kernel(const double* __r
             atomicMax(overflow, k);
             k = max_nbr;
         }
-        const uint32_t k4 = (k + 3u) & ~3u;  // max_nbr is a multiple of 4
-        if (k & 3u) {  // the last, partly filled group: its empty slots hold -1 already
-            *reinterpret_cast<int4*>(mine + (k & ~3u)) = q4;
-        }
-        cnt[i] = (int32_t)k4;
+        cnt[i] = (int32_t)lj_list_finish(mine, k, q4);
     }
 }
 
@@ -477,9 +485,7 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_build32_kernel(const LjRec32* 
             atomicMax(overflow, k);
             k = max_nbr;
         }
-        const uint32_t k4 = (k + 3u) & ~3u;
-        if (k & 3u) *reinterpret_cast<int4*>(mine + (k & ~3u)) = q4;
-        cnt[i] = (int32_t)k4;
+        cnt[i] = (int32_t)lj_list_finish(mine, k, q4);
     }
 }
 
@@ -554,36 +560,43 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_eval_kernel(const double* __re
             stale += (u2 <= half_skin2) ? 0.0 : 1.0;  // NaN counts as moved
         }
         double fx = 0.0, fy = 0.0, fz = 0.0;
-        const uint32_t n4 = (uint32_t)cnt[i];
-        int32_t jn[4] = {-1, -1, -1, -1};  // the NEXT group's four list entries: loaded one group ahead of the gathers they feed
+        constexpr uint32_t G = LJ_EVAL_GROUP;
+        const uint32_t n4 = (uint32_t)cnt[i];  // (a multiple of G)
+        int32_t jn[G];  // the NEXT group's list entries: loaded one group ahead of the gathers they feed
+#pragma unroll
+        for (uint32_t u = 0; u < G; ++u) jn[u] = -1;
         // ROWS: the table as the list kernel wrote it, nbr[i * max_nbr + k] -- one 16-byte load brings four entries, but every
         // lane reads a line of its own (+12 % on this kernel); else the transposed table, nbr[k * natoms + i], read coalesced
         const int4* __restrict__ mine = reinterpret_cast<const int4*>(nbr + (ROWS ? (size_t)i * max_nbr : 0));
-        if (n4 > 0) {
-            if constexpr (ROWS) { const int4 v = mine[0]; jn[0] = v.x; jn[1] = v.y; jn[2] = v.z; jn[3] = v.w; }
-            else {
+        auto fetch = [&](const uint32_t k0) {
+            if constexpr (ROWS) {
 #pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) jn[u] = nbr[(size_t)u * natoms + i];
-            }
-        }
-        for (uint32_t k0 = 0; k0 < n4; k0 += 4) {
-            int32_t jc[4];
-#pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) jc[u] = jn[u];
-            if (k0 + 4 < n4) {
-                if constexpr (ROWS) { const int4 v = mine[(k0 >> 2) + 1]; jn[0] = v.x; jn[1] = v.y; jn[2] = v.z; jn[3] = v.w; }
-                else {
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) jn[u] = nbr[(size_t)(k0 + 4 + u) * natoms + i];
+                for (uint32_t q = 0; q < G / 4; ++q) {
+                    const int4 v = mine[(k0 >> 2) + q];
+                    jn[4 * q] = v.x; jn[4 * q + 1] = v.y; jn[4 * q + 2] = v.z; jn[4 * q + 3] = v.w;
                 }
+            } else {
+#pragma unroll
+                for (uint32_t u = 0; u < G; ++u) jn[u] = nbr[(size_t)(k0 + u) * natoms + i];
+            }
+        };
+        if (n4 > 0) fetch(0);
+        for (uint32_t k0 = 0; k0 < n4; k0 += G) {
+            int32_t jc[G];
+#pragma unroll
+            for (uint32_t u = 0; u < G; ++u) jc[u] = jn[u];
+            if (k0 + G < n4) fetch(k0 + G);
+            double px[G], py[G], pz[G];
+#pragma unroll
+            for (uint32_t u = 0; u < G; ++u) {  // G gathers in flight
+                const size_t jj = (jc[u] < 0) ? (size_t)i : (size_t)jc[u];
+                px[u] = x[3 * jj]; py[u] = x[3 * jj + 1]; pz[u] = x[3 * jj + 2];
             }
 #pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) {  // four gathers in flight; an empty slot or a pair beyond rc adds selected zeros
-                const int32_t j = jc[u];
-                const size_t jj = (j < 0) ? (size_t)i : (size_t)j;
-                const double dx = xi - x[3 * jj], dy = yi - x[3 * jj + 1], dz = zi - x[3 * jj + 2];
+            for (uint32_t u = 0; u < G; ++u) {  // an empty slot or a pair beyond rc adds selected zeros
+                const double dx = xi - px[u], dy = yi - py[u], dz = zi - pz[u];
                 const double r2 = dx * dx + dy * dy + dz * dz;
-                const bool on = (j >= 0) && (r2 < rc2);
+                const bool on = (jc[u] >= 0) && (r2 < rc2);
                 const double inv2 = lj_rcp(on ? r2 : 1.0);
                 const double s6 = inv2 * inv2 * inv2;
                 e += on ? 4.0 * (s6 * s6 - s6) : 0.0;                     // pair_energy   lj.rs:22-25
