@@ -261,6 +261,39 @@ def make_context(env, kind):
                     ok = 0.0
         finally:
             u.free()
+        # ... and a whole two-loop recursion with an EXACT answer, through whatever launch form this context takes (ranks
+        # that own their GPU under p2p: the persistent kernel, whose hand-offs carry the exchange -- a path the reductions
+        # above do not touch).  m = 1, s = (1,0,1,0,..), y = (2,2,..), g = (-1,-3,-1,-3,..): alpha = 1/2, gamma = 1/4,
+        # beta = 1/2, d = (0, 1/2, 0, 1/2, ..), ||d||^2 = n/8, g.d = -3n/4 -- every sum is a sum of dyadic numbers.
+        if a.n % 2 == 0:
+            import numpy as np
+
+            from rust_lbfgs_amd import hotpath as H
+
+            nl = ctx.n_local
+            hist = H.History(ctx, 1)
+            gv, dv = DeviceVec(ctx), DeviceVec(ctx)
+            try:
+                pat = np.zeros(nl)
+                pat[0::2] = 1.0
+                hist.s(0).upload(pat)
+                hist.y(0).fill(2.0)
+                pat[0::2], pat[1::2] = -1.0, -3.0
+                gv.upload(pat)
+                hist.set_scalars(ys=np.array([float(a.n)]), alpha=np.zeros(1))
+                ctx.set_scalars(7, [float(a.n), 4.0 * a.n])          # gamma = ys / yy
+                for _ in range(2):
+                    hist.two_loop(dv, gv, 1, 0, 7, 8, 12)
+                    dn2, gd = ctx.scalars(12, 2)
+                    dh = dv.to_numpy()
+                    if dn2 != a.n / 8.0 or gd != -0.75 * a.n or np.any(dh[0::2] != 0.0) or np.any(dh[1::2] != 0.5):
+                        print(f"[bench] rank {env.rank}: two-loop self-test: ||d||^2 = {dn2} (want {a.n / 8.0}), "
+                              f"g.d = {gd} (want {-0.75 * a.n})", file=sys.stderr)
+                        ok = 0.0
+            finally:
+                hist.free()
+                gv.free()
+                dv.free()
     except Exception as e:  # noqa: BLE001
         print(f"[bench] rank {env.rank}: {kind} communicator unavailable: {e}", file=sys.stderr)
         ok = 0.0
