@@ -168,6 +168,7 @@ struct lbfgs_hip_ctx {
     bool p2p_exclusive = false;           // lbfgs_hip_comm.exclusive_device: no other rank shares this GPU
     unsigned int resident_attr_mask = 0;  // which resident kernels have had their dynamic-LDS limit raised on this device
     int lj_build_fp32 = 1;                // LBFGS_HIP_LJ_BUILD_FP32=0: the LJ_CELLS list from double-precision candidate tests
+    size_t resident_nt_bytes = (size_t)16 << 20;  // LBFGS_HIP_RESIDENT_NT_MB
     int resident_hybrid = 1;              // LBFGS_HIP_RESIDENT_HYBRID=0: shards that do not fit the chip take the kernel-per-step path
     uint64_t resident_elements = 0;       // elements of q the last resident launch kept on the chip (all of them unless hybrid)
     int resident_grid = 0;                // LBFGS_HIP_RESIDENT_GRID: workgroups of the resident kernel (0 = one per CU); tests
@@ -1052,6 +1053,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_GRID")) ctx->resident_grid = std::max(0, atoi(e));
     if (const char* e = getenv("LBFGS_HIP_LJ_BUILD_FP32")) ctx->lj_build_fp32 = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_HANDOFF_TIMEOUT_MS")) ctx->handoff_timeout_ticks = (unsigned long long)std::max(1, atoi(e)) * 100000ULL;
+    if (const char* e = getenv("LBFGS_HIP_RESIDENT_NT_MB")) ctx->resident_nt_bytes = (size_t)std::max(0, atoi(e)) << 20;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_HYBRID")) ctx->resident_hybrid = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_GRAPH")) ctx->graph_max_bytes = atoi(e) ? ~(size_t)0 : 0;
     if (const char* e = getenv("LBFGS_HIP_GRAPH_MAX_MB")) ctx->graph_max_bytes = (size_t)atoll(e) << 20;
@@ -1719,7 +1721,10 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     const unsigned long long handoffs = (unsigned long long)(ns + (ra.first_dot ? 0 : 1));
     ctx->red_count += handoffs - 1ull;  // one tag per hand-off (prep_red counted one)
     if (in_kernel_exchange) ctx->p2p_count += handoffs - 1ull;  // ... and one P2P epoch each (prep_red counted one)
-    const bool nt = n * sizeof(double) >= ctx->nt_store_threshold_bytes;  // the history vectors are read once per step either way
+    // streaming hints on the history vectors' loads (read once per step) and on d's stores: from 16 MiB vectors up for this
+    // kernel (measured: neutral at 16 MB, +2 % at 24 MB, +8 % at 32-48 MB, profiles/r02_resident_nt_threshold.log; the
+    // launch-per-step kernels want them from 64 / 128 MiB only: their running vector is re-read from the caches)
+    const bool nt = n * sizeof(double) >= ctx->resident_nt_bytes;
     const size_t lds_bytes = (size_t)el * BLOCK * sizeof(d2);
     int rc;
     {
