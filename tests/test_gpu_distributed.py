@@ -281,3 +281,28 @@ def test_p2p_exchange_times_out_instead_of_hanging(tmp_path):
     assert out["in_kernel"][0] == _ffi.HIP_ERR_COMM and "timed out" in out["in_kernel"][1], out
     assert out["standalone"][0] == _ffi.HIP_ERR_COMM, out
     assert out["seconds"] < 30.0
+
+
+def test_bench_p2p_leg_with_the_persistent_kernel(tmp_path):
+    """The shape of the driver's multi-GPU run as far as ONE GPU can rehearse it: `python bench.py --gpus 2 --comm p2p` with
+    `--exclusive-device 1` (ranks own "their" GPU: here each gets 32 workgroups of it), so the leg's start-up self-test
+    and the timed iterations run the persistent two-loop kernel with the exchange inside its hand-offs -- in its HYBRID
+    form, since 5e6 elements per rank exceed what 32 workgroups hold."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs the GPU")
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--device", "0", "--comm", "p2p", "--exclusive-device", "1", "--dim",
+           "10000000", "--steps", "5", "--warmup", "12", "--repeats", "1", "--no-vector-free", "--leg-timeout", "200"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LBFGS_HIP_RESIDENT_GRID="32")
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=400)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    j = json.loads(lines[0])
+    assert j["config"]["legs"]["p2p"]["status"] == "ok", j["config"]["legs"]
+    r = j["roofline"]
+    assert r["kernel"].startswith("two_loop_resident_kernel") and 0 < r["resident_elements"] < j["config"]["n_local_rank0"]
+    assert "self-test" not in p.stderr
