@@ -19,7 +19,7 @@ HIP_LIB = os.path.join(HERE, "liblbfgs_hip.so")
 SOLVER_LIB = os.path.join(HERE, "liblbfgs_solver.so")
 RESOURCES = os.path.join(HERE, "liblbfgs_hip.resources.txt")  # per-kernel register / scratch usage of the last build
 
-HIP_SRCS = [os.path.join(CSRC, f) for f in ("lbfgs_hip.hip", "ops.h", "stream.h", "gram.h", "lj.h", "resident.h")] + [
+HIP_SRCS = [os.path.join(CSRC, f) for f in ("lbfgs_hip.hip", "ops.h", "stream.h", "gram.h", "lj.h", "resident.h", "gram_combine.h")] + [
     os.path.join(ROOT, "include", "lbfgs_hip.h")
 ]
 SOLVER_SRCS = [os.path.join(CSRC, "host", "solver.cpp"), os.path.join(ROOT, "include", "lbfgs_solver.h"),
@@ -48,10 +48,10 @@ def hipcc():
 
 
 def _audit_agprs(asm_text):
-    """resident.h keeps data in AGPRs by hand (inline asm).  Every AGPR operand the COMPILER emitted in those kernels --
+    """resident.h and gram_combine.h keep data in AGPRs by hand (inline asm).  Every AGPR operand the COMPILER emitted in those kernels --
     anything outside an inline-asm block -- would overwrite that data.  Returns {kernel symbol: count}."""
     out = {}
-    for m in re.finditer(r"^(_ZN2lh24two_loop_resident_kernel\w+):", asm_text, re.M):
+    for m in re.finditer(r"^(_ZN2lh(?:24two_loop_resident_kernel|28gram_combine_resident_kernel)\w+):", asm_text, re.M):
         body = asm_text[m.end(): asm_text.index("s_endpgm", m.end())]
         in_asm, n = False, 0
         for line in body.splitlines():

@@ -26,6 +26,7 @@
 #include "gram.h"
 #include "lj.h"
 #include "resident.h"
+#include "gram_combine.h"
 
 using namespace lh;
 
@@ -167,6 +168,7 @@ struct lbfgs_hip_ctx {
     unsigned long long* gran = nullptr;   // tagged partial granules [MAX_RED][MAX_GRID][2] (stream.h)
     bool p2p_exclusive = false;           // lbfgs_hip_comm.exclusive_device: no other rank shares this GPU
     unsigned int resident_attr_mask = 0;  // which resident kernels have had their dynamic-LDS limit raised on this device
+    int gram_combine_resident = 1;        // LBFGS_HIP_GRAM_COMBINE_RESIDENT=0: the vector-free combine as one streaming pass over all columns
     int lj_build_fp32 = 1;                // LBFGS_HIP_LJ_BUILD_FP32=0: the LJ_CELLS list from double-precision candidate tests
     size_t resident_nt_bytes = (size_t)16 << 20;  // LBFGS_HIP_RESIDENT_NT_MB
     int resident_hybrid = 1;              // LBFGS_HIP_RESIDENT_HYBRID=0: shards that do not fit the chip take the kernel-per-step path
@@ -857,6 +859,53 @@ int prof_drain(lbfgs_hip_ctx* ctx) {
 }  // namespace
 
 namespace {
+// -> 1 launched, 0 not eligible (the caller streams all columns at once), < 0 error.  dn: ||d||^2, g.d
+int gram_combine_resident(lbfgs_hip_ctx* ctx, const double* const* cols, int nb, double* d, const double* delta, double* dn) {
+    if (!ctx->resident_on || !ctx->gram_combine_resident || ctx->handoff_ticket || ctx->capturing || ctx->grid_override > 0 ||
+        nb > GC_MAX_COLS)
+        return 0;
+    const uint64_t n = ctx->shard.n_local;
+    const int grid = std::min(ctx->cu_count, (int)BLOCK);
+    const uint64_t per_round = (uint64_t)grid * BLOCK;
+    if (n < 2 || (n >> 1) + per_round >= (1ull << 28)) return 0;
+    const uint64_t total = ((n >> 1) + per_round - 1) / per_round;
+    constexpr uint64_t TILE_MAX = GC_ER + RES_LDS_PAIRS_MAX;
+    const uint64_t ntiles = (total + TILE_MAX - 1) / TILE_MAX;
+    const uint64_t tile = (total + ntiles - 1) / ntiles;  // balanced tiles of <= 96 rounds
+    const size_t lds_bytes = (size_t)RES_LDS_PAIRS_MAX * BLOCK * sizeof(d2);
+    const bool nt = n * sizeof(double) >= ctx->resident_nt_bytes;
+    auto kern = nt ? gram_combine_resident_kernel<true> : gram_combine_resident_kernel<false>;
+    const unsigned int bit = 1u << (30 + (nt ? 1 : 0));
+    if (!(ctx->resident_attr_mask & bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) !=
+            hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        ctx->resident_attr_mask |= bit;
+    }
+    GramCombArgs a{};
+    for (int j = 0; j < nb; ++j) a.in[j] = cols[j];
+    a.d = d; a.delta = delta; a.n = n; a.nb = nb;
+    a.total_rounds = (uint32_t)total;
+    a.tile_rounds = (uint32_t)tile;
+    RedCtl red{};
+    bool in_kernel_exchange = false;
+    double* outs2[2] = {dn, dn + 1};
+    const int rc_p = prep_red(ctx, red, 2, outs2, nullptr, 0, &in_kernel_exchange);
+    if (rc_p != LBFGS_HIP_OK) return rc_p;
+    {
+        ProfScope ps(ctx, LBFGS_HIP_K_TWOLOOP_STEP);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, a, red);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    if (!in_kernel_exchange) {
+        const int rc = allreduce(ctx, outs2, 2);
+        if (rc != LBFGS_HIP_OK) return rc;
+    }
+    return 1;
+}
+
 template <int M>
 int two_loop_gram_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, int bound, int end, int e1,
                        const double* gnum, const double* gden, double* dn) {
@@ -907,7 +956,15 @@ int two_loop_gram_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
         hipLaunchKernelGGL(gram_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, ga);
     }
     HIP_TRY(ctx, hipGetLastError());
-    // d = sum_j delta_j b_j, ||d||^2, g.d
+    // d = sum_j delta_j b_j, ||d||^2, g.d -- with d accumulated on the chip, one column at a time (gram_combine.h), or, where
+    // that kernel cannot run, as a streaming pass over all the columns at once
+    {
+        const double* cols[2 * M + 1];
+        for (int b = 0; b < M; ++b) { cols[b] = h->s[b]->p; cols[M + b] = h->y[b]->p; }
+        cols[2 * M] = g->p;
+        const int rr = gram_combine_resident(ctx, cols, 2 * M + 1, d->p, h->gram_delta, dn);
+        if (rr != 0) return rr < 0 ? rr : LBFGS_HIP_OK;
+    }
     OpGramCombine<M> cmb{};
     for (int b = 0; b < M; ++b) { cmb.in[b] = h->s[b]->p; cmb.in[M + b] = h->y[b]->p; }
     cmb.in[2 * M] = g->p;
@@ -1051,6 +1108,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     if (const char* e = getenv("LBFGS_HIP_DEFER_SUMS")) ctx->defer_inner_sums = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT")) ctx->resident_on = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_GRID")) ctx->resident_grid = std::max(0, atoi(e));
+    if (const char* e = getenv("LBFGS_HIP_GRAM_COMBINE_RESIDENT")) ctx->gram_combine_resident = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_LJ_BUILD_FP32")) ctx->lj_build_fp32 = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_HANDOFF_TIMEOUT_MS")) ctx->handoff_timeout_ticks = (unsigned long long)std::max(1, atoi(e)) * 100000ULL;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_NT_MB")) ctx->resident_nt_bytes = (size_t)std::max(0, atoi(e)) << 20;

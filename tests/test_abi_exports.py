@@ -171,10 +171,11 @@ def test_resident_kernels_own_their_accumulation_registers(libs):
         _build.build_hip(force=True)
     txt = open(_build.RESOURCES).read()
     audit = re.findall(r"^agpr-audit: (\S+) (\d+)$", txt, re.M)
-    assert len(audit) == 12, audit          # (5 register budgets + the hybrid form of the largest) x 2 cache-hint variants
+    # (5 register budgets + the hybrid form of the largest) x 2 cache-hint variants, + the vector-free combine kernel x 2
+    assert len(audit) == 14, audit
     assert all(int(n) == 0 for _, n in audit), audit
     for sym, _ in audit:
         blk = txt[txt.index("Function Name: " + sym):]
         vgprs = int(re.search(r" VGPRs: (\d+)", blk).group(1))
-        hybrid = "ELb1EEEv" in sym          # two_loop_resident_kernel<ER, NT, HYB = true>
+        hybrid = "two_loop_resident" in sym and "ELb1EEEv" in sym          # two_loop_resident_kernel<ER, NT, HYB = true>
         assert vgprs <= (244 if hybrid else 200), (sym, vgprs)   # (the audit above is the guarantee; this keeps a distance)
