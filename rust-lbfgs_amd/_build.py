@@ -51,7 +51,7 @@ def _audit_agprs(asm_text):
     """resident.h and gram_combine.h keep data in AGPRs by hand (inline asm).  Every AGPR operand the COMPILER emitted in those kernels --
     anything outside an inline-asm block -- would overwrite that data.  Returns {kernel symbol: count}."""
     out = {}
-    for m in re.finditer(r"^(_ZN2lh(?:24two_loop_resident_kernel|28gram_combine_resident_kernel)\w+):", asm_text, re.M):
+    for m in re.finditer(r"^(_ZN2lh(?:24two_loop_resident_kernel|28gram_combine_resident_kernel|25gram_rows_resident_kernel)\w+):", asm_text, re.M):
         body = asm_text[m.end(): asm_text.index("s_endpgm", m.end())]
         in_asm, n = False, 0
         for line in body.splitlines():

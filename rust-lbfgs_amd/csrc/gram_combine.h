@@ -162,4 +162,182 @@ void gram_combine_resident_kernel(const GramCombArgs a, const RedCtl red) {
     grid_reduce<2>(acc, red, c0);
 }
 
+
+// ---- the rows pass of the vector-free two-loop, the same way ---------------------------------------------------------
+// out[r * NB + p] = b_r . b_p for the three refreshed rows r (positions 0, 1, 2 = new s, new y, g) and all NB = 2m+1
+// positions p.  gram.h's kernel reads the 2m+1 vectors of an element at once (21 concurrent streams: 5.8 TB/s); here a
+// tile of the THREE ROW VECTORS (20 pairs per thread and row = 60 pairs = all the accumulation registers) stays on the
+// chip while the other columns are streamed past it one after the other.  Every thread keeps its 3 * NB running sums in
+// an LDS column of its own (129 KB per workgroup at m = 10); they meet in the usual two-stage reduction at the end.
+constexpr int GR_T = 20;                   // pairs per thread, row and tile
+constexpr int GR_TG = GR_T / RES_UNROLL;   // groups of four
+static_assert(3 * GR_T * 4 <= 256 && GR_T % RES_UNROLL == 0, "three row tiles in the AGPRs");
+
+struct GramRowsResArgs {
+    const double* in[GC_MAX_COLS];  // position order: 0, 1, 2 = the rows
+    uint64_t n;
+    int nb;
+    uint32_t total_rounds;          // ceil(pairs / (grid * BLOCK))
+};
+
+template <bool NT>
+__device__ __forceinline__ void gr_fetch(d2 (&uu)[RES_UNROLL], const uint32_t group, const uint32_t p_first, const uint32_t p_stride,
+                                         const uint32_t n2, const double* up) {
+    const uint32_t p0 = res_opaque(p_first) + group * RES_UNROLL * p_stride;
+#pragma unroll
+    for (int u = 0; u < RES_UNROLL; ++u) {
+        const uint32_t p = p0 + (uint32_t)u * p_stride;
+        const bool in = p < n2;
+        uu[u] = ld16<NT>(up, in ? p : 0u);  // (a valid address: masked below -- pairs past the end contribute zeros)
+        if (!in) uu[u] = d2{0.0, 0.0};
+    }
+}
+
+template <int G, bool NT>
+struct GrGroups {
+    // the row vectors' tile -> a[(R * GR_T + 4G + u) * 4 ..]
+    static __device__ __forceinline__ void load_rows(const uint32_t p_first, const uint32_t p_stride, const uint32_t n2,
+                                                     const double* r0, const double* r1, const double* r2) {
+        if constexpr (G < GR_TG) {
+            d2 a0[RES_UNROLL], a1[RES_UNROLL], a2[RES_UNROLL];
+            gr_fetch<NT>(a0, G, p_first, p_stride, n2, r0);
+            gr_fetch<NT>(a1, G, p_first, p_stride, n2, r1);
+            gr_fetch<NT>(a2, G, p_first, p_stride, n2, r2);
+            asm volatile("" ::: "memory");
+            acc_put<0 * GR_T + G * RES_UNROLL + 0>(a0[0]); acc_put<0 * GR_T + G * RES_UNROLL + 1>(a0[1]);
+            acc_put<0 * GR_T + G * RES_UNROLL + 2>(a0[2]); acc_put<0 * GR_T + G * RES_UNROLL + 3>(a0[3]);
+            acc_put<1 * GR_T + G * RES_UNROLL + 0>(a1[0]); acc_put<1 * GR_T + G * RES_UNROLL + 1>(a1[1]);
+            acc_put<1 * GR_T + G * RES_UNROLL + 2>(a1[2]); acc_put<1 * GR_T + G * RES_UNROLL + 3>(a1[3]);
+            acc_put<2 * GR_T + G * RES_UNROLL + 0>(a2[0]); acc_put<2 * GR_T + G * RES_UNROLL + 1>(a2[1]);
+            acc_put<2 * GR_T + G * RES_UNROLL + 2>(a2[2]); acc_put<2 * GR_T + G * RES_UNROLL + 3>(a2[3]);
+            GrGroups<G + 1, NT>::load_rows(p_first, p_stride, n2, r0, r1, r2);
+        }
+    }
+    // sum[r] += row_r . v over group G's four pairs (x then y of every pair, as gram.h)
+    static __device__ __forceinline__ void dot3(const d2 (&v)[RES_UNROLL], double* sum) {
+        const d2 s[RES_UNROLL] = {acc_get<0 * GR_T + G * RES_UNROLL + 0>(), acc_get<0 * GR_T + G * RES_UNROLL + 1>(),
+                                  acc_get<0 * GR_T + G * RES_UNROLL + 2>(), acc_get<0 * GR_T + G * RES_UNROLL + 3>()};
+        const d2 y[RES_UNROLL] = {acc_get<1 * GR_T + G * RES_UNROLL + 0>(), acc_get<1 * GR_T + G * RES_UNROLL + 1>(),
+                                  acc_get<1 * GR_T + G * RES_UNROLL + 2>(), acc_get<1 * GR_T + G * RES_UNROLL + 3>()};
+        const d2 g[RES_UNROLL] = {acc_get<2 * GR_T + G * RES_UNROLL + 0>(), acc_get<2 * GR_T + G * RES_UNROLL + 1>(),
+                                  acc_get<2 * GR_T + G * RES_UNROLL + 2>(), acc_get<2 * GR_T + G * RES_UNROLL + 3>()};
+#pragma unroll
+        for (int u = 0; u < RES_UNROLL; ++u) {
+            sum[0] += s[u].x * v[u].x; sum[0] += s[u].y * v[u].y;
+            sum[1] += y[u].x * v[u].x; sum[1] += y[u].y * v[u].y;
+            sum[2] += g[u].x * v[u].x; sum[2] += g[u].y * v[u].y;
+        }
+        res_pin(sum[0]); res_pin(sum[1]); res_pin(sum[2]);
+    }
+    // one column past the tile: `cur`, `nxt` = its loaded groups G, G+1 (two groups of loads ahead, as the combine pass)
+    static __device__ __forceinline__ void col(d2 (&cur)[RES_UNROLL], d2 (&nxt)[RES_UNROLL], const uint32_t p_first,
+                                               const uint32_t p_stride, const uint32_t n2, const double* up, double* sum) {
+        if constexpr (G < GR_TG) {
+            d2 far[RES_UNROLL];
+            gr_fetch<NT>(far, (G + 2 < GR_TG) ? (uint32_t)(G + 2) : (uint32_t)G, p_first, p_stride, n2, up);  // (past the end: unused)
+            asm volatile("" ::: "memory");
+            dot3(cur, sum);
+            GrGroups<G + 1, NT>::col(nxt, far, p_first, p_stride, n2, up, sum);
+        }
+    }
+    // the rows among themselves (positions 0, 1, 2), from the chip: s9[r * 3 + p]
+    static __device__ __forceinline__ void rows_rows(double* s9) {
+        if constexpr (G < GR_TG) {
+            const d2 s[RES_UNROLL] = {acc_get<0 * GR_T + G * RES_UNROLL + 0>(), acc_get<0 * GR_T + G * RES_UNROLL + 1>(),
+                                      acc_get<0 * GR_T + G * RES_UNROLL + 2>(), acc_get<0 * GR_T + G * RES_UNROLL + 3>()};
+            const d2 y[RES_UNROLL] = {acc_get<1 * GR_T + G * RES_UNROLL + 0>(), acc_get<1 * GR_T + G * RES_UNROLL + 1>(),
+                                      acc_get<1 * GR_T + G * RES_UNROLL + 2>(), acc_get<1 * GR_T + G * RES_UNROLL + 3>()};
+            const d2 g[RES_UNROLL] = {acc_get<2 * GR_T + G * RES_UNROLL + 0>(), acc_get<2 * GR_T + G * RES_UNROLL + 1>(),
+                                      acc_get<2 * GR_T + G * RES_UNROLL + 2>(), acc_get<2 * GR_T + G * RES_UNROLL + 3>()};
+#pragma unroll
+            for (int u = 0; u < RES_UNROLL; ++u) {
+                const d2 r[3] = {s[u], y[u], g[u]};
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) { s9[a * 3 + b] += r[a].x * r[b].x; s9[a * 3 + b] += r[a].y * r[b].y; }
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) res_pin(s9[k]);
+            GrGroups<G + 1, NT>::rows_rows(s9);
+        }
+    }
+};
+
+template <bool NT>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void gram_rows_resident_kernel(const GramRowsResArgs a, const RedCtl red) {
+    asm volatile("" ::: "a255");
+    extern __shared__ double gr_acc[];  // [3 * nb][BLOCK]: every thread's running sums
+    const unsigned int p2p_epoch0 = red.p2p.world > 1 ? red.ctr->p2p_epoch : 0u;  // read in the prologue (stream.h)
+    const int NB = a.nb, NK = 3 * NB;
+    const uint32_t n2 = (uint32_t)(a.n >> 1);
+    const uint32_t G = gridDim.x, B = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t p_stride = G * BLOCK;
+    for (int k = 0; k < NK; ++k) gr_acc[(size_t)k * BLOCK + tid] = 0.0;
+    for (uint32_t e_lo = 0; e_lo < a.total_rounds; e_lo += GR_T) {
+        const uint32_t p_first = (e_lo * G + B) * BLOCK + tid;
+        GrGroups<0, NT>::load_rows(p_first, p_stride, n2, a.in[0], a.in[1], a.in[2]);
+        {
+            double s9[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            GrGroups<0, NT>::rows_rows(s9);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) gr_acc[(size_t)(r * NB + p) * BLOCK + tid] += s9[r * 3 + p];
+        }
+        for (int p = 3; p < NB; ++p) {
+            const double* up = a.in[p];
+            double sum[3] = {0.0, 0.0, 0.0};
+            d2 cur[RES_UNROLL], nxt[RES_UNROLL];
+            gr_fetch<NT>(cur, 0u, p_first, p_stride, n2, up);
+            gr_fetch<NT>(nxt, 1u, p_first, p_stride, n2, up);
+            GrGroups<0, NT>::col(cur, nxt, p_first, p_stride, n2, up, sum);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) gr_acc[(size_t)(r * NB + p) * BLOCK + tid] += sum[r];
+        }
+    }
+    if ((a.n & 1) && B == G - 1 && tid == 0) {  // odd n: the last element
+        for (int r = 0; r < 3; ++r)
+            for (int p = 0; p < NB; ++p) gr_acc[(size_t)(r * NB + p) * BLOCK + tid] += a.in[r][a.n - 1] * a.in[p][a.n - 1];
+    }
+    // ---- per-thread sums -> one partial per (sum, workgroup): wave tree, waves in order; then gram.h's hand-off
+    __shared__ double s_w[WAVES][MAX_RED];
+    __shared__ unsigned int s_last;
+    for (int k = 0; k < NK; ++k) {
+        const double w = wave_sum(gr_acc[(size_t)k * BLOCK + tid]);
+        if (lane == 0) s_w[wave][k] = w;
+    }
+    __syncthreads();
+    if ((int)tid < NK) {
+        double t = s_w[0][tid];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) t += s_w[w][tid];
+        store_agent(red.partials + (size_t)tid * MAX_GRID + B, t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int tk = __hip_atomic_fetch_add(red.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (tk == G - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last == 0u) return;
+    __shared__ double s_vals[MAX_RED];
+    for (int k = wave; k < NK; k += WAVES) {  // (the last workgroup, as gram.h: lane-strided partials, then the wave tree)
+        double s = 0.0;
+        for (unsigned int b = lane; b < G; b += 64) s += load_agent(red.partials + (size_t)k * MAX_GRID + b);
+        s = wave_sum(s);
+        if (lane == 0) s_vals[k] = s;
+    }
+    __syncthreads();
+    if (red.p2p.world > 1) {
+        __shared__ unsigned int s_bits[P2P_MAX_WORLD][MAX_RED][2];
+        p2p_exchange(red.p2p, p2p_epoch0, s_vals, NK, s_bits);
+        if (tid == 0) red.ctr->p2p_epoch = next_epoch(p2p_epoch0);
+    }
+    for (int k = tid; k < NK; k += BLOCK) red.out_contig[k] = s_vals[k];
+    if (tid == 0) __hip_atomic_store(red.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace lh

@@ -167,7 +167,7 @@ struct lbfgs_hip_ctx {
     struct LjCells* lj_cells = nullptr;   // LJ_CELLS: the rebuildable neighbour structure (allocated on demand)
     unsigned long long* gran = nullptr;   // tagged partial granules [MAX_RED][MAX_GRID][2] (stream.h)
     bool p2p_exclusive = false;           // lbfgs_hip_comm.exclusive_device: no other rank shares this GPU
-    unsigned int resident_attr_mask = 0;  // which resident kernels have had their dynamic-LDS limit raised on this device
+    unsigned long long resident_attr_mask = 0;  // which resident kernels have had their dynamic-LDS limit raised on this device
     int gram_combine_resident = 1;        // LBFGS_HIP_GRAM_COMBINE_RESIDENT=0: the vector-free combine as one streaming pass over all columns
     int lj_build_fp32 = 1;                // LBFGS_HIP_LJ_BUILD_FP32=0: the LJ_CELLS list from double-precision candidate tests
     size_t resident_nt_bytes = (size_t)16 << 20;  // LBFGS_HIP_RESIDENT_NT_MB
@@ -200,6 +200,7 @@ struct lbfgs_hip_ctx {
     int cu_count = 0;
     int grid_override = 0;
     int gram_grid = 0;  // workgroups of the Gram rows kernel (0 = same as the others)
+    bool gram_grid_forced = false;
     size_t nt_threshold_bytes = (size_t)128 << 20;  // measured crossover: 95 MiB vectors prefer plain, 190 MiB prefer nt
     size_t nt_store_threshold_bytes = (size_t)64 << 20;  // from here up to nt_threshold_bytes: `nt` on the STORES only
     bool prof_on = false;
@@ -859,6 +860,36 @@ int prof_drain(lbfgs_hip_ctx* ctx) {
 }  // namespace
 
 namespace {
+// the rows pass with the row vectors' tiles on the chip (gram_combine.h): -> true if launched (red is set up by the caller)
+bool gram_rows_resident(lbfgs_hip_ctx* ctx, const double* const* in, int nb, const RedCtl& red) {
+    if (!ctx->resident_on || !ctx->gram_combine_resident || ctx->capturing || ctx->grid_override > 0 || ctx->gram_grid_forced ||
+        nb > GC_MAX_COLS || 3 * nb > MAX_RED)
+        return false;
+    const uint64_t n = ctx->shard.n_local;
+    const int grid = std::min(ctx->cu_count, (int)BLOCK);
+    const uint64_t per_round = (uint64_t)grid * BLOCK;
+    if (n < 2 || (n >> 1) + per_round * (GR_T + 1) >= (1ull << 28)) return false;
+    const size_t lds_bytes = (size_t)3 * nb * BLOCK * sizeof(double);
+    if (lds_bytes > (size_t)150 * 1024) return false;  // (m <= 11: the sums of a workgroup must fit its LDS next to the static part)
+    const bool nt = n * sizeof(double) >= ctx->resident_nt_bytes;
+    auto kern = nt ? gram_rows_resident_kernel<true> : gram_rows_resident_kernel<false>;
+    const unsigned long long bit = 1ull << (42 + (nt ? 1 : 0));
+    if (!(ctx->resident_attr_mask & bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) !=
+            hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        ctx->resident_attr_mask |= bit;
+    }
+    GramRowsResArgs a{};
+    for (int j = 0; j < nb; ++j) a.in[j] = in[j];
+    a.n = n; a.nb = nb;
+    a.total_rounds = (uint32_t)(((n >> 1) + per_round - 1) / per_round);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, a, red);
+    return true;
+}
+
 // -> 1 launched, 0 not eligible (the caller streams all columns at once), < 0 error.  dn: ||d||^2, g.d
 int gram_combine_resident(lbfgs_hip_ctx* ctx, const double* const* cols, int nb, double* d, const double* delta, double* dn) {
     if (!ctx->resident_on || !ctx->gram_combine_resident || ctx->handoff_ticket || ctx->capturing || ctx->grid_override > 0 ||
@@ -875,7 +906,7 @@ int gram_combine_resident(lbfgs_hip_ctx* ctx, const double* const* cols, int nb,
     const size_t lds_bytes = (size_t)RES_LDS_PAIRS_MAX * BLOCK * sizeof(d2);
     const bool nt = n * sizeof(double) >= ctx->resident_nt_bytes;
     auto kern = nt ? gram_combine_resident_kernel<true> : gram_combine_resident_kernel<false>;
-    const unsigned int bit = 1u << (30 + (nt ? 1 : 0));
+    const unsigned long long bit = 1ull << (40 + (nt ? 1 : 0));
     if (!(ctx->resident_attr_mask & bit)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) !=
             hipSuccess) {
@@ -934,7 +965,9 @@ int two_loop_gram_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
         const uint64_t n = ctx->shard.n_local;
         const int grid = ctx->gram_grid > 0 ? ctx->gram_grid : grid_for(ctx);
         ProfScope ps(ctx, LBFGS_HIP_K_TWOLOOP_STEP);
-        if (n * sizeof(double) >= ctx->nt_threshold_bytes)
+        if (gram_rows_resident(ctx, rows.in, NB, red)) {
+            // (the three row vectors' tiles on the chip, the other columns streamed past them: gram_combine.h)
+        } else if (n * sizeof(double) >= ctx->nt_threshold_bytes)
             hipLaunchKernelGGL((gram_rows_kernel<M, true, GRAM_ROWS_UNROLL>), dim3(grid), dim3(BLOCK), 0, ctx->stream, rows, n, red);
         else
             hipLaunchKernelGGL((gram_rows_kernel<M, false, GRAM_ROWS_UNROLL>), dim3(grid), dim3(BLOCK), 0, ctx->stream, rows, n, red);
@@ -1116,7 +1149,10 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     if (const char* e = getenv("LBFGS_HIP_GRAPH")) ctx->graph_max_bytes = atoi(e) ? ~(size_t)0 : 0;
     if (const char* e = getenv("LBFGS_HIP_GRAPH_MAX_MB")) ctx->graph_max_bytes = (size_t)atoll(e) << 20;
     if (const char* e = getenv("LBFGS_HIP_NT_STORE_THRESHOLD_MB")) ctx->nt_store_threshold_bytes = (size_t)atoll(e) << 20;
-    if (const char* e = getenv("LBFGS_HIP_GRAM_GRID")) ctx->gram_grid = std::min(MAX_GRID, std::max(0, atoi(e)));
+    if (const char* e = getenv("LBFGS_HIP_GRAM_GRID")) {  // (asking for a grid asks for the streaming rows kernel)
+        ctx->gram_grid = std::min(MAX_GRID, std::max(0, atoi(e)));
+        ctx->gram_grid_forced = true;
+    }
     for (int k = 0; k < LBFGS_HIP_K_CLASSES && k < 16; ++k) {
         char name[32];
         snprintf(name, sizeof(name), "LBFGS_HIP_GRID_K%d", k);
@@ -1669,7 +1705,7 @@ int resident_launch(lbfgs_hip_ctx* ctx, const ResArgs& ra, const RedCtl& red, in
     auto kern_nt = two_loop_resident_kernel<ER, true, HYB>;
     auto kern_pl = two_loop_resident_kernel<ER, false, HYB>;
     // more than 64 KiB of dynamic LDS has to be asked for, once per kernel AND device: remembered in the context
-    const unsigned int bit = 1u << ((ER / 8 + (HYB ? 8 : 0)) * 2 + (nt ? 1 : 0));  // ER/8 in {0, 1, 3, 5, 7}
+    const unsigned long long bit = 1ull << ((ER / 8 + (HYB ? 8 : 0)) * 2 + (nt ? 1 : 0));  // ER/8 in {0, 1, 3, 5, 7}: bits 0..31
     if (!(ctx->resident_attr_mask & bit)) {
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(nt ? kern_nt : kern_pl),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, RES_LDS_PAIRS_MAX * BLOCK * (int)sizeof(d2)));

@@ -171,8 +171,8 @@ def test_resident_kernels_own_their_accumulation_registers(libs):
         _build.build_hip(force=True)
     txt = open(_build.RESOURCES).read()
     audit = re.findall(r"^agpr-audit: (\S+) (\d+)$", txt, re.M)
-    # (5 register budgets + the hybrid form of the largest) x 2 cache-hint variants, + the vector-free combine kernel x 2
-    assert len(audit) == 14, audit
+    # (5 register budgets + the hybrid form of the largest) x 2 cache-hint variants, + the vector-free combine and rows kernels x 2 each
+    assert len(audit) == 16, audit
     assert all(int(n) == 0 for _, n in audit), audit
     for sym, _ in audit:
         blk = txt[txt.index("Function Name: " + sym):]
