@@ -13,20 +13,26 @@ history update (which also forms the accepted x and g) and the fused two-loop re
 the n-vector is sharded contiguously over the ranks (total work fixed => "strong" scaling) and every
 reduction is closed by an all-reduce of its f64 scalars.
 
-Process structure.  N = 1 runs in this process.  N > 1 never measures in the process the user (or
-torch.distributed.run) started: that process is a SUPERVISOR that touches no GPU and runs one fresh
-child job per communicator ("leg"), each under a wall-clock timeout:
-  * `python bench.py --gpus N` (no RANK in the environment): per leg one
+Process structure.  N = 1 runs in this process (its CPU baseline runs BESIDE the GPU work, in a child pinned to one
+core).  N > 1 never measures in the process the user (or torch.distributed.run) started: that process is a SUPERVISOR
+that touches no GPU and runs fresh child jobs, each under a wall-clock timeout and all of them inside ONE total budget
+(--total-budget, default 520 s: the driver allows 600):
+  * `python bench.py --gpus N` (no RANK in the environment): per job one
     `python -m torch.distributed.run --nproc-per-node N bench.py --_rank-mode --comm <leg>` child;
   * launched by torch.distributed.run (RANK set): every rank is a supervisor (gloo group, CPU only);
-    rank 0 picks a fresh rendezvous port per leg and each rank starts ITS child
+    rank 0 decides, picks a fresh rendezvous port per job, and each rank starts ITS child
     `python bench.py --_rank-mode --comm <leg>` with the same RANK / LOCAL_RANK / WORLD_SIZE.
-Legs, in this order: "p2p" (direct xGMI mailbox exchange inside the reducing kernels -- the path the
-multi-process tests cover; the two-loop runs as one persistent kernel), "p2p-per-step" (the same
-communicator with a kernel per two-loop step) only if the p2p leg failed, then "rccl" (ncclAllReduce on
-the compute stream); "callback" (host-staged all-reduce through gloo) only if none produced a result.  A leg that fails or hangs is reported in
-`config.legs`; the run prints ONE JSON line with the best leg as `value` and exits 0 if any leg
-succeeded.
+Phase 1, PROBES: per communicator one short job (<= --probe-timeout) that only creates the context and runs its
+start-up self-test (known-answer reductions, a reduction closed inside a streaming kernel, a whole two-loop recursion with
+an exact answer).  Phase 2, MEASUREMENTS, only for communicators whose probe passed, each with a share of what is left of
+the budget: "p2p" (direct exchange inside the reducing kernels, mailboxes in device memory mapped over xGMI; the two-loop
+runs as one persistent kernel), "p2p-per-step" (the same communicator with a kernel per two-loop step) only if the p2p
+MEASUREMENT failed, "rccl" (ncclAllReduce on the compute stream), "p2p-host" (the p2p exchange with host-coherent
+mailboxes: the placement a machine falls back to when device memory cannot be mapped between its GPUs; tried before rccl
+when p2p gave nothing), "callback" (host-staged all-reduce through gloo) only if nothing produced a result.  Every job's
+outcome is echoed to stderr as it lands; SIGTERM / SIGINT kill the running job and print the best line so far.  The run
+prints ONE JSON line with the best leg as `value`, every probe and leg in `config.probes` / `config.legs`, and exits 0 if
+any leg succeeded.
 
 Timing.  W warm-up steps (plus whatever fills the history: bound = m before anything is timed), then
 EXACTLY K steps between barrier + synchronize on both sides, max over ranks.  That K-step region is
@@ -63,8 +69,12 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--dim", dest="n", type=int, default=100_000_000, help="n, the number of variables")
     ap.add_argument("--hist", dest="m", type=int, default=10, help="m, the number of L-BFGS corrections")
-    ap.add_argument("--repeats", type=int, default=5,
-                    help="how many times the K-step timed region is measured (median reported)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="how many times the K-step timed region is measured (median reported); 0 = as many as it takes to "
+                         "time --min-timed-seconds of iterations, at least 5 and at most 40")
+    ap.add_argument("--min-timed-seconds", type=float, default=5.0,
+                    help="--repeats 0: total length of the timed regions (the GPU is busy about twice as long: every repeat "
+                         "rebuilds its state and warms up)")
     ap.add_argument("--no-prof", action="store_true", help="do not time kernels with HIP events in the timed region")
     ap.add_argument("--prof-every", type=int, default=5,
                     help="time kernels with HIP events on every k-th step of the timed region only: an event pair per "
@@ -74,12 +84,17 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-full", action="store_true",
                     help="skip the CPU baseline at the metric's own n (needs (2m+7)*8n bytes of host memory, ~50 s)")
     ap.add_argument("--grid", type=int, default=0, help="workgroups per launch (0 = library default)")
-    ap.add_argument("--comm", default="auto", choices=["auto", "rccl", "p2p", "callback"],
-                    help="N>1: how scalars are all-reduced (auto = p2p, then rccl; callback if both fail)")
+    ap.add_argument("--comm", default="auto", choices=["auto", "rccl", "p2p", "p2p-host", "callback"],
+                    help="N>1: how scalars are all-reduced (auto = p2p, rccl and p2p-host, each probed first; callback if none works)")
     ap.add_argument("--pg-backend", default="auto",
                     help="torch.distributed backend of a rank process, used for rendezvous, barriers and the max over "
                          "ranks (auto = nccl for the rccl leg, gloo otherwise)")
-    ap.add_argument("--leg-timeout", type=float, default=420.0, help="N>1: wall-clock bound on one communicator leg (s)")
+    ap.add_argument("--leg-timeout", type=float, default=150.0,
+                    help="N>1: upper bound on one measurement job (s); the actual bound is its share of what is left of --total-budget")
+    ap.add_argument("--total-budget", type=float, default=520.0,
+                    help="N>1: wall-clock budget of the whole run (s): probes and legs get their timeouts from what is left of it")
+    ap.add_argument("--probe-timeout", type=float, default=30.0,
+                    help="N>1: bound on one communicator probe (s); the first probe gets twice that (it pays the box's cold start)")
     ap.add_argument("--no-vector-free", action="store_true",
                     help="skip the extra measurement of the vector-free (Gram) two-loop extension")
     ap.add_argument("--line-eval", type=int, default=2, choices=[0, 1, 2],
@@ -90,6 +105,8 @@ def parse(argv=None):
                     help="tell the communicator that every rank owns its GPU (-1: yes unless --device is given); experiments "
                          "with several ranks on ONE GPU pass 1 together with LBFGS_HIP_RESIDENT_GRID = CUs / ranks")
     ap.add_argument("--_rank-mode", dest="rank_mode", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--_probe", dest="probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--_cpu-baseline-child", dest="cpu_child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
 
@@ -119,8 +136,20 @@ def host_info():
     return model, cores, usable, avail
 
 
+def pin_to_one_core():
+    """Pin this process to ONE of the cores it may use (the last one: furthest from core 0, where the kernel and the GPU
+    driver's interrupt handling tend to live).  -> the core, or None where the platform has no affinity call."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, {cores[-1]})
+        return cores[-1]
+    except (AttributeError, OSError, IndexError):
+        return None
+
+
 def oracle_ips(n, m, timed):
-    """iterations/sec of the oracle (C restatement of the reference's sequential arithmetic) on one host core."""
+    """The oracle (C restatement of the reference's sequential arithmetic) on one host core: `timed` iterations, each timed
+    on its own, after the history has filled.  -> (iterations/sec of the MEDIAN iteration, of the FASTEST one, warm-up count)."""
     import numpy as np
 
     from oracle import oracle as O
@@ -130,26 +159,31 @@ def oracle_ips(n, m, timed):
     warm = m + 2  # the history is full (bound = m) from iteration m+2 on
     for _ in range(warm):
         st.propagate()
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(timed):
+        t0 = time.perf_counter()
         st.propagate()
-    dt = time.perf_counter() - t0
+        ts.append(time.perf_counter() - t0)
     st.close()
-    return timed / dt, warm
+    ts.sort()
+    med = ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
+    return 1.0 / med, 1.0 / ts[0], warm
 
 
 def cpu_baseline(a):
     model, cores, usable, avail = host_info()
-    ips_s, warm_s = oracle_ips(a.cpu_n, a.m, 6)
+    core = pin_to_one_core()
+    ips_s, best_s, warm_s = oracle_ips(a.cpu_n, a.m, 6)
     scaled = ips_s * a.cpu_n / a.n
     out = {
         "value": scaled, "unit": "iters/sec", "cores": 1, "kind": "port",
-        "host_cpu": model, "host_cores_total": cores, "host_cores_usable": usable,
-        "sampled_and_scaled": {"value": scaled, "n_sample": a.cpu_n, "iters_per_sec_at_n_sample": ips_s,
-                               "timed_iterations": 6, "warmup_iterations": warm_s},
-        "sample": f"oracle (gcc -O2 -ffp-contract=off, sequential sums, 1 thread) on the same quadratic at n={a.cpu_n}, m={a.m}: "
-                  f"6 iterations after {warm_s} warm-up = {ips_s:.3f} iters/sec, scaled by n_sample/n (every pass is O(n)) "
-                  f"to n={a.n}",
+        "host_cpu": model, "host_cores_total": cores, "host_cores_usable": usable, "pinned_to_core": core,
+        "value_is": "1 / (median of the separately timed iterations)",
+        "sampled_and_scaled": {"value": scaled, "best": best_s * a.cpu_n / a.n, "n_sample": a.cpu_n,
+                               "iters_per_sec_at_n_sample": ips_s, "timed_iterations": 6, "warmup_iterations": warm_s},
+        "sample": f"oracle (gcc -O2 -ffp-contract=off, sequential sums, 1 thread pinned to one core) on the same quadratic at "
+                  f"n={a.cpu_n}, m={a.m}: median of 6 iterations after {warm_s} warm-up = {ips_s:.3f} iters/sec, scaled by "
+                  f"n_sample/n (every pass is O(n)) to n={a.n}",
     }
     need = (2 * a.m + 9) * 8 * a.n  # 2m history + 7 problem vectors (+ the caller's x and slack)
     if a.no_cpu_full or a.n <= a.cpu_n:
@@ -158,16 +192,54 @@ def cpu_baseline(a):
         out["full_size"] = f"skipped: needs {need / 1e9:.1f} GB of host memory, {0 if avail is None else avail / 1e9:.1f} GB available"
         return out
     try:
-        ips_f, warm_f = oracle_ips(a.n, a.m, 3)
+        ips_f, best_f, warm_f = oracle_ips(a.n, a.m, 3)
     except Exception as e:  # noqa: BLE001  (MemoryError included)
         out["full_size"] = f"failed: {e!r}"
         return out
     out["value"] = ips_f
-    out["full_size"] = {"value": ips_f, "n": a.n, "timed_iterations": 3, "warmup_iterations": warm_f}
-    out["sample"] = (f"oracle (gcc -O2 -ffp-contract=off, sequential sums, 1 thread) on the metric's own configuration n={a.n}, "
-                     f"m={a.m}: 3 iterations after {warm_f} warm-up = {ips_f:.4f} iters/sec (sampled at n={a.cpu_n} and scaled: "
-                     f"{scaled:.4f})")
+    out["full_size"] = {"value": ips_f, "best": best_f, "n": a.n, "timed_iterations": 3, "warmup_iterations": warm_f}
+    out["sample"] = (f"oracle (gcc -O2 -ffp-contract=off, sequential sums, 1 thread pinned to one core) on the metric's own "
+                     f"configuration n={a.n}, m={a.m}: median of 3 separately timed iterations after {warm_f} warm-up = "
+                     f"{ips_f:.4f} iters/sec (fastest: {best_f:.4f}; sampled at n={a.cpu_n} and scaled: {scaled:.4f}); timed in a "
+                     f"child process while the GPU measurement ran")
     return out
+
+
+def cpu_baseline_child_main(a):
+    """`bench.py --_cpu-baseline-child`: the CPU baseline alone, as ONE JSON line (the N = 1 run starts this before its GPU
+    work and collects the line afterwards, so the ~45 s of CPU time overlap the GPU measurement instead of following it)."""
+    out = cpu_baseline(a)
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+def start_cpu_baseline(a):
+    """-> Popen of the child above (never touches a GPU), or None."""
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--_cpu-baseline-child", "--dim", str(a.n), "--hist", str(a.m),
+            "--cpu-n", str(a.cpu_n)]
+    if a.no_cpu_full:
+        args.append("--no-cpu-full")
+    env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    try:
+        return subprocess.Popen(args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    except OSError as e:
+        print(f"[bench] cpu baseline child not started: {e}", file=sys.stderr)
+        return None
+
+
+def collect_cpu_baseline(child, a, timeout=420.0):
+    if child is None:
+        return cpu_baseline(a)  # in this process, after the GPU work
+    try:
+        out, _ = child.communicate(timeout=timeout)
+        j = last_json(out)
+        if j is not None and "value" in j:
+            return j
+        return {"value": None, "unit": "iters/sec", "cores": 1, "kind": "port", "sample": f"the baseline child printed no result (exit code {child.returncode})"}
+    except subprocess.TimeoutExpired:
+        child.kill()
+        return {"value": None, "unit": "iters/sec", "cores": 1, "kind": "port", "sample": f"the baseline child did not finish within {timeout:.0f} s"}
 
 
 # ======================================================================================== one rank
@@ -234,8 +306,10 @@ def make_context(env, kind):
         return R.Context(a.n, device=env.dev), "none"
     ok, ctx = 1.0, None
     try:
-        # one rank per GPU (the driver's launch) unless --device forces several ranks onto one card (tests)
-        ctx = sharded_context(a.n, device=env.dev, kind=kind, exclusive_device=(a.device < 0) if a.exclusive_device < 0 else bool(a.exclusive_device))
+        # one rank per GPU (the driver's launch) unless --device forces several ranks onto one card (tests).
+        # The "p2p" leg means mailboxes in DEVICE memory, strictly (no silent retry: host placement is its own leg).
+        ctx = sharded_context(a.n, device=env.dev, kind={"p2p": "p2p-device"}.get(kind, kind),
+                              exclusive_device=(a.device < 0) if a.exclusive_device < 0 else bool(a.exclusive_device))
         # known-answer reductions through the real code path before trusting it
         tri = env.world * (env.world + 1) / 2.0
         for it in range(16):
@@ -342,7 +416,11 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
 
     ok = 1.0
     dts, ncalls = [], 0
-    for rep in range(max(1, repeats)):
+    auto = repeats <= 0
+    nrep = 5 if auto else repeats
+    rep = -1
+    while rep + 1 < nrep:
+        rep += 1
         try:
             if ok:
                 fresh()
@@ -372,6 +450,10 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
         ok = env.reduce(ok, "MIN")
         if ok != 1.0:
             break
+        if auto and rep == 0:
+            # as many repeats as it takes to time --min-timed-seconds of iterations (the same number on every rank: dts[0] is
+            # the max over ranks), so that the run holds the GPU long enough for an outside observer to see it busy
+            nrep = int(min(40, max(5, -(-a.min_timed_seconds // max(dts[0], 1e-6)))))
     res = None
     if ok == 1.0:
         ctx.prof_enable(False)
@@ -448,9 +530,14 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
                 "allreduce": ms_comm / sampled, "allreduce_launches": nc / sampled, "sampled_steps": nt}
         srt = sorted(dts)
         med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+        first = prefill + a.warmup + 1  # LbfgsState::propagate calls count from 1 (the first is a no-op: lbfgs.rs:507-510)
         res = dict(label=label, value=a.steps / med, ms_per_step=med / a.steps * 1e3, roofline=roof, n_local=n_local,
                    prefill=prefill, trials=ncalls / max(a.steps * len(dts), 1), restarts=hold["restarts"],
-                   repeats=[round(a.steps / d, 3) for d in dts], best=a.steps / srt[0], timed_s=sum(dts))
+                   repeats=[round(a.steps / d, 3) for d in dts], best=a.steps / srt[0], timed_s=sum(dts),
+                   window={"first_iteration": first, "last_iteration": first + a.steps - 1,
+                           "line_search_trials_per_step": ncalls / max(a.steps * len(dts), 1),
+                           "note": "every repeat times the SAME iterations of a freshly built run (propagate calls, counted from 1); "
+                                   "later iterations of this problem need fewer line-search trials and read faster"})
     if hold["state"] is not None:
         try:
             hold["state"].close()
@@ -495,6 +582,7 @@ def compose(a, world, results, ext, legs=None):
            "line_search_trials_per_step": best["trials"], "restarts": best["restarts"],
            "repeats": len(best["repeats"]), "repeats_iters_per_sec": best["repeats"],
            "best_repeat_iters_per_sec": round(best["best"], 3), "timed_seconds": round(best["timed_s"], 3),
+           "timed_window": best["window"],
            "value_is": "median over the repeats of K steps / (max over ranks of the K-step wall time)",
            "allreduce": best["label"],
            "allreduce_measured_iters_per_sec": {r["label"]: round(r["value"], 3) for r in results},
@@ -520,7 +608,8 @@ def compose(a, world, results, ext, legs=None):
 
 
 def worker_main(a):
-    """One rank: measures ONE communicator (N = 1: none) and, on rank 0, prints the line."""
+    """One rank: measures ONE communicator (N = 1: none) and, on rank 0, prints the line.  --_probe: only the context and
+    its start-up self-test (a supervisor's phase 1)."""
     # stdout carries exactly ONE JSON line: RCCL, gloo and friends print banners to fd 1, so park it on stderr
     sys.stdout.flush()
     real_stdout = os.dup(1)
@@ -530,13 +619,28 @@ def worker_main(a):
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env > 1 and comm == "auto":
         comm = "p2p"
+    # N = 1: the CPU baseline (~45 s on one core at the metric's size) runs BESIDE the GPU work, in a child pinned to one
+    # core that is started first and collected last
+    cpu_child = None
+    if world_env <= 1 and not a.no_cpu_baseline and not a.probe and "RANK" not in os.environ:
+        cpu_child = start_cpu_baseline(a)
     env = Env(a, comm)
     a.gpus = env.world
 
     import rust_lbfgs_amd  # noqa: F401  (fails loudly if the HIP extension is not built)
 
     results, ext = [], {}
+    t_ctx = time.perf_counter()
     ctx, label = make_context(env, comm if env.world > 1 else "none")
+    if a.probe:
+        placement = getattr(ctx, "p2p_placement", None) if ctx is not None else None
+        if ctx is not None:
+            ctx.close()
+        env.finish()
+        if env.rank == 0 and ctx is not None:
+            os.write(real_stdout, (json.dumps({"probe": "ok", "comm": label, "mailboxes": placement,
+                                               "seconds": round(time.perf_counter() - t_ctx, 2)}) + "\n").encode())
+        return 0 if ctx is not None else 4
     if ctx is not None:
         r = measure(env, ctx, label, repeats=a.repeats)
         if r is not None:
@@ -548,11 +652,13 @@ def worker_main(a):
                         r["roofline"]["frac_of_copy"] = r["roofline"]["achieved"] / cal["copy_1r1w_GBps"]
                 except Exception as e:  # noqa: BLE001
                     print(f"[bench] calibration skipped: {e}", file=sys.stderr)
+            if getattr(ctx, "p2p_placement", None):
+                r["mailboxes"] = ctx.p2p_placement
             results.append(r)
             if not a.no_vector_free and a.m <= 10:
                 # EXTENSION, reported beside the headline, never as `value`: the same iteration with the
                 # two-loop carried out in Gram-coefficient space (4m+3 passes, 2 all-reduces)
-                rv = measure(env, ctx, label + "+vector_free", vector_free=True, repeats=min(a.repeats, 3))
+                rv = measure(env, ctx, label + "+vector_free", vector_free=True, repeats=3 if a.repeats <= 0 else min(a.repeats, 3))
                 if rv is not None:
                     tl = rv["roofline"].get("two_loop", {})
                     ext[label] = {"iters_per_sec": round(rv["value"], 3), "two_loop_ms": tl.get("ms"),
@@ -567,8 +673,13 @@ def worker_main(a):
             rc = 3
         else:
             out = compose(a, env.world, results, ext)
+            if results[0].get("mailboxes"):
+                out["config"]["p2p_mailboxes"] = results[0]["mailboxes"]
             if env.world == 1 and not a.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(a)
+                out["cpu_baseline"] = collect_cpu_baseline(cpu_child, a)
+                cpu_child = None
+    if cpu_child is not None:
+        cpu_child.kill()
     env.finish()
     if out is not None:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
@@ -584,13 +695,19 @@ def free_port():
     return p
 
 
-def passthrough(a, leg):
+LEG_COMM = {"p2p": "p2p", "p2p-per-step": "p2p", "p2p-host": "p2p-host", "rccl": "rccl", "callback": "callback"}
+
+
+def passthrough(a, leg, probe=False, vector_free=True):
     args = ["--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup), "--dim", str(a.n), "--hist",
-            str(a.m), "--repeats", str(a.repeats), "--prof-every", str(a.prof_every), "--line-eval", str(a.line_eval),
-            "--pg-backend", a.pg_backend, "--comm", leg.split("-")[0], "--no-cpu-baseline", "--_rank-mode"]
+            str(a.m), "--repeats", str(a.repeats), "--min-timed-seconds", str(a.min_timed_seconds), "--prof-every",
+            str(a.prof_every), "--line-eval", str(a.line_eval), "--pg-backend", a.pg_backend, "--comm", LEG_COMM[leg],
+            "--no-cpu-baseline", "--_rank-mode"]
+    if probe:
+        args.append("--_probe")
     if a.no_prof:
         args.append("--no-prof")
-    if a.no_vector_free:
+    if a.no_vector_free or not vector_free:
         args.append("--no-vector-free")
     if a.grid:
         args += ["--grid", str(a.grid)]
@@ -601,31 +718,43 @@ def passthrough(a, leg):
     return args
 
 
-def run_child(cmd, env, timeout):
-    """-> (status, stdout).  The child gets its own process group, so a hung leg is killed with all its descendants
-    (torch.distributed.run's workers included); never a re-exec of this process."""
+class Job:
+    """The child job that is running right now (so that a signal handler can end it)."""
+    proc = None
+
+
+def kill_group(p):
     import signal
 
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        try:
+            os.killpg(p.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            break
+        try:
+            p.wait(timeout=5)
+            break
+        except subprocess.TimeoutExpired:
+            continue
+
+
+def run_child(cmd, env, timeout):
+    """-> (status, stdout).  The child gets its own process group, so a hung job is killed with all its descendants
+    (torch.distributed.run's workers included); never a re-exec of this process."""
     p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=None, text=True, start_new_session=True)
+    Job.proc = p
     try:
-        out, _ = p.communicate(timeout=timeout)
+        out, _ = p.communicate(timeout=max(1.0, timeout))
         return ("ok" if p.returncode == 0 else f"exit code {p.returncode}"), out
     except subprocess.TimeoutExpired:
-        for sig in (signal.SIGTERM, signal.SIGKILL):
-            try:
-                os.killpg(p.pid, sig)
-            except ProcessLookupError:
-                break
-            try:
-                p.wait(timeout=10)
-                break
-            except subprocess.TimeoutExpired:
-                continue
+        kill_group(p)
         try:
             out, _ = p.communicate(timeout=5)
         except Exception:  # noqa: BLE001
             out = ""
         return f"timed out after {timeout:.0f} s (killed)", out or ""
+    finally:
+        Job.proc = None
 
 
 def last_json(text):
@@ -640,7 +769,12 @@ def last_json(text):
 
 
 def supervisor_main(a):
-    """N > 1.  This process never touches a GPU: it runs one child job per communicator leg under a timeout."""
+    """N > 1.  This process never touches a GPU: it runs child jobs -- a probe per communicator, then a measurement per
+    communicator that passed -- each under a timeout that is its share of what is left of ONE total budget."""
+    import signal
+
+    t_start = time.monotonic()
+    left = lambda: a.total_budget - (time.monotonic() - t_start)  # noqa: E731
     # stdout carries exactly ONE JSON line (gloo prints connection banners to fd 1): park it on stderr
     sys.stdout.flush()
     real_stdout = os.dup(1)
@@ -649,6 +783,52 @@ def supervisor_main(a):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ["WORLD_SIZE"]) if under_launcher else a.gpus
     a.gpus = world
+    probes, report, lines = {}, {}, []
+    state = {"done": False}
+
+    def final_line():
+        """the best measurement so far as the run's line (None if there is none)"""
+        if not lines:
+            return None
+        leg, best = max(lines, key=lambda t: t[1]["value"])
+        best = json.loads(json.dumps(best))
+        cfg = best["config"]
+        cfg["probes"], cfg["legs"] = probes, report
+        cfg["allreduce"] = leg
+        cfg["allreduce_measured_iters_per_sec"] = {lg: round(j["value"], 3) for lg, j in lines}
+        ext = {}
+        for lg, j in lines:
+            for k, v in (j["config"].get("extension_vector_free_two_loop") or {}).items():
+                ext[lg] = v
+        cfg["extension_vector_free_two_loop"] = ext
+        cfg["launch"] = ("torch.distributed.run ranks as supervisors, one child rank each per job"
+                         if under_launcher else "self-launched: one torch.distributed.run child per job")
+        cfg["budget"] = {"total_s": a.total_budget, "used_s": round(time.monotonic() - t_start, 1)}
+        return best
+
+    def on_signal(signum, _frame):
+        # the driver (or torch.distributed.run, on its behalf) wants this run to end NOW: end the running job and hand over
+        # whatever has been measured -- a line from the legs that finished is worth more than none
+        if state["done"]:
+            return
+        state["done"] = True
+        pgid = Job.proc.pid if Job.proc is not None else None
+        if Job.proc is not None:
+            kill_group(Job.proc)
+        rc = 1
+        if rank == 0:
+            best = final_line()
+            print(f"[bench] signal {signum}: stopping with {len(lines)} measured leg(s); running job's process group: {pgid}",
+                  file=sys.stderr)
+            if best is not None:
+                best["config"]["interrupted_by_signal"] = int(signum)
+                os.write(real_stdout, (json.dumps(best) + "\n").encode())
+                rc = 0
+        os._exit(rc)
+
+    signal.signal(signal.SIGTERM, on_signal)
+    signal.signal(signal.SIGINT, on_signal)
+
     dist = None
     if under_launcher:  # the ranks' supervisors coordinate over gloo (CPU only)
         import datetime
@@ -656,33 +836,37 @@ def supervisor_main(a):
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         import torch.distributed as dist
 
-        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=a.leg_timeout + 120))
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=a.total_budget + 120))
+    else:
+        try:  # page the framework in BEFORE the first child is on the clock (a fresh box takes a minute over it; CPU only)
+            import torch  # noqa: F401
+        except Exception:  # noqa: BLE001
+            pass
     base_env = dict(os.environ)
     base_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
     base_env.setdefault("GLOO_SOCKET_IFNAME", "lo")         # one node: never depend on the hostname resolving
-    legs = ["p2p", "rccl"] if a.comm == "auto" else [a.comm]
-    if os.environ.get("LBFGS_BENCH_LEGS"):  # testing: e.g. "hang,p2p" (a leg that never returns)
-        legs = os.environ["LBFGS_BENCH_LEGS"].split(",")
-    report, lines = {}, []
-    tried_callback = False
-    i = 0
-    while i < len(legs):
-        leg = legs[i]
-        i += 1
-        t0 = time.perf_counter()
-        if leg == "hang":  # test hook: a child that never prints and never exits
-            cmd_tail, child = None, [sys.executable, "-c", "import time; time.sleep(100000)"]
-        else:
-            # (LBFGS_BENCH_WORKER: the CPU suite runs the rank processes on the test double of the C-ABI)
-            cmd_tail = [os.environ.get("LBFGS_BENCH_WORKER") or os.path.join(ROOT, "bench.py")] + passthrough(a, leg)
-            child = None
+
+    def run_job(leg, probe, timeout, vector_free=True):
+        """One child job on every rank.  -> (status, json or None); identical status on every rank."""
+        # test hooks: "hang*" = a measurement that never returns (its probe passes), "hangprobe" = a probe that never returns,
+        # "failprobe" = a probe that fails at once
+        hook = leg.startswith("hang") or leg == "failprobe"   # ("hang", "hang2", ...: several hung legs in one run)
+        if hook and probe and leg != "hangprobe" and leg != "failprobe":
+            return "ok", {"probe": "ok", "comm": leg}
+        if leg == "failprobe":
+            return "exit code 4", None
         leg_env = dict(base_env)
         if leg == "p2p-per-step":  # the p2p communicator with one kernel per two-loop step (no persistent kernel)
             leg_env["LBFGS_HIP_RESIDENT"] = "0"
+        if hook:
+            cmd_tail, child = None, [sys.executable, "-c", "import time; time.sleep(100000)"]
+        else:
+            # (LBFGS_BENCH_WORKER: the CPU suite runs the rank processes on the test double of the C-ABI)
+            cmd_tail = [os.environ.get("LBFGS_BENCH_WORKER") or os.path.join(ROOT, "bench.py")] + passthrough(a, leg, probe, vector_free)
+            child = None
         if under_launcher:
-            port = [free_port() if rank == 0 else 0]
-            dist.broadcast_object_list(port, src=0)
-            env = dict(leg_env, MASTER_PORT=str(port[0]))
+            port = decided(free_port() if rank == 0 else None)
+            env = dict(leg_env, MASTER_PORT=str(port))
             for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
                       "TORCHELASTIC_USE_AGENT_STORE"):
                 env.pop(k, None)  # the child does its own env:// rendezvous on the fresh port
@@ -691,53 +875,106 @@ def supervisor_main(a):
             env = leg_env
             cmd = child or [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                             "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + cmd_tail
-        status, out = run_child(cmd, env, a.leg_timeout)
-        if under_launcher:  # a leg counts only if every rank's child ended well
+        status, out = run_child(cmd, env, timeout)
+        if under_launcher:  # a job counts only if every rank's child ended well
             all_status = [None] * world
             dist.all_gather_object(all_status, status)
-            bad = [f"rank {r}: {s}" for r, s in enumerate(all_status) if s != "ok"]
+            bad = [f"rank {r}: {st}" for r, st in enumerate(all_status) if st != "ok"]
             if bad:
                 status = "; ".join(bad)
         j = last_json(out) if (rank == 0 and status == "ok") else None
+        if rank == 0 and status == "ok" and j is None:
+            status = "no JSON line"
+        return decided(status), j
+
+    RESERVE = 8.0  # seconds kept for composing and printing the line
+
+    def decided(value):
+        """rank 0's value on every rank: every decision that shapes the sequence of jobs is rank 0's (its clock, its results)"""
+        if not under_launcher:
+            return value
+        box = [value if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    # ---- phase 1: probes
+    if os.environ.get("LBFGS_BENCH_LEGS"):  # testing: e.g. "hang,p2p" (a leg that never returns)
+        comms = os.environ["LBFGS_BENCH_LEGS"].split(",")
+    elif a.comm == "auto":
+        comms = ["p2p", "p2p-host", "rccl"]
+    else:
+        comms = [a.comm]
+    passed = []
+    for i, leg in enumerate(comms):
+        t0 = time.monotonic()
+        tmo = decided(min(a.probe_timeout * (2.0 if i == 0 else 1.0), left() - RESERVE))
+        if tmo < 3.0:
+            probes[leg] = {"status": "skipped: budget spent", "seconds": 0.0}
+            continue
+        status, j = run_job(leg, True, tmo)
+        probes[leg] = {"status": status, "seconds": round(time.monotonic() - t0, 1), "timeout_s": round(tmo, 1)}
+        if j and j.get("mailboxes"):
+            probes[leg]["mailboxes"] = j["mailboxes"]
+        if status == "ok":
+            passed.append(leg)
         if rank == 0:
-            if status == "ok" and j is None:
-                status = "no JSON line"
-            report[leg] = {"status": status, "seconds": round(time.perf_counter() - t0, 1),
-                           "iters_per_sec": round(j["value"], 3) if j else None}
-            if j:
-                lines.append((leg, j))
-            print(f"[bench] leg {leg}: {report[leg]}", file=sys.stderr)
-        if leg == "p2p" and a.comm == "auto":
-            # The p2p leg runs the two-loop as ONE persistent kernel whose hand-offs include the xGMI exchange.  If that
-            # leg did not produce a result, the same communicator is tried with a kernel per step before RCCL is.
-            retry = [report.get("p2p", {}).get("iters_per_sec") is None] if rank == 0 else [False]
-            if under_launcher:
-                dist.broadcast_object_list(retry, src=0)
-            if retry[0]:
-                legs.insert(i, "p2p-per-step")
-        if i == len(legs) and a.comm == "auto" and not tried_callback:
-            # last resort: the host-staged all-reduce through gloo, only if nothing has produced a result
-            have = [len(lines)]
-            if under_launcher:
-                dist.broadcast_object_list(have, src=0)
-            if have[0] == 0:
-                legs.append("callback")
-            tried_callback = True
+            print(f"[bench] probe {leg}: {probes[leg]}  ({left():.0f} s of the budget left)", file=sys.stderr)
+
+    # ---- phase 2: measurements.  Order: p2p, (p2p-per-step only if the p2p MEASUREMENT failed), then -- fallback order while
+    # there is no result -- p2p-host before rccl; once there is a result the others follow as comparisons, rccl first.
+    def measure_leg(leg, legs_after):
+        t0 = time.monotonic()
+        cap = min(a.leg_timeout, 150.0) if leg.startswith("p2p") else a.leg_timeout
+        tmo = decided(min(cap, (left() - RESERVE) / (1 + legs_after)))
+        if tmo < 10.0:
+            report[leg] = {"status": "skipped: budget spent", "seconds": 0.0, "iters_per_sec": None}
+            if rank == 0:
+                print(f"[bench] leg {leg}: {report[leg]}", file=sys.stderr)
+            return False
+        # the vector-free extension is an extra: not once less than a third of the budget is left
+        vf = decided(left() >= a.total_budget / 3.0)
+        status, j = run_job(leg, False, tmo, vector_free=vf)
+        report[leg] = {"status": status, "seconds": round(time.monotonic() - t0, 1), "timeout_s": round(tmo, 1),
+                       "iters_per_sec": round(j["value"], 3) if j else None}
+        if j:
+            lines.append((leg, j))
+        if rank == 0:
+            print(f"[bench] leg {leg}: {report[leg]}  ({left():.0f} s of the budget left)", file=sys.stderr)
+        return j is not None
+
+    def sync_have():
+        return decided(len(lines) > 0)
+
+    todo = [c for c in passed]
+    explicit = bool(os.environ.get("LBFGS_BENCH_LEGS")) or a.comm != "auto"
+    if explicit:
+        for i, leg in enumerate(todo):
+            measure_leg(leg, len(todo) - 1 - i)
+    else:
+        if "p2p" in todo:
+            others = [c for c in todo if c != "p2p"]
+            measure_leg("p2p", len(others))
+            if not sync_have():
+                measure_leg("p2p-per-step", len(others))
+        rest = [c for c in todo if c != "p2p"]
+        if not sync_have():  # fallback order
+            rest.sort(key=lambda c: {"p2p-host": 0, "rccl": 1}.get(c, 2))
+        else:                # comparisons
+            rest.sort(key=lambda c: {"rccl": 0, "p2p-host": 1}.get(c, 2))
+        for i, leg in enumerate(rest):
+            measure_leg(leg, len(rest) - 1 - i)
+    if not sync_have() and (a.comm == "auto") and "callback" not in report:
+        # last resort: the host-staged all-reduce through gloo, only if nothing has produced a result
+        measure_leg("callback", 0)
+
+    state["done"] = True
     rc = 0
     if rank == 0:
-        if not lines:
-            print("bench.py: no communicator leg produced a result: " + json.dumps(report), file=sys.stderr)
+        best = final_line()
+        if best is None:
+            print("bench.py: no communicator leg produced a result: " + json.dumps({"probes": probes, "legs": report}), file=sys.stderr)
             rc = 1
         else:
-            leg, best = max(lines, key=lambda t: t[1]["value"])
-            best["config"]["legs"] = report
-            best["config"]["allreduce_measured_iters_per_sec"] = {lg: round(j["value"], 3) for lg, j in lines}
-            ext = {}
-            for lg, j in lines:
-                ext.update(j["config"].get("extension_vector_free_two_loop") or {})
-            best["config"]["extension_vector_free_two_loop"] = ext
-            best["config"]["launch"] = ("torch.distributed.run ranks as supervisors, one child rank each per leg"
-                                        if under_launcher else "self-launched: one torch.distributed.run child per leg")
             os.write(real_stdout, (json.dumps(best) + "\n").encode())
     if dist is not None:
         ok = [rc]
@@ -750,6 +987,8 @@ def supervisor_main(a):
 
 def main():
     a = parse()
+    if a.cpu_child:
+        return cpu_baseline_child_main(a)
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if a.rank_mode or (a.gpus <= 1 and world_env <= 1):
         return worker_main(a)

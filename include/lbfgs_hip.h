@@ -39,7 +39,10 @@
 extern "C" {
 #endif
 
-#define LBFGS_HIP_ABI_VERSION 1
+/* 2: lbfgs_hip_objective.skin, lbfgs_hip_comm.exclusive_device, LBFGS_HIP_K_TWOLOOP_RESIDENT (all round 2, unversioned then),
+ *    mailbox placements, lbfgs_hip_build_id.  A caller compares lbfgs_hip_abi_version() with the constant it was built
+ *    against before anything else (rust-lbfgs_amd/_ffi.py, integration/rust-shim, tests/support/c_caller.c do). */
+#define LBFGS_HIP_ABI_VERSION 2
 #define LBFGS_HIP_BOARD_SLOTS 256
 
 /* status codes */
@@ -95,13 +98,29 @@ typedef struct lbfgs_hip_comm {
 /* context                                                                     */
 /* ------------------------------------------------------------------------- */
 int lbfgs_hip_abi_version(void);
+/* 16 hex digits: hash of the sources and compiler flags this library was built from (rust-lbfgs_amd/_build.py stamps
+ * it; "unstamped" for a hand build).  The Python loader and tests/test_abi_exports.py compare it with the hash of the
+ * checked-out sources, so a stale prebuilt library is rebuilt -- or refused -- instead of being trusted by its mtime. */
+const char* lbfgs_hip_build_id(void);
 int lbfgs_hip_device_count(int* count);
 /* rank 0: produce the 128-byte RCCL unique id to broadcast to the other ranks */
 int lbfgs_hip_rccl_unique_id(void* out128);
-/* P2P step 1 (before ctx_create): allocate this rank's mailbox in uncached device memory and export
- * its 64-byte IPC handle; the host framework all-gathers the handles into lbfgs_hip_comm.p2p_handles. */
+/* P2P step 1 (before ctx_create): allocate this rank's mailbox and export a 64-byte handle; the host framework
+ * all-gathers the handles into lbfgs_hip_comm.p2p_handles.  Two placements:
+ *   DEVICE  uncached device memory, exported as a HIP IPC handle and mapped by the peers over xGMI (the fast one);
+ *   HOST    a POSIX shared-memory segment registered with HIP (host-coherent, reached over PCIe by every GPU): for
+ *           machines where IPC mapping of device memory between the GPUs fails or is slow.  Same kernels, same bits.
+ * lbfgs_hip_p2p_mailbox_create takes the placement from the environment (LBFGS_HIP_P2P_MAILBOX=device|host,
+ * default device).  ctx_create recognises the placement of every peer's handle by itself (ranks need not agree). */
+enum { LBFGS_HIP_MAILBOX_AUTO = -1, LBFGS_HIP_MAILBOX_DEVICE = 0, LBFGS_HIP_MAILBOX_HOST = 1 };
 int lbfgs_hip_p2p_mailbox_create(int device, void** mailbox_out, void* ipc_handle64_out);
+int lbfgs_hip_p2p_mailbox_create2(int device, int placement, void** mailbox_out, void* ipc_handle64_out);
 void lbfgs_hip_p2p_mailbox_destroy(int device, void* mailbox); /* only for a mailbox never handed to lbfgs_hip_ctx_create */
+/* After EVERY rank's lbfgs_hip_ctx_create has returned (a barrier of the host framework): removes the name of this
+ * rank's HOST-placed mailbox from the system, so that the segment cannot outlive the processes that map it (it is
+ * also removed by lbfgs_hip_ctx_destroy).  No-op for the DEVICE placement.  *placement_out (may be NULL) receives
+ * the placement of this rank's mailbox, or -1 without a P2P communicator. */
+int lbfgs_hip_ctx_p2p_seal(lbfgs_hip_ctx* ctx, int* placement_out);
 /* shard == NULL => single rank holding n elements.  comm == NULL => NONE.
  * stream == NULL => the context creates its own non-blocking stream. */
 int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfgs_hip_shard* shard,

@@ -146,6 +146,8 @@ int lbfgs_state_download(lbfgs_state* st, int which, double* host);
 void* lbfgs_state_devptr(lbfgs_state* st, int which);
 lbfgs_hip_vec* lbfgs_state_vec(lbfgs_state* st, int which); /* borrowed handle (e.g. Problem::search_direction) */
 int lbfgs_state_info(lbfgs_state* st, uint64_t* k, uint64_t* end, double* step, double* gamma);
+/* 16 hex digits: hash of the sources and flags liblbfgs_solver.so was built from (see lbfgs_hip_build_id) */
+const char* lbfgs_solver_build_id(void);
 lbfgs_hip_history* lbfgs_state_history(lbfgs_state* st);
 
 /* Lbfgs::minimize (lbfgs.rs:399-421).  x is read as the start point and receives the result

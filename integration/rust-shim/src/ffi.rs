@@ -8,6 +8,9 @@ use std::os::raw::{c_char, c_int, c_void};
 #[repr(C)] pub struct lbfgs_hip_history { _p: [u8; 0] }
 #[repr(C)] pub struct lbfgs_state { _p: [u8; 0] }
 
+/// `LBFGS_HIP_ABI_VERSION` of the `include/lbfgs_hip.h` these declarations mirror; `Context::new` refuses a library
+/// that reports another one (struct layouts are shared by value).
+pub const LBFGS_HIP_ABI_VERSION: i32 = 2;
 pub const LBFGS_HIP_OK: c_int = 0;
 pub const LBFGS_ERR_EVALUATE: c_int = -1;
 pub const LBFGS_PANIC_OWLQN_RANGE: c_int = -20;
@@ -144,6 +147,7 @@ pub struct lbfgs_report {
 extern "C" {
     // ---- include/lbfgs_hip.h: context, vectors, scalar board --------------------------------------
     pub fn lbfgs_hip_abi_version() -> c_int;
+    pub fn lbfgs_hip_build_id() -> *const c_char;
     pub fn lbfgs_hip_device_count(count: *mut c_int) -> c_int;
     pub fn lbfgs_hip_rccl_unique_id(out128: *mut c_void) -> c_int;
     pub fn lbfgs_hip_ctx_create(out: *mut *mut lbfgs_hip_ctx, device: c_int, n: u64, shard: *const lbfgs_hip_shard,

@@ -370,6 +370,11 @@ struct Context {
 
 impl Context {
     fn new(device: c_int, n: usize) -> Result<Self> {
+        // the #[repr(C)] mirrors in ffi.rs are passed by value: never talk to a library of another ABI version
+        if unsafe { ffi::lbfgs_hip_abi_version() != ffi::LBFGS_HIP_ABI_VERSION } {
+            bail!("liblbfgs_hip reports ABI version {}, this crate was written against {}",
+                  unsafe { ffi::lbfgs_hip_abi_version() }, ffi::LBFGS_HIP_ABI_VERSION);
+        }
         let mut raw = ptr::null_mut();
         let rc = unsafe { ffi::lbfgs_hip_ctx_create(&mut raw, device, n as u64, ptr::null(), ptr::null(), ptr::null_mut()) };
         if rc != ffi::LBFGS_HIP_OK {

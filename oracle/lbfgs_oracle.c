@@ -848,3 +848,11 @@ double oracle_state_step(const oracle_state* st) { return st->step; }
 double oracle_state_gamma(const oracle_state* st) { return st->last_gamma; }
 const char* oracle_state_ls_error(const oracle_state* st) { return st->ls_error; }
 int oracle_state_ls_failed(const oracle_state* st) { return st->ls_failed; }
+
+/* Which sources this library was built from: oracle.py passes the content hash of lbfgs_oracle.{c,h}, objectives.c and the
+ * Makefile, and rebuilds when a prebuilt library carries another one (the string is readable from the file itself). */
+#ifndef LBFGS_ORACLE_BUILD_ID
+#define LBFGS_ORACLE_BUILD_ID "unstamped"
+#endif
+static const char oracle_build_id_marker[] = "LBFGS_ORACLE_BUILD_ID=" LBFGS_ORACLE_BUILD_ID;
+const char* oracle_build_id(void) { return oracle_build_id_marker + sizeof("LBFGS_ORACLE_BUILD_ID=") - 1; }

@@ -172,6 +172,7 @@ double oracle_state_step(const oracle_state* st);
 double oracle_state_gamma(const oracle_state* st);   /* last gamma = ys/yy */
 /* message of the last swallowed line-search failure (line.rs:213-220), "" if none */
 const char* oracle_state_ls_error(const oracle_state* st);
+const char* oracle_build_id(void); /* content hash of the sources this library was built from (oracle.py) */
 /* 1 if the last line search failed and was swallowed (quirk 6) */
 int oracle_state_ls_failed(const oracle_state* st);
 

@@ -43,14 +43,36 @@ class OracleError(RuntimeError):
         self.code = code
 
 
+def source_id() -> str:
+    """content hash of the oracle's sources and Makefile (16 hex digits)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("lbfgs_oracle.c", "objectives.c", "lbfgs_oracle.h", "Makefile"):
+        h.update(f.encode() + b"\0")
+        with open(os.path.join(_HERE, f), "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
+def embedded_id(lib: str):
+    import re
+
+    try:
+        with open(lib, "rb") as fh:
+            m = re.search(rb"LBFGS_ORACLE_BUILD_ID=([0-9a-f]{16})", fh.read())
+    except OSError:
+        return None
+    return m.group(1).decode() if m else None
+
+
 def build(force: bool = False) -> str:
-    """Compile the oracle with its Makefile (gcc -O2 -ffp-contract=off)."""
-    srcs = [os.path.join(_HERE, f) for f in ("lbfgs_oracle.c", "objectives.c", "lbfgs_oracle.h", "Makefile")]
-    stale = force or not os.path.exists(_LIB_PATH) or any(
-        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
-    )
-    if stale:
-        subprocess.run(["make", "-C", _HERE, "-B", _LIB_NAME], check=True, capture_output=True)
+    """Compile the oracle with its Makefile (gcc -O2 -ffp-contract=off).  Rebuilt when the library does not carry the
+    hash of the checked-out sources (never by modification time: prebuilt libraries travel with snapshots)."""
+    want = source_id()
+    if force or embedded_id(_LIB_PATH) != want:
+        subprocess.run(["make", "-C", _HERE, "-B", _LIB_NAME, "BUILD_ID=" + want], check=True, capture_output=True)
     return _LIB_PATH
 
 

@@ -5,8 +5,13 @@
 
 hipcc cross-compiles for gfx950 without a GPU.  -ffp-contract=off on both sides: the
 reference's arithmetic is mul-then-add with separate roundings (src/math.rs:35,41).
+
+Builds are CONTENT-ADDRESSED: a library carries the hash of the sources and flags it was compiled from
+(`lbfgs_hip_build_id()`, `lbfgs_solver_build_id()`; the string is also readable from the file), and it is rebuilt
+whenever that differs from the hash of the checked-out sources.  Modification times play no part.
 """
 import glob
+import hashlib
 import os
 import re
 import subprocess
@@ -26,11 +31,49 @@ SOLVER_SRCS = [os.path.join(CSRC, "host", "solver.cpp"), os.path.join(ROOT, "inc
                os.path.join(ROOT, "include", "lbfgs_hip.h")]
 
 
-def _stale(target, srcs):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in srcs)
+def source_hash(paths, flags=()):
+    """16 hex digits over the CONTENTS of `paths` (in the order given, names included) and the compiler flags."""
+    h = hashlib.sha256()
+    for p in paths:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    for fl in flags:
+        h.update(fl.encode() + b"\0")
+    return h.hexdigest()[:16]
+
+
+def embedded_id(lib, marker):
+    """The build id a library carries (the string `<marker>=<16 hex digits>` inside the file), or None.  Reading the file
+    instead of loading it: the answer must not depend on a HIP runtime being present."""
+    try:
+        with open(lib, "rb") as f:
+            m = re.search(re.escape(marker.encode()) + rb"=([0-9a-f]{16})", f.read())
+    except OSError:
+        return None
+    return m.group(1).decode() if m else None
+
+
+HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+             # (resident.h parks data in the accumulation registers by hand: the compiler must not spill into them)
+             "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-Wall"]
+SOLVER_FLAGS = ["-O2", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall"]
+
+
+def hip_build_id():
+    """What liblbfgs_hip.so must carry to belong to the checked-out sources."""
+    return source_hash(HIP_SRCS, HIP_FLAGS)
+
+
+def solver_build_id():
+    return source_hash(SOLVER_SRCS, SOLVER_FLAGS + [hip_build_id()])
+
+
+def _stale(target, marker, want):
+    """A library is stale when the id it carries is not the hash of the sources -- never by modification time: prebuilt,
+    git-ignored libraries travel with snapshots and checkouts that reset mtimes."""
+    return embedded_id(target, marker) != want
 
 
 def _run(cmd, cwd=None):
@@ -65,17 +108,19 @@ def _audit_agprs(asm_text):
     return out
 
 
+LAST_BUILD = {}  # name -> "compiled" | "reused" (what build_all did this time; __graft_entry__.build() prints it)
+
+
 def build_hip(force=False):
-    if force or _stale(HIP_LIB, HIP_SRCS):
+    want = hip_build_id()
+    if force or _stale(HIP_LIB, "LBFGS_HIP_BUILD_ID", want) or not os.path.exists(RESOURCES):
         # -Rpass-analysis=kernel-resource-usage: registers / scratch / occupancy of every kernel, kept next to the library
         # (tests/test_abi_exports.py requires ScratchSize == 0 everywhere: a kernel that touches scratch memory pays
         # ~12 us of extra dispatch cost per launch on MI355X, measured).  -save-temps keeps the device assembly long
         # enough to audit the resident kernels' AGPR usage (same test).
         with tempfile.TemporaryDirectory(prefix="lbfgs_hip_build_") as tmp:
-            r = _run([hipcc(), "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-                      # (resident.h parks data in the accumulation registers by hand: the compiler must not spill into them)
-                      "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-save-temps",
-                      "-Wall", "-Rpass-analysis=kernel-resource-usage", HIP_SRCS[0], "-o", HIP_LIB, "-ldl"], cwd=tmp)
+            r = _run([hipcc(), *HIP_FLAGS, "-save-temps", "-Rpass-analysis=kernel-resource-usage",
+                      '-DLBFGS_HIP_BUILD_ID="%s"' % want, HIP_SRCS[0], "-o", HIP_LIB, "-ldl", "-lrt"], cwd=tmp)
             asm = glob.glob(os.path.join(tmp, "*amdgcn*gfx950.s"))
             if len(asm) != 1:
                 raise RuntimeError("build: expected one device assembly file, found %r" % (asm,))
@@ -88,14 +133,23 @@ def build_hip(force=False):
             f.write("\n# AGPR operands emitted by the compiler (outside inline asm) in the resident kernels\n")
             for k in sorted(audit):
                 f.write("agpr-audit: %s %d\n" % (k, audit[k]))
+        if embedded_id(HIP_LIB, "LBFGS_HIP_BUILD_ID") != want:
+            raise RuntimeError("build: %s does not carry the id it was built with" % HIP_LIB)
+        LAST_BUILD["liblbfgs_hip.so"] = "compiled"
+    else:
+        LAST_BUILD.setdefault("liblbfgs_hip.so", "reused")
     return HIP_LIB
 
 
 def build_solver(force=False):
     build_hip(force)
-    if force or _stale(SOLVER_LIB, SOLVER_SRCS + [HIP_LIB]):
-        _run(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall", SOLVER_SRCS[0], "-o",
+    want = solver_build_id()
+    if force or _stale(SOLVER_LIB, "LBFGS_SOLVER_BUILD_ID", want):
+        _run(["g++", *SOLVER_FLAGS, '-DLBFGS_SOLVER_BUILD_ID="%s"' % want, SOLVER_SRCS[0], "-o",
               SOLVER_LIB, "-L" + HERE, "-llbfgs_hip", "-Wl,-rpath,$ORIGIN"])
+        LAST_BUILD["liblbfgs_solver.so"] = "compiled"
+    else:
+        LAST_BUILD["liblbfgs_solver.so"] = "reused"
     return SOLVER_LIB
 
 
@@ -103,5 +157,37 @@ def build_all(force=False):
     return build_hip(force), build_solver(force)
 
 
+def build_variant(name, extra_flags):
+    """A/B builds (tools/build_variants.sh): both libraries compiled with extra -D flags into tools/bin/variants/<name>/
+    (load them with LBFGS_HIP_LIB_DIR), with the same resource report and AGPR audit as the in-tree build; raises if a
+    kernel of the variant touches scratch memory or the compiler put something into an accumulation register."""
+    out = os.path.join(ROOT, "tools", "bin", "variants", name)
+    os.makedirs(out, exist_ok=True)
+    hip_lib, solver_lib = os.path.join(out, "liblbfgs_hip.so"), os.path.join(out, "liblbfgs_solver.so")
+    flags = HIP_FLAGS + list(extra_flags)
+    bid = source_hash(HIP_SRCS, flags)
+    with tempfile.TemporaryDirectory(prefix="lbfgs_hip_variant_") as tmp:
+        r = _run([hipcc(), *flags, "-save-temps", "-Rpass-analysis=kernel-resource-usage", '-DLBFGS_HIP_BUILD_ID="%s"' % bid,
+                  HIP_SRCS[0], "-o", hip_lib, "-ldl", "-lrt"], cwd=tmp)
+        asm = glob.glob(os.path.join(tmp, "*amdgcn*gfx950.s"))
+        with open(asm[0]) as f:
+            audit = _audit_agprs(f.read())
+    with open(os.path.join(out, "liblbfgs_hip.resources.txt"), "w") as f:
+        f.write(r.stderr)
+        for k in sorted(audit):
+            f.write("agpr-audit: %s %d\n" % (k, audit[k]))
+    scratch = [ln for ln in r.stderr.splitlines() if "ScratchSize" in ln and not ln.rstrip().endswith(": 0 [-Rpass-analysis=kernel-resource-usage]")]
+    bad = {k: v for k, v in audit.items() if v}
+    if scratch or bad:
+        raise RuntimeError("variant %s: scratch %r, compiler-placed AGPR operands %r" % (name, scratch[:3], bad))
+    _run(["g++", *SOLVER_FLAGS, SOLVER_SRCS[0], "-o", solver_lib, "-L" + out, "-llbfgs_hip", "-Wl,-rpath,$ORIGIN"])
+    return out
+
+
 if __name__ == "__main__":
-    print(build_all(force=True))
+    import sys
+
+    if len(sys.argv) >= 3 and sys.argv[1] == "--variant":  # python rust-lbfgs_amd/_build.py --variant NAME -DX=1 -DY=2
+        print("built", build_variant(sys.argv[2], sys.argv[3:]))
+    else:
+        print(build_all(force=True))

@@ -23,6 +23,8 @@ HIP_ERR_ARG, HIP_ERR_HIP, HIP_ERR_COMM, HIP_ERR_NOMEM, HIP_ERR_NO_DEVICE = -101,
 LS_MORETHUENTE, LS_BT_ARMIJO, LS_BT_STRONGWOLFE, LS_BT_WOLFE = 0, 1, 2, 3
 EVAL_HOST, EVAL_DEVICE, EVAL_BUILTIN = 0, 1, 2
 COMM_NONE, COMM_RCCL, COMM_CALLBACK, COMM_P2P = 0, 1, 2, 3
+MAILBOX_AUTO, MAILBOX_DEVICE, MAILBOX_HOST = -1, 0, 1
+ABI_VERSION = 2  # LBFGS_HIP_ABI_VERSION of the include/lbfgs_hip.h these declarations were written against
 OBJ_QUADRATIC, OBJ_LOGISTIC, OBJ_ROSENBROCK, OBJ_LJ_ALLPAIRS, OBJ_LJ_NEIGHBORS, OBJ_LJ_CELLS = 1, 2, 3, 4, 5, 6
 (K_TWOLOOP_STEP, K_TWOLOOP_EDGE, K_UPDATE, K_LINE, K_EVAL, K_OWLQN, K_BLAS1, K_COMM, K_TWOLOOP_ALL,
  K_TWOLOOP_RESIDENT) = range(10)
@@ -89,8 +91,8 @@ class CReport(C.Structure):
 
 # every symbol include/lbfgs_hip.h declares
 HIP_SYMBOLS = """
-lbfgs_hip_abi_version lbfgs_hip_device_count lbfgs_hip_rccl_unique_id lbfgs_hip_p2p_mailbox_create
-lbfgs_hip_p2p_mailbox_destroy lbfgs_hip_ctx_create lbfgs_hip_ctx_destroy
+lbfgs_hip_abi_version lbfgs_hip_build_id lbfgs_hip_device_count lbfgs_hip_rccl_unique_id lbfgs_hip_p2p_mailbox_create
+lbfgs_hip_p2p_mailbox_create2 lbfgs_hip_p2p_mailbox_destroy lbfgs_hip_ctx_p2p_seal lbfgs_hip_ctx_create lbfgs_hip_ctx_destroy
 lbfgs_hip_last_error lbfgs_hip_sync lbfgs_hip_stream lbfgs_hip_get_shard lbfgs_hip_set_grid lbfgs_hip_path_stats
 lbfgs_hip_vec_alloc lbfgs_hip_vec_free lbfgs_hip_vec_upload lbfgs_hip_vec_download lbfgs_hip_vec_fill
 lbfgs_hip_vec_ptr lbfgs_hip_vec_swap
@@ -114,7 +116,7 @@ lbfgs_hip_prof_enable lbfgs_hip_prof_reset lbfgs_hip_prof_read
 SOLVER_SYMBOLS = """
 lbfgs_param_default lbfgs_build lbfgs_is_converged lbfgs_propagate lbfgs_get_report lbfgs_state_free
 lbfgs_state_error lbfgs_state_ls_error lbfgs_line_search lbfgs_state_download lbfgs_state_devptr lbfgs_state_info
-lbfgs_state_history lbfgs_state_vec lbfgs_minimize
+lbfgs_state_history lbfgs_state_vec lbfgs_minimize lbfgs_solver_build_id
 lbfgs_problem_new lbfgs_problem_evaluate lbfgs_problem_update_search_direction lbfgs_problem_dginit
 lbfgs_problem_dg_unchecked lbfgs_problem_save_state lbfgs_problem_revert lbfgs_problem_take_line_step
 lbfgs_problem_update_orthant_new_point lbfgs_problem_constrain_search_direction lbfgs_problem_norms
@@ -127,6 +129,10 @@ def declare(L):
     vp, dp, i, u64, dbl = C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_uint64, C.c_double
     sig = {
         "lbfgs_hip_abi_version": (i, []),
+        "lbfgs_hip_build_id": (C.c_char_p, []),
+        "lbfgs_solver_build_id": (C.c_char_p, []),
+        "lbfgs_hip_p2p_mailbox_create2": (i, [i, i, C.POINTER(vp), vp]),
+        "lbfgs_hip_ctx_p2p_seal": (i, [vp, C.POINTER(i)]),
         "lbfgs_hip_device_count": (i, [C.POINTER(i)]),
         "lbfgs_hip_rccl_unique_id": (i, [vp]),
         "lbfgs_hip_p2p_mailbox_create": (i, [i, C.POINTER(vp), vp]),
@@ -290,5 +296,10 @@ def load():
     _one_hip_runtime()
     # liblbfgs_solver.so names liblbfgs_hip.so as a dependency (rpath $ORIGIN); RTLD_LOCAL keeps the
     # lbfgs_hip_* symbols out of the global namespace
-    _LIB = declare(C.CDLL(solver, mode=C.RTLD_LOCAL))
+    lib = declare(C.CDLL(solver, mode=C.RTLD_LOCAL))
+    got = lib.lbfgs_hip_abi_version()
+    if got != ABI_VERSION:  # struct layouts are shared by value: never talk to a library with another one
+        raise ImportError(f"{hip} has ABI version {got}, this package was written against {ABI_VERSION}: rebuild "
+                          "(python -c 'import rust_lbfgs_amd as r; r.build()')")
+    _LIB = lib
     return _LIB

@@ -615,6 +615,13 @@ void lbfgs_param_default(lbfgs_param* p) {  // lbfgs.rs:161-176, line.rs:151-162
 
 static std::string g_build_error;
 
+#ifndef LBFGS_SOLVER_BUILD_ID
+#define LBFGS_SOLVER_BUILD_ID "unstamped"
+#endif
+// (readable from the file as well as through the call: rust-lbfgs_amd/_build.py embedded_id)
+static const char lbfgs_solver_build_id_marker[] = "LBFGS_SOLVER_BUILD_ID=" LBFGS_SOLVER_BUILD_ID;
+const char* lbfgs_solver_build_id(void) { return lbfgs_solver_build_id_marker + sizeof("LBFGS_SOLVER_BUILD_ID=") - 1; }
+
 void lbfgs_state_free(lbfgs_state* st) {
     if (!st) return;
     lbfgs_hip_history_destroy(st->hist);
@@ -630,6 +637,13 @@ static int problem_new(lbfgs_state** out, lbfgs_hip_ctx* ctx, const lbfgs_param*
                        const lbfgs_evaluator* eval, bool with_history) {
     if (!out || !ctx || !param || !eval || (with_history && param->m < 1)) return LBFGS_ERR_PARAM;
     *out = nullptr;
+    if (lbfgs_hip_abi_version() != LBFGS_HIP_ABI_VERSION) {  // struct layouts of lbfgs_hip.h are shared by value
+        char b[128];
+        snprintf(b, sizeof(b), "liblbfgs_hip has ABI version %d, this solver was built against %d", lbfgs_hip_abi_version(),
+                 LBFGS_HIP_ABI_VERSION);
+        g_build_error = b;
+        return LBFGS_ERR_PARAM;
+    }
     lbfgs_state* st = new (std::nothrow) lbfgs_state();
     if (!st) return LBFGS_HIP_ERR_NOMEM;
     st->ctx = ctx;
@@ -798,13 +812,17 @@ int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
 
     uint64_t ncall = 0;
     {
+        const double fx0 = st->fx;  // f at the point the search starts from
         const int rc_ls = line_search_find(st, st->step, &ncall, true);  // :517-521
         if (rc_ls != LBFGS_OK) {
             // a hard error (negative step, gradient-only + More-Thuente, backend / communicator failure): the
             // reference's save_state COPIES (core.rs:207-210), so its x still is the point the search started from.
             // Undo the buffer exchange so that VEC_X names that point again (minimize() hands it back to the caller).
+            // fx goes back with it: after a failure in the middle of the search st->fx would be the last TRIAL's value,
+            // which belongs to neither x nor xp (lbfgs_get_report / lbfgs_problem_status return fx next to x).
             (void)lbfgs_hip_vec_swap(st->x, st->xp);
             (void)lbfgs_hip_vec_swap(st->gx, st->gp);
+            st->fx = fx0;
             st->norms_valid = false;
             st->point_deferred = false;
             return rc_ls;

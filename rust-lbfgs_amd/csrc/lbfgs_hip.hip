@@ -9,12 +9,19 @@
 #include "../../include/lbfgs_hip.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <array>
+#include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <map>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -79,6 +86,99 @@ bool rccl_load(std::string* err) {
     return true;
 }
 std::string g_create_error;  // last error of a failed ctx_create (no ctx to hold it)
+
+#ifndef LBFGS_HIP_BUILD_ID
+#define LBFGS_HIP_BUILD_ID "unstamped"
+#endif
+// (the marker makes the id readable from the FILE, without loading it: rust-lbfgs_amd/_build.py embedded_id)
+const char lbfgs_hip_build_id_marker[] = "LBFGS_HIP_BUILD_ID=" LBFGS_HIP_BUILD_ID;
+
+// ---- HOST-placed P2P mailboxes (lbfgs_hip.h): a POSIX shared-memory segment, registered with HIP so that kernels reach
+// it through a device address (fine-grained host memory: system-scope atomics go straight to host DRAM over PCIe).
+// The 64-byte handle carries a magic word and the segment's name instead of a hipIpcMemHandle_t.
+constexpr char HOST_MBOX_MAGIC[8] = {'L', 'H', 'M', 'B', 'O', 'X', 'H', '1'};
+struct HostMbox {
+    void* host = nullptr;
+    size_t bytes = 0;
+    std::string name;
+    bool owner = false;   // this process created the segment: it unlinks the name
+    bool linked = false;  // the name still exists
+};
+std::map<void*, HostMbox> g_host_mbox;  // device address -> mapping
+std::mutex g_host_mbox_mu;
+
+void host_mbox_unlink_all() {  // atexit: names of segments this process still owns
+    std::lock_guard<std::mutex> lk(g_host_mbox_mu);
+    for (auto& kv : g_host_mbox)
+        if (kv.second.owner && kv.second.linked) {
+            (void)shm_unlink(kv.second.name.c_str());
+            kv.second.linked = false;
+        }
+}
+
+// map + register the segment `name` (create = this process makes it); -> device address or nullptr (*err set)
+void* host_mbox_map(const std::string& name, size_t bytes, bool create, std::string* err) {
+    const int fd = shm_open(name.c_str(), create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDWR, 0600);
+    if (fd < 0) {
+        *err = "shm_open(" + name + "): " + strerror(errno);
+        return nullptr;
+    }
+    if (create && ftruncate(fd, (off_t)bytes) != 0) {
+        *err = std::string("ftruncate: ") + strerror(errno);
+        (void)close(fd);
+        (void)shm_unlink(name.c_str());
+        return nullptr;
+    }
+    void* host = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    (void)close(fd);
+    if (host == MAP_FAILED) {
+        *err = std::string("mmap: ") + strerror(errno);
+        if (create) (void)shm_unlink(name.c_str());
+        return nullptr;
+    }
+    if (create) memset(host, 0, bytes);  // tag 0 is never a valid epoch
+    void* dev = nullptr;
+    hipError_t e = hipHostRegister(host, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e == hipSuccess) {
+        e = hipHostGetDevicePointer(&dev, host, 0);
+        if (e != hipSuccess) (void)hipHostUnregister(host);
+    }
+    if (e != hipSuccess) {
+        *err = std::string("hipHostRegister of the shared mailbox: ") + hipGetErrorString(e);
+        (void)munmap(host, bytes);
+        if (create) (void)shm_unlink(name.c_str());
+        return nullptr;
+    }
+    static bool hooked = false;
+    std::lock_guard<std::mutex> lk(g_host_mbox_mu);
+    if (!hooked) {
+        atexit(host_mbox_unlink_all);
+        hooked = true;
+    }
+    HostMbox hm;
+    hm.host = host;
+    hm.bytes = bytes;
+    hm.name = name;
+    hm.owner = create;
+    hm.linked = create;
+    g_host_mbox[dev] = hm;
+    return dev;
+}
+// -> true if `dev` was a host-placed mailbox (now released)
+bool host_mbox_release(void* dev) {
+    HostMbox hm;
+    {
+        std::lock_guard<std::mutex> lk(g_host_mbox_mu);
+        auto it = g_host_mbox.find(dev);
+        if (it == g_host_mbox.end()) return false;
+        hm = it->second;
+        g_host_mbox.erase(it);
+    }
+    (void)hipHostUnregister(hm.host);
+    (void)munmap(hm.host, hm.bytes);
+    if (hm.owner && hm.linked) (void)shm_unlink(hm.name.c_str());
+    return true;
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------------ P2P all-reduce
@@ -176,7 +276,21 @@ struct lbfgs_hip_ctx {
     int resident_grid = 0;                // LBFGS_HIP_RESIDENT_GRID: workgroups of the resident kernel (0 = one per CU); tests
     bool resident_on = true;              // LBFGS_HIP_RESIDENT=0: never use the on-chip-resident two-loop kernel (resident.h)
     unsigned long long resident_launches = 0;  // two-loops that ran as the resident kernel (tests / bench read it)
-    int resident_ok = -1;                 // -1 = not probed yet, 0 = this device cannot hold the grid resident, 1 = usable
+    int resident_ok = -1;                 // -1 = not probed yet, 0 = this device / queue cannot hold the grid resident, 1 = usable
+    // The latest two-loop if it ran as the resident kernel and nothing has been enqueued since (one rank only): should its
+    // hand-offs time out -- the kernel did not get every CU it asked for -- lbfgs_hip_scalars_read re-runs the recursion
+    // with a kernel per step (inputs g, s, y, ys are intact; d and alpha are outputs) and stops using the resident kernel.
+    struct LastResident {
+        bool valid = false;
+        lbfgs_hip_history* h = nullptr;
+        lbfgs_hip_vec* d = nullptr;
+        const lbfgs_hip_vec* g = nullptr;
+        uint64_t k = 0, owl_start = 0, owl_end = 0;
+        int end = 0, gnum = 0, gden = 0, dn = 0, first = -1;
+        bool owl = false;
+    } last_res;
+    unsigned long long resident_fallbacks = 0;  // how often that happened
+    int resident_fault = 0;               // LBFGS_HIP_RESIDENT_FAULT=1 (tests): the next resident launch loses its last workgroup
     bool defer_inner_sums = true;         // LBFGS_HIP_DEFER_SUMS=0: the two-loop's inner dots are reduced by their own kernels (A/B)
     double* dot_parts = nullptr;          // 2 x MAX_GRID: workgroup partials of the two-loop's inner dot products (ping-pong)
     DevCounters* dev_ctr = nullptr;       // device-resident sequence numbers (stream.h); the three fields below shadow them
@@ -290,14 +404,17 @@ struct ProfScope {
 };
 
 // the cross-workgroup hand-off part of a RedCtl for the NEXT reducing launch
-int fill_handoff(lbfgs_hip_ctx* ctx, RedCtl& red) {
+// `nred`: sums of that launch.  Kernels with more than RED_PTRS sums (the Gram rows) always take the ticket form, which
+// neither reads nor advances DevCounters::red_epoch -- the host's shadow of it must not count them either.
+int fill_handoff(lbfgs_hip_ctx* ctx, RedCtl& red, int nred) {
+    ctx->last_res.valid = false;  // (two_loop_impl sets it again after a resident launch)
     red.partials = ctx->partials;
     red.ticket = ctx->ticket;
     red.gran = ctx->gran;
     red.err = ctx->p2p_err;
     red.timeout_ticks = ctx->handoff_timeout_ticks;  // (10 s of the 100 MHz wall clock unless LBFGS_HIP_HANDOFF_TIMEOUT_MS says otherwise)
     red.ctr = ctx->dev_ctr;
-    red.tagged = ctx->handoff_ticket ? 0u : 1u;
+    red.tagged = (ctx->handoff_ticket || nred > RED_PTRS) ? 0u : 1u;
     if (red.tagged) {
         // the device walks the tags 1, 2, ..., 2^32-1, 1, ... by itself; when they come round, no granule of the buffer
         // may still carry a tag from the previous round
@@ -385,7 +502,7 @@ int prep_red(lbfgs_hip_ctx* ctx, RedCtl& red, int nred, double* const* red_out, 
     red.dup_ptr = dup_ptr;
     red.dup_k = dup_k;
     if (nred > 0) {
-        const int rc_h = fill_handoff(ctx, red);
+        const int rc_h = fill_handoff(ctx, red, nred);
         if (rc_h != LBFGS_HIP_OK) return rc_h;
     }
     if (nred <= RED_PTRS) {
@@ -432,6 +549,7 @@ template <class Op>
 int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out, double* dup_ptr = nullptr,
            int dup_k = 0, bool partials_only = false, unsigned int* grid_out = nullptr) {
     static_assert(Op::NRED <= MAX_RED, "the partials buffer holds MAX_RED sums per workgroup");
+    ctx->last_res.valid = false;
     RedCtl red{};
     bool in_kernel_exchange = false;
     if (partials_only) {
@@ -739,7 +857,7 @@ int lj_cells_eval(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, const lbfg
     const uint32_t grid = std::max(1u, std::min(want, (uint32_t)MAX_GRID));
     for (int attempt = 0;; ++attempt) {
         RedCtl red{};
-        if ((rc = fill_handoff(ctx, red)) != LBFGS_HIP_OK) return rc;
+        if ((rc = fill_handoff(ctx, red, 2)) != LBFGS_HIP_OK) return rc;
         red.out[0] = out;
         red.out[1] = lc->host_dev;  // the "moved too far" count goes straight to host-mapped memory
         // a cheap look first: has the list gone stale?  (then the evaluation kernel returns at once and the list is rebuilt)
@@ -785,7 +903,7 @@ int lj_eval(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, const lbfgs_hip_
     }
     RedCtl red{};
     {
-        const int rc_h = fill_handoff(ctx, red);
+        const int rc_h = fill_handoff(ctx, red, 1);
         if (rc_h != LBFGS_HIP_OK) return rc_h;
     }
     red.out[0] = out;
@@ -957,7 +1075,7 @@ int two_loop_gram_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
     {
         RedCtl red{};
         {
-            const int rc_h = fill_handoff(ctx, red);
+            const int rc_h = fill_handoff(ctx, red, 3 * NB);
             if (rc_h != LBFGS_HIP_OK) return rc_h;
         }
         red.out_contig = h->gram_rows;
@@ -1011,11 +1129,18 @@ int two_loop_gram_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
 static int two_loop_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
                          int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end,
                          bool owl, uint64_t owl_start, uint64_t owl_end);
+static int two_loop_eager(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
+                          int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end,
+                          bool owl, uint64_t owl_start, uint64_t owl_end);
 
+#if LH_RES_TRACE
+namespace { void res_trace_print(); }
+#endif
 // ==================================================================================== context
 extern "C" {
 
 int lbfgs_hip_abi_version(void) { return LBFGS_HIP_ABI_VERSION; }
+const char* lbfgs_hip_build_id(void) { return lbfgs_hip_build_id_marker + sizeof("LBFGS_HIP_BUILD_ID=") - 1; }
 
 int lbfgs_hip_device_count(int* count) {
     int c = 0;
@@ -1040,11 +1165,35 @@ int lbfgs_hip_rccl_unique_id(void* out128) {
 }
 
 int lbfgs_hip_p2p_mailbox_create(int device, void** mailbox_out, void* ipc_handle64_out) {
+    return lbfgs_hip_p2p_mailbox_create2(device, LBFGS_HIP_MAILBOX_AUTO, mailbox_out, ipc_handle64_out);
+}
+
+int lbfgs_hip_p2p_mailbox_create2(int device, int placement, void** mailbox_out, void* ipc_handle64_out) {
     if (!mailbox_out || !ipc_handle64_out) return fail(nullptr, LBFGS_HIP_ERR_ARG, "null argument");
     *mailbox_out = nullptr;
+    if (placement == LBFGS_HIP_MAILBOX_AUTO) {
+        const char* e = getenv("LBFGS_HIP_P2P_MAILBOX");
+        placement = (e && strcmp(e, "host") == 0) ? LBFGS_HIP_MAILBOX_HOST : LBFGS_HIP_MAILBOX_DEVICE;
+    }
+    if (placement != LBFGS_HIP_MAILBOX_DEVICE && placement != LBFGS_HIP_MAILBOX_HOST)
+        return fail(nullptr, LBFGS_HIP_ERR_ARG, "unknown mailbox placement %d", placement);
     hipError_t e = hipSetDevice(device);
-    void* p = nullptr;
     const size_t bytes = P2P_MBOX_WORDS * sizeof(unsigned long long);
+    if (placement == LBFGS_HIP_MAILBOX_HOST) {
+        if (e != hipSuccess) return fail(nullptr, LBFGS_HIP_ERR_COMM, "P2P mailbox: %s", hipGetErrorString(e));
+        static unsigned int serial = 0;
+        char name[48];
+        snprintf(name, sizeof(name), "/lbfgs_hip_mbox_%ld_%u_%08x", (long)getpid(), serial++, (unsigned int)std::chrono::steady_clock::now().time_since_epoch().count());
+        std::string err;
+        void* dev = host_mbox_map(name, bytes, true, &err);
+        if (!dev) return fail(nullptr, LBFGS_HIP_ERR_COMM, "P2P mailbox (host placement): %s", err.c_str());
+        memset(ipc_handle64_out, 0, HIP_IPC_HANDLE_SIZE);
+        memcpy(ipc_handle64_out, HOST_MBOX_MAGIC, sizeof(HOST_MBOX_MAGIC));
+        memcpy((char*)ipc_handle64_out + sizeof(HOST_MBOX_MAGIC), name, strlen(name) + 1);
+        *mailbox_out = dev;
+        return LBFGS_HIP_OK;
+    }
+    void* p = nullptr;
     if (e == hipSuccess) e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
     if (e == hipSuccess) e = hipMemset(p, 0, bytes);  // tag 0 is never a valid epoch
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -1062,6 +1211,7 @@ int lbfgs_hip_p2p_mailbox_create(int device, void** mailbox_out, void* ipc_handl
 void lbfgs_hip_p2p_mailbox_destroy(int device, void* mailbox) {
     if (!mailbox) return;
     (void)hipSetDevice(device);
+    if (host_mbox_release(mailbox)) return;
     (void)hipFree(mailbox);
 }
 
@@ -1141,6 +1291,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     if (const char* e = getenv("LBFGS_HIP_DEFER_SUMS")) ctx->defer_inner_sums = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT")) ctx->resident_on = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_GRID")) ctx->resident_grid = std::max(0, atoi(e));
+    if (const char* e = getenv("LBFGS_HIP_RESIDENT_FAULT")) ctx->resident_fault = atoi(e);
     if (const char* e = getenv("LBFGS_HIP_GRAM_COMBINE_RESIDENT")) ctx->gram_combine_resident = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_LJ_BUILD_FP32")) ctx->lj_build_fp32 = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_HANDOFF_TIMEOUT_MS")) ctx->handoff_timeout_ticks = (unsigned long long)std::max(1, atoi(e)) * 100000ULL;
@@ -1223,10 +1374,26 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
         }
         for (int r = 0; r < W; ++r) {  // (p2p_mbox[me] was taken over at the top)
             if (r == me) continue;
-            hipIpcMemHandle_t hdl;
-            memcpy(&hdl, (const char*)comm->p2p_handles + (size_t)r * HIP_IPC_HANDLE_SIZE, sizeof(hdl));
+            const char* hraw = (const char*)comm->p2p_handles + (size_t)r * HIP_IPC_HANDLE_SIZE;
             void* p = nullptr;
-            hipError_t e = hipIpcOpenMemHandle(&p, hdl, hipIpcMemLazyEnablePeerAccess);
+            if (memcmp(hraw, HOST_MBOX_MAGIC, sizeof(HOST_MBOX_MAGIC)) == 0) {  // HOST placement: the segment's name
+                char name[HIP_IPC_HANDLE_SIZE - sizeof(HOST_MBOX_MAGIC) + 1] = {0};
+                memcpy(name, hraw + sizeof(HOST_MBOX_MAGIC), HIP_IPC_HANDLE_SIZE - sizeof(HOST_MBOX_MAGIC));
+                std::string err;
+                p = host_mbox_map(name, P2P_MBOX_WORDS * sizeof(unsigned long long), false, &err);
+                if (!p) {
+                    int rc = fail(nullptr, LBFGS_HIP_ERR_COMM, "mailbox of rank %d (host placement): %s", r, err.c_str());
+                    lbfgs_hip_ctx_destroy(ctx);
+                    return rc;
+                }
+                ctx->p2p_mbox[r] = (unsigned long long*)p;  // (released through the registry: p2p_opened stays false)
+                continue;
+            }
+            hipIpcMemHandle_t hdl;
+            memcpy(&hdl, hraw, sizeof(hdl));
+            // (LBFGS_HIP_TEST_FAIL_IPC_OPEN=1: tests of the host-placement fallback pretend the mapping is refused)
+            hipError_t e = getenv("LBFGS_HIP_TEST_FAIL_IPC_OPEN") ? hipErrorInvalidValue
+                                                                  : hipIpcOpenMemHandle(&p, hdl, hipIpcMemLazyEnablePeerAccess);
             if (e != hipSuccess) {
                 int rc = fail(nullptr, LBFGS_HIP_ERR_COMM, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
                 lbfgs_hip_ctx_destroy(ctx);
@@ -1254,13 +1421,16 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
 
 void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* ctx) {
     if (!ctx) return;
+#if LH_RES_TRACE
+    res_trace_print();
+#endif
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->nccl && g_rccl.ok) g_rccl.CommDestroy(ctx->nccl);
     for (int r = 0; r < P2P_MAX_WORLD; ++r) {
         if (!ctx->p2p_mbox[r]) continue;
         if (ctx->p2p_opened[r]) (void)hipIpcCloseMemHandle(ctx->p2p_mbox[r]);
-        else (void)hipFree(ctx->p2p_mbox[r]);
+        else if (!host_mbox_release(ctx->p2p_mbox[r])) (void)hipFree(ctx->p2p_mbox[r]);
     }
     if (ctx->p2p_err) (void)hipFree(ctx->p2p_err);
     for (auto& pc : ctx->prof)
@@ -1281,6 +1451,26 @@ void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* ctx) {
     if (ctx->mirror) (void)hipHostFree(ctx->mirror);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+int lbfgs_hip_ctx_p2p_seal(lbfgs_hip_ctx* ctx, int* placement_out) {
+    if (!ctx) return LBFGS_HIP_ERR_ARG;
+    int placement = -1;
+    if (ctx->comm_kind == LBFGS_HIP_COMM_P2P) {
+        void* own = ctx->p2p_mbox[ctx->shard.rank];
+        placement = LBFGS_HIP_MAILBOX_DEVICE;
+        std::lock_guard<std::mutex> lk(g_host_mbox_mu);
+        auto it = g_host_mbox.find(own);
+        if (it != g_host_mbox.end()) {
+            placement = LBFGS_HIP_MAILBOX_HOST;
+            if (it->second.owner && it->second.linked) {
+                (void)shm_unlink(it->second.name.c_str());
+                it->second.linked = false;
+            }
+        }
+    }
+    if (placement_out) *placement_out = placement;
+    return LBFGS_HIP_OK;
 }
 
 const char* lbfgs_hip_last_error(const lbfgs_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -1339,6 +1529,7 @@ int lbfgs_hip_vec_alloc(lbfgs_hip_ctx* ctx, lbfgs_hip_vec** out) {
 
 void lbfgs_hip_vec_free(lbfgs_hip_vec* v) {
     if (!v) return;
+    v->ctx->last_res.valid = false;
     (void)hipStreamSynchronize(v->ctx->stream);
     (void)hipFree(v->p);
     delete v;
@@ -1370,6 +1561,7 @@ void* lbfgs_hip_vec_ptr(lbfgs_hip_vec* v) { return v ? (void*)v->p : nullptr; }
 
 int lbfgs_hip_vec_swap(lbfgs_hip_vec* a, lbfgs_hip_vec* b) {
     if (!same_ctx(a, b)) return LBFGS_HIP_ERR_ARG;
+    a->ctx->last_res.valid = false;
     double* t = a->p;
     a->p = b->p;
     b->p = t;
@@ -1383,9 +1575,8 @@ static int device_error(lbfgs_hip_ctx* ctx, unsigned int flag) {
     return fail(ctx, LBFGS_HIP_ERR_COMM, "P2P all-reduce timed out waiting for a peer");
 }
 
-int lbfgs_hip_scalars_read(lbfgs_hip_ctx* ctx, int first, int count, double* host) {
-    if (!ctx || !host || !slot_ok(first, count)) return LBFGS_HIP_ERR_ARG;
-    if (count == 0) return lbfgs_hip_sync(ctx);
+// one read; *flag receives the device error word that travelled with the results (0 = none)
+static int scalars_read_once(lbfgs_hip_ctx* ctx, int first, int count, double* host, unsigned int* flag_out) {
     if (ctx->mirror) {  // fast path: every requested slot was (or is being) published by a kernel's last workgroup
         bool all = true;
         for (int i = 0; i < count && all; ++i) all = ctx->mirror_valid[first + i];
@@ -1406,7 +1597,7 @@ int lbfgs_hip_scalars_read(lbfgs_hip_ctx* ctx, int first, int count, double* hos
                 // a timed-out in-kernel exchange is published next to the results (before the sequence word)
                 const volatile unsigned long long* perr =
                     reinterpret_cast<volatile unsigned long long*>(ctx->mirror + LBFGS_HIP_BOARD_SLOTS + 3);
-                if (*perr) return device_error(ctx, (unsigned int)*perr);
+                *flag_out = (unsigned int)*perr;
                 return LBFGS_HIP_OK;
             }
         }
@@ -1421,8 +1612,39 @@ int lbfgs_hip_scalars_read(lbfgs_hip_ctx* ctx, int first, int count, double* hos
     if (ctx->p2p_err) {
         unsigned int flag;
         memcpy(&flag, ctx->pinned + LBFGS_HIP_BOARD_SLOTS, sizeof(flag));
-        if (flag) return device_error(ctx, flag);
+        *flag_out = flag;
     }
+    return LBFGS_HIP_OK;
+}
+
+int lbfgs_hip_scalars_read(lbfgs_hip_ctx* ctx, int first, int count, double* host) {
+    if (!ctx || !host || !slot_ok(first, count)) return LBFGS_HIP_ERR_ARG;
+    if (count == 0) return lbfgs_hip_sync(ctx);
+    unsigned int flag = 0;
+    int rc = scalars_read_once(ctx, first, count, host, &flag);
+    if (rc != LBFGS_HIP_OK) return rc;
+    if (flag == 2u && ctx->last_res.valid && ctx->comm_kind == LBFGS_HIP_COMM_NONE) {
+        // The resident two-loop kernel waited in vain for a workgroup: it was not given every CU it asked for (another
+        // kernel-resident process or stream on this GPU, a CU-masked queue).  Nothing is lost: its inputs are intact.  Clear
+        // the error word, never use that kernel again in this context, and run the recursion with a kernel per step.
+        const lbfgs_hip_ctx::LastResident lr = ctx->last_res;
+        ctx->last_res.valid = false;
+        ctx->resident_ok = 0;
+        ctx->resident_fallbacks += 1;
+        fprintf(stderr, "[lbfgs_hip] warning: the on-chip-resident two-loop kernel timed out waiting for a workgroup (the GPU is "
+                        "shared with another resident kernel, or the queue is CU-masked); re-running this two-loop with a kernel per "
+                        "step and staying on that path (LBFGS_HIP_RESIDENT=0 avoids the wait)\n");
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->p2p_err, 0, sizeof(unsigned int), ctx->stream));
+        if (ctx->mirror) *reinterpret_cast<volatile unsigned long long*>(ctx->mirror + LBFGS_HIP_BOARD_SLOTS + 3) = 0ull;
+        int ne = 0;
+        rc = two_loop_eager(lr.h, lr.d, lr.g, lr.k, lr.end, lr.gnum, lr.gden, lr.dn, lr.first, &ne, lr.owl, lr.owl_start, lr.owl_end);
+        if (rc != LBFGS_HIP_OK) return rc;
+        flag = 0;
+        rc = scalars_read_once(ctx, first, count, host, &flag);
+        if (rc != LBFGS_HIP_OK) return rc;
+    }
+    if (flag) return device_error(ctx, flag);
     return LBFGS_HIP_OK;
 }
 
@@ -1700,6 +1922,46 @@ int lbfgs_hip_two_loop_owlqn(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs
 
 // ---- the two-loop as ONE kernel with the running vector resident in registers + LDS (resident.h) ----------------
 namespace {
+#if LH_RES_TRACE
+// A/B builds only (tools/handoff_trace.sh): workgroups 0 and G/2 leave wall-clock stamps (100 MHz) of every hand-off in
+// the ticket form's partials buffer -- entry, partial published, first poll back, totals known -- which are averaged here
+// over all launches of the process and printed when the context goes.
+struct ResTraceAcc {
+    double pre = 0, first_poll = 0, rest = 0, whole = 0, step = 0, polls = 0;
+    unsigned long long handoffs = 0, steps = 0;
+} g_res_trace[2];
+void res_trace_collect(lbfgs_hip_ctx* ctx, unsigned int first_tag, int handoffs) {
+    static unsigned long long host[2 * 64 * 8];
+    if (handoffs > 60 || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(host, ctx->partials, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess)
+        return;
+    for (int w = 0; w < 2; ++w) {
+        long long prev_end = 0;
+        for (int h = 0; h < handoffs; ++h) {
+            const unsigned long long* tr = host + ((size_t)w * 64 + ((first_tag + (unsigned int)h) & 63u)) * 8;
+            ResTraceAcc& a = g_res_trace[w];
+            a.pre += (double)(long long)(tr[1] - tr[0]);
+            a.first_poll += (double)(long long)(tr[2] - tr[1]);
+            a.rest += (double)(long long)(tr[3] - tr[2]);
+            a.whole += (double)(long long)(tr[3] - tr[0]);
+            a.polls += (double)tr[4];
+            a.handoffs += 1;
+            if (h > 0) { a.step += (double)((long long)tr[0] - prev_end); a.steps += 1; }
+            prev_end = (long long)tr[3];
+        }
+    }
+}
+void res_trace_print() {
+    for (int w = 0; w < 2; ++w) {
+        const ResTraceAcc& a = g_res_trace[w];
+        if (!a.handoffs) continue;
+        const double k = 10.0 / (double)a.handoffs;  // ticks of 10 ns -> ns per hand-off
+        fprintf(stderr, "[res-trace] workgroup %s: %llu hand-offs: whole %.0f ns = sums+publish %.0f + first poll back %.0f + until totals %.0f ; "
+                        "%.2f polls ; step between hand-offs %.0f ns\n", w ? "G/2" : "0", a.handoffs, a.whole * k, a.pre * k, a.first_poll * k,
+                a.rest * k, a.polls / (double)a.handoffs, a.steps ? a.step * 10.0 / (double)a.steps : 0.0);
+    }
+}
+#endif
 template <int ER, bool HYB = false>
 int resident_launch(lbfgs_hip_ctx* ctx, const ResArgs& ra, const RedCtl& red, int grid, size_t lds_bytes, bool nt) {
     auto kern_nt = two_loop_resident_kernel<ER, true, HYB>;
@@ -1765,6 +2027,28 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, two_loop_resident_kernel<ER_MAX, false, true>, BLOCK, lds_max);
         ctx->resident_ok = (e == hipSuccess && nb >= 1) ? 1 : 0;
         (void)hipGetLastError();
+        // ... and does this queue reach every CU the device reports?  A CU-masked stream (hipExtStreamCreateWithCUMask,
+        // HSA_CU_MASK / ROC_GLOBAL_CU_MASK) would leave part of the grid waiting for CUs it never gets: kernel per step then.
+        // (A partitioned device -- CPX / DPX -- reports its own CU count, so it needs no special case.)
+        if (ctx->resident_ok == 1) {
+            uint32_t mask[32] = {0};
+            if (hipExtStreamGetCUMask(ctx->stream, 32, mask) == hipSuccess) {
+                int cus = 0;
+                for (uint32_t w : mask) cus += __builtin_popcount(w);
+                if (cus > 0 && cus < ctx->cu_count) {
+                    ctx->resident_ok = 0;
+                    fprintf(stderr, "[lbfgs_hip] note: this stream reaches %d of the device's %d CUs (CU mask): the two-loop runs with a "
+                                    "kernel per step instead of the chip-wide resident kernel\n", cus, ctx->cu_count);
+                }
+            }
+            (void)hipGetLastError();
+            const char* gm = getenv("ROC_GLOBAL_CU_MASK");
+            const char* hm = getenv("HSA_CU_MASK");
+            if ((gm && *gm) || (hm && *hm)) {
+                ctx->resident_ok = 0;
+                fprintf(stderr, "[lbfgs_hip] note: a global CU mask is set in the environment: the two-loop runs with a kernel per step\n");
+            }
+        }
         if (getenv("LBFGS_HIP_VERBOSE"))
             fprintf(stderr, "[lbfgs_hip] resident two-loop kernel: %s (%s, %d workgroup(s) per CU with %zu bytes of LDS)\n",
                     ctx->resident_ok ? "usable" : "not usable", hipGetErrorString(e), nb, lds_max);
@@ -1803,10 +2087,15 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
         add(h->s[jat(i)]->p, h->y[jat(i - 1)]->p, jat(i), 1, 0, i, 0);
     add(h->s[jat(0)]->p, g->p, jat(0), 1, 0, 0, 1);  // last step: ||d||^2 and g.d
     ra.nsteps = ns;
+    ra.fault_drop_last = ctx->resident_fault > 0 ? 1 : 0;
+    if (ctx->resident_fault > 0) ctx->resident_fault -= 1;
 
     RedCtl red{};
     bool in_kernel_exchange = false;
     double* outs2[4] = {ra.out_dn, ra.out_dn + 1, ra.out_dn + 2, ra.out_dn + 3};
+#if LH_RES_TRACE
+    const unsigned int trace_first_tag = (unsigned int)(ctx->red_count % 0xFFFFFFFFull) + 1u;
+#endif
     const int rc_p = prep_red(ctx, red, owl ? 4 : 2, outs2, nullptr, 0, &in_kernel_exchange);
     if (rc_p != LBFGS_HIP_OK) return rc_p;
     // (one hand-off per step -- under OWL-QN the last step's travels after the projection, with four values -- plus one
@@ -1835,6 +2124,9 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
         }
     }
     if (rc != LBFGS_HIP_OK) return rc;
+#if LH_RES_TRACE
+    res_trace_collect(ctx, trace_first_tag, (int)handoffs);
+#endif
     ctx->resident_launches += 1;
     ctx->resident_elements = hybrid ? 2ull * per_round * (uint64_t)(er + el) : n;
     *new_end = e1;
@@ -1862,6 +2154,12 @@ static int two_loop_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip
     {  // small enough to keep the running vector on the chip?  then the whole recursion is one kernel
         const int rr = two_loop_resident(h, d, g, k, end, gamma_num_slot, gamma_den_slot, dnorm_slot, first_dot_slot, new_end, owl,
                                          owl_start, owl_end);
+        if (rr > 0 && ctx->comm_kind == LBFGS_HIP_COMM_NONE) {  // (see lbfgs_hip_ctx::last_res)
+            lbfgs_hip_ctx::LastResident& lr = ctx->last_res;
+            lr.valid = true; lr.h = h; lr.d = d; lr.g = g; lr.k = k; lr.end = end;
+            lr.gnum = gamma_num_slot; lr.gden = gamma_den_slot; lr.dn = dnorm_slot; lr.first = first_dot_slot;
+            lr.owl = owl; lr.owl_start = owl_start; lr.owl_end = owl_end;
+        }
         if (rr != 0) return rr < 0 ? rr : LBFGS_HIP_OK;
     }
     const uint64_t bound = std::min<uint64_t>((uint64_t)h->m, k);

@@ -51,6 +51,21 @@ constexpr int RES_UNROLL = 4;          // pairs whose loads are issued together 
 #ifndef LH_RES_HBM_UNROLL
 #define LH_RES_HBM_UNROLL 4
 #endif
+#ifndef LH_RES_SLIM
+#define LH_RES_SLIM 1  // hand-off with two workgroup barriers instead of five (res_exchange); 0 = the round-2 form (A/B builds)
+#endif
+#ifndef LH_RES_PREFETCH
+// where the NEXT step's first operand groups are loaded relative to the hand-off that yields its coefficient:
+//   0  right before the hand-off (round 2): HBM keeps streaming while the workgroups wait -- but a wave's loads return in
+//      order (vmcnt), so the polls of the hand-off cannot be read before those loads have come back;
+//   1  after the hand-off (A/B only: nothing in flight while the workgroups wait);
+//   2  inside the step's last on-chip group (the loads have returned when the step's own last operands have, the polls
+//      find an empty queue, and the window is ready when the coefficient is)
+#define LH_RES_PREFETCH 0
+#endif
+#ifndef LH_RES_TRACE
+#define LH_RES_TRACE 0  // 1: workgroups 0 and G/2 log wall-clock stamps of every hand-off into RedCtl::partials (tools/handoff_trace.py)
+#endif
 constexpr int RES_HBM_UNROLL = LH_RES_HBM_UNROLL;  // hybrid: rounds per group of the part of q that stays in HBM
 constexpr int RES_AHEAD = LH_RES_AHEAD;  // groups whose loads are in flight ahead of the group being worked on (2 was measured:
                                          // no faster at 1.25e7 elements, 4 % slower at 3e6 -- the hand-off is latency, not bandwidth)
@@ -82,6 +97,8 @@ struct ResArgs {
     uint32_t lds_pairs;         // of which in LDS (a multiple of RES_UNROLL)
     uint32_t hbm_pairs;         // hybrid: the rounds beyond registers + LDS, whose part of q lives in `d` itself (0: none)
     int nsteps;
+    int fault_drop_last;        // tests (LBFGS_HIP_RESIDENT_FAULT=1): the last workgroup leaves at once, as if it had never been
+                                // given a CU -- the others time out in their first hand-off and the host falls back
     ResStep step[RES_MAX_STEPS];
 };
 
@@ -92,11 +109,45 @@ struct ResArgs {
 //                 mailboxes (stream.h p2p_exchange, epoch `p2p_tag`; rank-ordered sum: the same bits on every rank) and
 //                 publishes the global totals as tagged granules in rows [8 + parity*4 + k], which the other workgroups
 //                 poll.  The mailbox is uncached and system-scope: one poller per GPU, not 256.
+// The hand-off is pure latency (nothing streams while a workgroup waits), so it is built from as few serial pieces as
+// possible: the workgroup's sums are formed with ONE barrier each (every thread adds the four wave sums itself, in
+// block_sum's order -- no second trip through LDS to broadcast), and the two sums use different LDS rows, so no barrier
+// separates the publish from the polls or one hand-off from the next: two barriers per hand-off (round 2: five).
+// `lds`: [8][WAVES], rows 0-3 for the sums a workgroup publishes, rows 4-7 for the totals it collects.  A row is written
+// before one of the two barriers and read right after it; its next write lies behind the OTHER barrier of the same or the
+// next hand-off, which no thread passes before every thread has finished that read.
+template <int NS>
+__device__ __forceinline__ void res_block_total(double (&acc)[NS], double (*rows)[WAVES]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const double w = wave_sum(acc[k]);
+        if (lane == 0) rows[k][wave] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {  // block_sum's order: the waves' sums, wave 0 first
+        double t = rows[k][0];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) t += rows[k][w];
+        acc[k] = t;
+    }
+}
+#if LH_RES_TRACE
+#define LH_TR(...) __VA_ARGS__
+#else
+#define LH_TR(...)
+#endif
 template <int NS>
 __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& red, const unsigned int tag, const unsigned int p2p_tag,
                                              const int parity, double (*lds)[WAVES], double* s_tot,
                                              unsigned int (*s_bits)[MAX_RED][2]) {
+    LH_TR(const long long tr0 = wall_clock64(); long long tr1 = 0, tr2 = 0; unsigned int tr_polls = 0;)
+#if LH_RES_SLIM
+    res_block_total<NS>(acc, lds);  // (every thread holds the workgroup's sums)
+#else
     block_sum<NS>(acc, lds);
+#endif
     const unsigned int G = gridDim.x;
     const bool multi = red.p2p.world > 1;
     const unsigned long long t = (unsigned long long)tag << 32;
@@ -109,7 +160,11 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
             __hip_atomic_store(g + 1, t | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    LH_TR(tr1 = wall_clock64();)
+#if !LH_RES_SLIM
     __syncthreads();  // lds is reused below
+#endif
+    double (*rows2)[WAVES] = LH_RES_SLIM ? lds + 4 : lds;
     double tot[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) tot[k] = 0.0;
@@ -127,6 +182,7 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
                 }
 #pragma unroll
                 for (int k = 0; k < NS; ++k) ok = ok && (unsigned int)(lo[k] >> 32) == tag && (unsigned int)(hi[k] >> 32) == tag;
+                LH_TR(if (tr_polls++ == 0) tr2 = wall_clock64();)
                 if (ok) break;
                 // (slow path only) give up after the timeout -- or at once if somebody already has: one missing workgroup must
                 // cost ONE timeout, not one per hand-off and workgroup
@@ -140,12 +196,24 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
 #pragma unroll
             for (int k = 0; k < NS; ++k) tot[k] += __longlong_as_double((long long)((hi[k] << 32) | (lo[k] & 0xffffffffULL)));
         }
-        block_sum<NS>(tot, lds);  // the reducer's order: thread-strided partials, wave tree, waves in order
+        // the reducer's order: thread-strided partials, wave tree, waves in order
+#if LH_RES_SLIM
+        res_block_total<NS>(tot, rows2);
+        if (multi) {  // (workgroup 0 only) p2p_exchange works on LDS
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) s_tot[k] = tot[k];
+            }
+            __syncthreads();
+        }
+#else
+        block_sum<NS>(tot, rows2);
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) s_tot[k] = tot[k];
         }
         __syncthreads();
+#endif
 #if LH_RES_P2P_ONE_HOP
         if (multi) p2p_publish(red.p2p, p2p_tag, s_tot, NS);  // (workgroup 0 only) this rank's totals to every rank's mailbox
     }
@@ -184,10 +252,32 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
         __syncthreads();
     }
 #endif
+#if LH_RES_SLIM
+    // (s_tot is written behind a barrier of this hand-off and next written behind one of the next: no barrier needed here)
+    if (multi) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] = s_tot[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] = tot[k];
+    }
+#else
 #pragma unroll
     for (int k = 0; k < NS; ++k) acc[k] = s_tot[k];
     __syncthreads();  // s_tot and lds are free again
+#endif
+#if LH_RES_TRACE
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == (G >> 1))) {
+        unsigned long long* tr = reinterpret_cast<unsigned long long*>(red.partials) + ((size_t)(blockIdx.x ? 1 : 0) * 64 + (tag & 63u)) * 8;
+        tr[0] = (unsigned long long)tr0;
+        tr[1] = (unsigned long long)tr1;
+        tr[2] = (unsigned long long)tr2;
+        tr[3] = (unsigned long long)wall_clock64();
+        tr[4] = tr_polls;
+    }
+#endif
 }
+#undef LH_TR
 
 // One step over this thread's pairs.  MODE 0: q += c*u ; acc0 += v.q     (3 streams -> 2: u and v)
 //                                     MODE 1: q = (q + c*u)*gamma ; acc0 += u.q   (the gamma transition)
@@ -448,13 +538,23 @@ struct ResRegStep {
         }
     }
 };
-// one whole step; on entry the window holds the operands of groups 0 .. RES_AHEAD-1, on exit nothing
-template <int ER, bool NT, int MODE>
+// one whole step; on entry the window holds the operands of groups 0 .. RES_AHEAD-1, on exit nothing.
+// EARLY (LH_RES_PREFETCH == 2): the window of the NEXT step (operands nup, nvp) is loaded into `wnext` while the last
+// on-chip group of this step is worked on -- every step has at least one LDS group -- so that those loads have returned
+// when this step's own last operands have: a wave's loads return in order, and the polls of the hand-off that follows
+// must not queue behind a window of HBM loads.
+template <int ER, bool NT, int MODE, bool EARLY>
 __device__ __forceinline__ void res_step(ResWin& w, d2* q_lds, const ResPos& ps, const double* up, const double* vp, const double c,
-                                         const double gamma, double* acc) {
+                                         const double gamma, double* acc, ResWin& wnext, const double* nup, const double* nvp) {
     ResRegStep<0, ER, NT, MODE>::run(w, ps, up, vp, c, gamma, acc);
     const uint32_t tid = threadIdx.x, NL = ps.EL / RES_UNROLL;
     for (uint32_t j = 0; j < NL; ++j) {
+        if constexpr (EARLY) {
+            if (j + 1 == NL) {
+                ResFetch<ER, NT, true>::window(wnext, ps, nup, nvp);
+                asm volatile("" ::: "memory");
+            }
+        }
         d2 fu[RES_UNROLL], fv[RES_UNROLL];
         ResFetch<ER, NT, MODE != 1>::lds(j + RES_AHEAD, ps, up, vp, fu, fv);
         asm volatile("" ::: "memory");
@@ -596,11 +696,12 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
     static_assert(ER % RES_UNROLL == 0 && ER >= 0 && 4 * ER <= 256, "pairs in AGPRs (ER = 0: everything in LDS)");
     asm volatile("" ::: "a255");  // this kernel owns the whole accumulation register file (the wave gets 512 registers)
     extern __shared__ d2 q_lds[];  // [lds_pairs][BLOCK]
-    __shared__ double lds[4][WAVES];
+    __shared__ double lds[8][WAVES];  // (res_exchange: rows 0-3 and 4-7)
     __shared__ double s_tot[4];
     __shared__ double s_alpha[RES_MAX_STEPS / 2];
     __shared__ unsigned int s_bits[P2P_MAX_WORLD][MAX_RED][2];  // (p2p_exchange's staging: 4 KiB; unused with one rank)
     constexpr int NG = ER / RES_UNROLL;
+    if (a.fault_drop_last && blockIdx.x == gridDim.x - 1 && gridDim.x > 1) return;  // (uniform per workgroup; see ResArgs)
     const DevCounters c0 = load_counters(red);
     // 32-bit pair indices (the host admits only shards of < 2^28 pairs): one uniform stride, one add per element
     const uint32_t n2 = (uint32_t)(a.n >> 1);
@@ -654,8 +755,11 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
     int parity = 0;
     double dot;
     // (see ResWin: the next step's first groups are loaded BEFORE the hand-off that yields its coefficient)
-    ResWin win;
+    ResWin win, wnext;
     const ResPos ps{p_first, p_stride, n2, EL};
+    // (hybrid: the HBM rounds follow the on-chip groups and need the registers an early window would hold)
+    constexpr int PF = HYB ? (LH_RES_PREFETCH == 2 ? 0 : LH_RES_PREFETCH) : LH_RES_PREFETCH;
+    constexpr bool EARLY = PF == 2;
     auto prefetch = [&](const int si) {
         const double* up = a.step[si].u;
         const double* vp = a.step[si].v ? a.step[si].v : up;  // (the gamma transition has no v: those loads go unused)
@@ -694,20 +798,25 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         const double* qsrc = si == 0 ? a.g : a.d;  // (hybrid rounds only)
         const double qsign = si == 0 ? -1.0 : 1.0;
         const bool rev = LH_RES_HBM_ALTERNATE && (si & 1);  // (see LH_RES_HBM_ALTERNATE)
+        // the next step's operands (EARLY: loaded inside this step; past the last step: this step's again, unused)
+        const int sn = si + 1 < a.nsteps ? si + 1 : si;
+        const double* nup = a.step[sn].u;
+        const double* nvp = a.step[sn].v ? a.step[sn].v : nup;
         if (mode == 0) {
-            res_step<ER, NT, 0>(win, q_lds, ps, st.u, st.v, c, gamma, acc);
+            res_step<ER, NT, 0, EARLY>(win, q_lds, ps, st.u, st.v, c, gamma, acc, wnext, nup, nvp);
             if constexpr (HYB) res_step_hbm<NT, 0>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc, ow);
         } else if (mode == 1) {
-            res_step<ER, NT, 1>(win, q_lds, ps, st.u, st.u, c, gamma, acc);
+            res_step<ER, NT, 1, EARLY>(win, q_lds, ps, st.u, st.u, c, gamma, acc, wnext, nup, nvp);
             if constexpr (HYB) res_step_hbm<NT, 1>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.u, c, gamma, acc, ow);
         } else {
-            res_step<ER, NT, 2>(win, q_lds, ps, st.u, st.v, c, gamma, acc);
+            res_step<ER, NT, 2, EARLY>(win, q_lds, ps, st.u, st.v, c, gamma, acc, wnext, nup, nvp);
             if constexpr (HYB) {
                 if (a.owl) res_step_hbm<NT, 3>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc, ow);  // (projected here)
                 else res_step_hbm<NT, 2>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc, ow);
             }
         }
-        if (si + 1 < a.nsteps) prefetch(si + 1);
+        if constexpr (EARLY) win = wnext;
+        else if constexpr (PF == 0) { if (si + 1 < a.nsteps) prefetch(si + 1); }
         if (tail_owner) {
             const double ut = st.u[a.n - 1], vt = (mode == 1) ? ut : st.v[a.n - 1];
             q_tail = q_tail + c * ut;
@@ -732,6 +841,7 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         tag = next_epoch(tag);
         ptag = next_epoch(ptag);
         parity ^= 1;
+        if constexpr (PF == 1) { if (si + 1 < a.nsteps) prefetch(si + 1); }
     }
 
     // ---- d = q (OWL-QN: projected, with the sums of the projected direction) ; totals

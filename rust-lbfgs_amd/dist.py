@@ -10,6 +10,7 @@ cross-rank traffic is a sum all-reduce of 1-6 f64 scalars per reduction -- RCCL
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -58,17 +59,19 @@ def rccl_comm(process_group=None):
     return CommSpec(_ffi.COMM_RCCL, unique_id=buf)
 
 
-def p2p_comm(device, process_group=None, timeout_s=5.0, exclusive_device=False):
-    """Direct xGMI exchange: every rank exports its mailbox by IPC handle, torch.distributed gathers them.
+def p2p_comm(device, process_group=None, timeout_s=5.0, exclusive_device=False, placement=_ffi.MAILBOX_AUTO):
+    """Direct exchange between the GPUs: every rank exports its mailbox by a 64-byte handle, torch.distributed gathers them.
     exclusive_device=True tells the library that no other rank shares this rank's GPU (lbfgs_hip_comm.exclusive_device):
-    only then does it use kernels that fill the whole chip while they wait for their peers."""
+    only then does it use kernels that fill the whole chip while they wait for their peers.
+    placement: MAILBOX_DEVICE (uncached HBM, mapped by the peers through HIP IPC over xGMI), MAILBOX_HOST (a shared-memory
+    segment registered with HIP: host-coherent, reached over PCIe) or MAILBOX_AUTO (LBFGS_HIP_P2P_MAILBOX, default device)."""
     import torch.distributed as dist
 
     L = _ffi.load()
     world = dist.get_world_size(process_group)
     mbox = C.c_void_p()
     hdl = (C.c_char * 64)()
-    rc = L.lbfgs_hip_p2p_mailbox_create(device, C.byref(mbox), hdl)
+    rc = L.lbfgs_hip_p2p_mailbox_create2(device, placement, C.byref(mbox), hdl)
     ok = [None] * world
     dist.all_gather_object(ok, (rc, bytes(hdl.raw)), group=process_group)
     if any(r != 0 for r, _ in ok):
@@ -86,6 +89,31 @@ def p2p_comm(device, process_group=None, timeout_s=5.0, exclusive_device=False):
     spec.c.p2p_timeout_s = timeout_s
     spec.c.exclusive_device = int(bool(exclusive_device))
     return spec
+
+
+def _p2p_context(n, device, shard, process_group, stream, exclusive_device, placement):
+    """The P2P context of this rank, created COLLECTIVELY: every rank learns whether every rank succeeded (one rank that
+    cannot map a peer's mailbox must not leave the others with a context nobody will answer in).  Returns
+    (ctx or None, this rank's error or None)."""
+    import torch.distributed as dist
+
+    ctx, err = None, None
+    try:
+        comm = p2p_comm(device, process_group, exclusive_device=exclusive_device, placement=placement)
+        ctx = Context(n, device=device, shard=shard, comm=comm, stream=stream)
+    except LbfgsError as e:
+        err = e
+    oks = [None] * dist.get_world_size(process_group)
+    dist.all_gather_object(oks, err is None, group=process_group)
+    if all(oks):
+        # every rank has mapped every mailbox: a host-placed segment can lose its name now (nothing outlives the processes)
+        placed = C.c_int(-1)
+        ctx.check(ctx._L.lbfgs_hip_ctx_p2p_seal(ctx._h, C.byref(placed)))
+        ctx.p2p_placement = {0: "device", 1: "host"}.get(placed.value)
+        return ctx, None
+    if ctx is not None:
+        ctx.close()
+    return None, err or LbfgsError(_ffi.HIP_ERR_COMM, "the P2P communicator failed on another rank")
 
 
 def callback_comm(process_group=None):
@@ -106,23 +134,42 @@ def callback_comm(process_group=None):
     return CommSpec(_ffi.COMM_CALLBACK, callback=_ffi.ALLREDUCE_CB(allreduce))
 
 
-def sharded_context(n, device=0, kind="rccl", process_group=None, stream=None, exclusive_device=False):
-    """Context for this rank's shard of a global n-vector (world from torch.distributed).  exclusive_device: see p2p_comm."""
+def sharded_context(n, device=0, kind="rccl", process_group=None, stream=None, exclusive_device=False, bounds=None):
+    """Context for this rank's shard of a global n-vector (world from torch.distributed).  exclusive_device: see p2p_comm.
+    bounds: explicit shard boundaries [0, b_1, ..., b_{world-1}, n] (non-decreasing; default: shard_range's even split)."""
     import torch.distributed as dist
 
     rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
-    lo, hi = shard_range(n, rank, world)
+    if bounds is not None:
+        if len(bounds) != world + 1 or bounds[0] != 0 or bounds[-1] != n or any(a > b for a, b in zip(bounds, bounds[1:])):
+            raise ValueError("bounds must be [0, ..., n], non-decreasing, one entry more than there are ranks")
+        lo, hi = bounds[rank], bounds[rank + 1]
+    else:
+        lo, hi = shard_range(n, rank, world)
     shard = _ffi.Shard(rank, world, n, lo, hi - lo)
-    import os
-
     if world == 1 and not (kind == "rccl" and os.environ.get("LBFGS_FORCE_RCCL") == "1"):
         comm = None  # (LBFGS_FORCE_RCCL=1 exercises the RCCL code path with a 1-rank communicator)
     elif kind == "rccl":
         comm = rccl_comm(process_group)
     elif kind == "callback":
         comm = callback_comm(process_group)
-    elif kind == "p2p":
-        comm = p2p_comm(device, process_group, exclusive_device=exclusive_device)
+    elif kind in ("p2p", "p2p-device", "p2p-host"):
+        # "p2p": mailboxes in device memory, mapped by the peers through HIP IPC (xGMI) -- unless LBFGS_HIP_P2P_MAILBOX says
+        # otherwise -- and, if ANY rank fails there (hipIpcOpenMemHandle of a peer's device memory refused), every rank
+        # retries with host-placed mailboxes (shared memory, PCIe): same kernels, same bits, more latency per exchange.
+        # "p2p-device" / "p2p-host" force one placement, no retry.
+        first = {"p2p": _ffi.MAILBOX_AUTO, "p2p-device": _ffi.MAILBOX_DEVICE, "p2p-host": _ffi.MAILBOX_HOST}[kind]
+        ctx, err = _p2p_context(n, device, shard, process_group, stream, exclusive_device, first)
+        if ctx is None and kind == "p2p" and os.environ.get("LBFGS_HIP_P2P_MAILBOX", "device") != "host":
+            if rank == 0:
+                import sys
+
+                print(f"[lbfgs_hip] P2P mailboxes in device memory are not usable here ({err}); retrying with host-placed "
+                      "mailboxes", file=sys.stderr)
+            ctx, err = _p2p_context(n, device, shard, process_group, stream, exclusive_device, _ffi.MAILBOX_HOST)
+        if ctx is None:
+            raise err
+        return ctx
     else:
         raise ValueError(kind)
     return Context(n, device=device, shard=shard, comm=comm, stream=stream)

@@ -23,14 +23,41 @@ HDRS = [os.path.join(ROOT, "include", "lbfgs_hip.h"), os.path.join(ROOT, "includ
         os.path.join(ROOT, "oracle", "lbfgs_oracle.h")]
 
 
+def _build_id(flags):
+    """content hash of everything the test double is compiled from (same scheme as rust-lbfgs_amd/_build.py)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for p in SRCS + C_SRCS + HDRS:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    for fl in flags:
+        h.update(fl.encode() + b"\0")
+    return h.hexdigest()[:16]
+
+
+def _embedded_id(lib):
+    import re
+
+    try:
+        with open(lib, "rb") as f:
+            m = re.search(rb"LBFGS_MOCK_BUILD_ID=([0-9a-f]{16})", f.read())
+    except OSError:
+        return None
+    return m.group(1).decode() if m else None
+
+
 def build(force=False):
-    deps = SRCS + C_SRCS + HDRS
-    if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
-        return LIB
     objs = []
     flags = ["-O2", "-ffp-contract=off", "-fPIC", "-Wall"]
     if SANITIZE:
         flags = ["-O1", "-g", "-ffp-contract=off", "-fPIC", "-Wall", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+    want = _build_id(flags)
+    if not force and _embedded_id(LIB) == want:  # (by content, never by modification time)
+        return LIB
+    flags = flags + ['-DLBFGS_MOCK_BUILD_ID="%s"' % want]
     for s in C_SRCS:
         o = os.path.join(HERE, os.path.basename(s) + (".asan.o" if SANITIZE else ".o"))
         subprocess.run(["gcc", "-std=c11", *flags, "-c", s, "-o", o], check=True, capture_output=True)

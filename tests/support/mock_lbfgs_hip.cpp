@@ -77,7 +77,18 @@ int lbfgs_hip_abi_version(void) { return LBFGS_HIP_ABI_VERSION; }
 int lbfgs_hip_device_count(int* count) { *count = 0; return LBFGS_HIP_OK; }
 int lbfgs_hip_rccl_unique_id(void*) { return fail(nullptr, LBFGS_HIP_ERR_COMM, "mock: no RCCL"); }
 int lbfgs_hip_p2p_mailbox_create(int, void**, void*) { return fail(nullptr, LBFGS_HIP_ERR_COMM, "mock: no P2P"); }
+int lbfgs_hip_p2p_mailbox_create2(int, int, void**, void*) { return fail(nullptr, LBFGS_HIP_ERR_COMM, "mock: no P2P"); }
 void lbfgs_hip_p2p_mailbox_destroy(int, void*) {}
+int lbfgs_hip_ctx_p2p_seal(lbfgs_hip_ctx* ctx, int* placement_out) {
+    if (!ctx) return LBFGS_HIP_ERR_ARG;
+    if (placement_out) *placement_out = -1;
+    return LBFGS_HIP_OK;
+}
+#ifndef LBFGS_MOCK_BUILD_ID
+#define LBFGS_MOCK_BUILD_ID "unstamped"
+#endif
+static const char mock_build_id_marker[] = "LBFGS_MOCK_BUILD_ID=" LBFGS_MOCK_BUILD_ID;
+const char* lbfgs_hip_build_id(void) { return mock_build_id_marker + sizeof("LBFGS_MOCK_BUILD_ID=") - 1; }
 
 int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int, uint64_t n, const lbfgs_hip_shard* shard, const lbfgs_hip_comm* comm,
                          void*) {

@@ -64,7 +64,56 @@ def test_product_libraries_do_not_link_the_oracle(libs):
 
 
 def test_abi_version(libs):
-    assert libs[0].lbfgs_hip_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "lbfgs_hip.h")).read()
+    want = int(re.search(r"#define LBFGS_HIP_ABI_VERSION (\d+)", hdr).group(1))
+    assert want == 2
+    assert libs[0].lbfgs_hip_abi_version() == want == _ffi.ABI_VERSION
+    # the other callers written against the header compare before anything else
+    assert re.search(r"pub const LBFGS_HIP_ABI_VERSION: i32 = %d;" % want, open(RUST_FFI).read())
+    assert "lbfgs_hip_abi_version() != ffi::LBFGS_HIP_ABI_VERSION" in open(
+        os.path.join(ROOT, "integration", "rust-shim", "src", "lib.rs")).read()
+    assert "lbfgs_hip_abi_version() == LBFGS_HIP_ABI_VERSION" in open(os.path.join(ROOT, "tests", "support", "c_caller.c")).read()
+
+
+def test_loader_refuses_another_abi_version(libs, monkeypatch):
+    """The Python binding shares struct layouts with the library by value: a library of another ABI version is refused."""
+    monkeypatch.setattr(_ffi, "ABI_VERSION", 1)
+    prev, _ffi._LIB = _ffi._LIB, None
+    try:
+        with pytest.raises(ImportError, match="ABI version"):
+            _ffi.load()
+    finally:
+        _ffi._LIB = prev
+
+
+def test_libraries_carry_the_hash_of_the_checked_out_sources(libs, tmp_path):
+    """Builds are content-addressed (rust-lbfgs_amd/_build.py): the libraries these tests run on were compiled from exactly
+    the sources and flags in this tree.  Prebuilt, git-ignored libraries travel with snapshots; a stale one is detected by
+    its id, whatever the modification times say."""
+    libs[0].lbfgs_hip_build_id.restype = C.c_char_p
+    libs[1].lbfgs_solver_build_id.restype = C.c_char_p
+    assert libs[0].lbfgs_hip_build_id().decode() == _build.hip_build_id() == _build.embedded_id(_build.HIP_LIB, "LBFGS_HIP_BUILD_ID")
+    assert libs[1].lbfgs_solver_build_id().decode() == _build.solver_build_id() == _build.embedded_id(
+        _build.SOLVER_LIB, "LBFGS_SOLVER_BUILD_ID")
+    assert re.fullmatch(r"[0-9a-f]{16}", _build.hip_build_id())
+    # staleness is decided by content: a library newer than every source is stale if the sources differ ...
+    src = tmp_path / "a.c"
+    src.write_text("int f(void) { return 1; }\n")
+    id1 = _build.source_hash([str(src)], ["-O2"])
+    lib = tmp_path / "lib.bin"
+    lib.write_bytes(b"\x7fELF....X_ID=" + id1.encode() + b"\0....")
+    assert not _build._stale(str(lib), "X_ID", id1)
+    src.write_text("int f(void) { return 2; }\n")
+    os.utime(src, (1, 1))  # ... however old the edited source looks
+    assert _build._stale(str(lib), "X_ID", _build.source_hash([str(src)], ["-O2"]))
+    # ... and flags are part of the identity
+    src.write_text("int f(void) { return 1; }\n")
+    assert _build.source_hash([str(src)], ["-O2"]) == id1 != _build.source_hash([str(src)], ["-O3"])
+    assert _build._stale(str(tmp_path / "missing.so"), "X_ID", id1)
+    # the test infrastructure is built the same way
+    from oracle import oracle as O
+
+    assert O.embedded_id(O.build()) == O.source_id()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -151,7 +200,7 @@ def test_no_kernel_uses_scratch_memory(libs):
     array dynamically gets a private-segment (scratch) allocation, and on MI355X that costs ~12 us of extra dispatch
     time on EVERY launch of it (measured in round 2: a by-value copy of a small struct did it).  The build keeps the
     compiler's per-kernel resource report next to the library."""
-    if not os.path.exists(_build.RESOURCES) or os.path.getmtime(_build.RESOURCES) < os.path.getmtime(_build.HIP_LIB) - 5:
+    if not os.path.exists(_build.RESOURCES):
         _build.build_hip(force=True)
     txt = open(_build.RESOURCES).read()
     names = re.findall(r"Function Name: (\S+)", txt)

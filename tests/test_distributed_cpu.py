@@ -29,9 +29,12 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 case = json.loads(os.environ["LBFGS_CASE"])
 n = case["n"]
+bounds = json.loads(os.environ.get("LBFGS_TEST_BOUNDS", "null"))     # uneven shards: [0, b1, ..., n]
+if os.environ.get("LBFGS_TEST_RESIDENT_GRIDS"):                      # workgroups of the resident kernel, per rank
+    os.environ["LBFGS_HIP_RESIDENT_GRID"] = os.environ["LBFGS_TEST_RESIDENT_GRIDS"].split(",")[rank]
 ctx = D.sharded_context(n, kind=os.environ.get("LBFGS_COMM_KIND", "callback"),
-                        exclusive_device=os.environ.get("LBFGS_TEST_EXCLUSIVE_DEVICE") == "1")
-lo, hi = D.shard_range(n, rank, world)
+                        exclusive_device=os.environ.get("LBFGS_TEST_EXCLUSIVE_DEVICE") == "1", bounds=bounds)
+lo, hi = (bounds[rank], bounds[rank + 1]) if bounds else D.shard_range(n, rank, world)
 assert ctx.n_local == hi - lo and ctx.shard.offset == lo
 b = R.lbfgs().with_m(case["m"]).with_max_iterations(case["iters"]).with_epsilon(0.0)
 if case.get("owl"):
@@ -72,6 +75,7 @@ try:
 except R.LbfgsError as e:
     err = e.code
     xs = x
+placement = getattr(ctx, "p2p_placement", None)
 ctx_resident = ctx.resident_two_loops()
 ctx_resident_elements = ctx.resident_elements()
 nred, _ = ctx.prof_read(_ffi.K_COMM)   # the test double counts its all-reduces here
@@ -79,7 +83,7 @@ if os.environ.get("LBFGS_WORKER_PRODUCT") == "1":
     nred = 1
 ctx.close()
 out = dict(rank=rank, lo=lo, hi=hi, rows=rows, x=xs.tolist(), allreduces=nred, err=err,
-           resident=ctx_resident, resident_elements=ctx_resident_elements)
+           resident=ctx_resident, resident_elements=ctx_resident_elements, placement=placement)
 json.dump(out, open(os.path.join(os.environ["LBFGS_OUT"], f"rank{rank}.json"), "w"))
 dist.barrier()
 dist.destroy_process_group()
@@ -281,28 +285,103 @@ def test_bench_supervisor_two_ranks(launcher):
 
 @pytest.mark.parametrize("launcher", [False, True], ids=["plain_python", "torch_distributed_run"])
 def test_bench_supervisor_survives_a_hung_and_a_failed_leg(launcher):
-    """A leg that never returns is killed at --leg-timeout, a leg whose communicator does not exist (the test double has
-    no RCCL) fails, and the run still prints the line of the leg that worked and exits 0."""
+    """A leg that never returns is killed at its timeout, a communicator that does not exist (the test double has no RCCL)
+    fails its PROBE and is never measured, and the run still prints the line of the leg that worked and exits 0."""
     p = _run_bench(["--leg-timeout", "15"], launcher, legs="hang,rccl,callback")
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout
-    legs = json.loads(lines[0])["config"]["legs"]
-    assert "timed out" in legs["hang"]["status"] and legs["rccl"]["status"] != "ok" and legs["callback"]["status"] == "ok"
+    cfg = json.loads(lines[0])["config"]
+    legs, probes = cfg["legs"], cfg["probes"]
+    assert probes["hang"]["status"] == "ok" and probes["rccl"]["status"] != "ok" and probes["callback"]["status"] == "ok"
+    assert "timed out" in legs["hang"]["status"] and "rccl" not in legs and legs["callback"]["status"] == "ok"
 
 
 def test_bench_supervisor_default_leg_order():
-    """No --comm: p2p (persistent two-loop kernel), then -- because it failed: the test double has no P2P -- the same
-    communicator with a kernel per step, then rccl, and the host-staged callback only because none of them worked."""
-    p = _run_bench(["--leg-timeout", "60"], False)
+    """No --comm: the communicators are probed in the order p2p, p2p-host, rccl; the test double has none of them, so no leg
+    is measured and the host-staged callback runs as the last resort -- only because nothing else produced a result."""
+    p = _run_bench(["--probe-timeout", "60"], False)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout
-    legs = json.loads(lines[0])["config"]["legs"]
-    assert list(legs) == ["p2p", "p2p-per-step", "rccl", "callback"]
-    assert [legs[k]["status"] == "ok" for k in legs] == [False, False, False, True]
+    cfg = json.loads(lines[0])["config"]
+    assert list(cfg["probes"]) == ["p2p", "p2p-host", "rccl"]
+    assert all(v["status"] != "ok" for v in cfg["probes"].values())
+    assert list(cfg["legs"]) == ["callback"] and cfg["legs"]["callback"]["status"] == "ok"
 
 
-def test_bench_supervisor_reports_failure_when_no_leg_works():
-    p = _run_bench(["--leg-timeout", "60", "--comm", "rccl"], False)  # the test double has no RCCL; no fallback when a leg is forced
-    assert p.returncode != 0 and not p.stdout.strip()
+@pytest.mark.parametrize("launcher", [True], ids=["torch_distributed_run"])   # (the driver's launch form for N > 1)
+def test_bench_supervisor_two_hung_legs_stay_inside_the_budget(launcher):
+    """Two legs in a row that never return: each is killed at ITS SHARE of what is left of --total-budget (not at a fixed
+    per-leg timeout), so the leg behind them still gets its turn and the whole run ends inside the budget with a line."""
+    import time
+
+    t0 = time.monotonic()
+    p = _run_bench(["--total-budget", "80", "--leg-timeout", "60"], launcher, legs="hang,hang2,callback", timeout=200)
+    wall = time.monotonic() - t0
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    cfg = json.loads(lines[0])["config"]
+    legs = cfg["legs"]
+    assert "timed out" in legs["hang"]["status"] and "timed out" in legs["hang2"]["status"] and legs["callback"]["status"] == "ok"
+    # the shares: a third, then half of what was left (never the 60 s the option would allow)
+    assert legs["hang"]["timeout_s"] <= 27.0 and legs["hang2"]["timeout_s"] <= 32.0, legs
+    assert cfg["budget"]["used_s"] <= 80.0 and wall < 105.0, (cfg["budget"], wall)
+
+
+def test_bench_supervisor_failed_or_hung_probe_skips_its_leg():
+    """Only communicators whose probe passed are measured: a probe that fails and a probe that never returns (killed at the
+    probe timeout) both keep their legs out of phase 2."""
+    p = _run_bench(["--probe-timeout", "6"], False, legs="failprobe,hangprobe,callback")
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    cfg = json.loads(lines[0])["config"]
+    assert cfg["probes"]["failprobe"]["status"] != "ok" and "timed out" in cfg["probes"]["hangprobe"]["status"]
+    assert cfg["probes"]["callback"]["status"] == "ok"
+    assert list(cfg["legs"]) == ["callback"] and cfg["legs"]["callback"]["status"] == "ok"
+
+
+def test_bench_supervisor_sigterm_prints_the_best_line_so_far():
+    """The driver's clock runs out in the middle of a leg: SIGTERM ends the running job and the run prints the line of the
+    legs that HAVE finished (exit code 0), instead of dying with nothing."""
+    import signal
+    import threading
+    import time
+
+    env = dict(os.environ, LBFGS_BENCH_WORKER=os.path.join(ROOT, "tests", "support", "bench_on_mock.py"),
+               OMP_NUM_THREADS="1", LBFGS_BENCH_LEGS="callback,hang")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "12", "--dim", "3000",
+           "--hist", "5", "--repeats", "2", "--no-vector-free", "--total-budget", "400", "--leg-timeout", "300"]
+    p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    seen, err_lines = threading.Event(), []
+
+    def watch():
+        for ln in p.stderr:
+            err_lines.append(ln)
+            if "[bench] leg callback" in ln:
+                seen.set()
+
+    th = threading.Thread(target=watch, daemon=True)
+    th.start()
+    assert seen.wait(timeout=150), "".join(err_lines)[-2000:]
+    time.sleep(2.0)  # the hung leg is running now
+    p.send_signal(signal.SIGTERM)
+    out = p.stdout.read()
+    rc = p.wait(timeout=60)
+    th.join(timeout=10)
+    assert rc == 0, "".join(err_lines)[-2000:]
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1, out
+    j = json.loads(lines[0])
+    assert j["value"] > 0 and j["config"]["interrupted_by_signal"] == signal.SIGTERM
+    assert j["config"]["legs"]["callback"]["status"] == "ok" and "hang" not in j["config"]["legs"]
+    # nothing of the hung job is left behind: its whole process group is gone
+    import re
+
+    m = re.search(r"running job's process group: (\d+)", "".join(err_lines))
+    assert m, "".join(err_lines)[-1000:]
+    time.sleep(0.5)
+    with pytest.raises(ProcessLookupError):
+        os.killpg(int(m.group(1)), 0)

@@ -22,16 +22,20 @@ pytestmark = pytest.mark.gpu
     dict(name="owlqn_straddle", n=30_001, m=6, iters=20, objective="logistic", owl=[0.5, 7000, 29000]),
     dict(name="host_closure", n=1000, m=4, iters=12, objective="closure"),
 ], ids=lambda c: c["name"])
-@pytest.mark.parametrize("kind", ["callback", "p2p"])
+@pytest.mark.parametrize("kind", ["callback", "p2p", "p2p-host"])
 def test_two_processes_one_gpu(case, kind, tmp_path, monkeypatch):
     """kind = "p2p": the direct-exchange communicator (IPC mailboxes, tagged granules) between two
-    processes whose "peer" is the same GPU -- the protocol is identical to the 8-GPU xGMI case."""
+    processes whose "peer" is the same GPU -- the protocol is identical to the 8-GPU xGMI case.
+    kind = "p2p-host": the same exchange with the mailboxes in host-coherent shared memory (the second placement:
+    what a machine falls back to when device memory cannot be mapped between its GPUs)."""
     if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
         pytest.skip("covered by tests/test_distributed_cpu.py")
     monkeypatch.setenv("LBFGS_WORKER_PRODUCT", "1")
     monkeypatch.setenv("LBFGS_COMM_KIND", kind)
     outs = run_world(case, 2, tmp_path)
     ref_rows, ref_x = oracle_rows(case)
+    if kind != "callback":
+        assert [o["placement"] for o in outs] == ["host" if kind == "p2p-host" else "device"] * 2
     assert outs[0]["rows"] == outs[1]["rows"]
     assert len(outs[0]["rows"]) == len(ref_rows)
     for got, ref in zip(outs[0]["rows"], ref_rows):
@@ -40,6 +44,25 @@ def test_two_processes_one_gpu(case, kind, tmp_path, monkeypatch):
             assert abs(a - b) <= 1e-9 * max(abs(b), 1e-6), (got, ref)
     x = np.concatenate([np.array(o["x"]) for o in outs])
     assert np.max(np.abs(x - ref_x)) <= 1e-9 * max(np.max(np.abs(ref_x)), 1e-12)
+
+
+def test_p2p_falls_back_to_host_mailboxes_when_ipc_mapping_fails(tmp_path, monkeypatch):
+    """hipIpcOpenMemHandle of a peer's device memory refused (simulated: LBFGS_HIP_TEST_FAIL_IPC_OPEN) on every rank: the
+    ranks decide TOGETHER to drop the device-placed mailboxes and come up with host-placed ones -- same trajectory, same
+    bits as the device placement gives (the exchange adds the ranks' totals in rank order either way)."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs the GPU")
+    monkeypatch.setenv("LBFGS_WORKER_PRODUCT", "1")
+    monkeypatch.setenv("LBFGS_COMM_KIND", "p2p")
+    case = dict(name="quadratic", n=200_003, m=7, iters=25, objective="quadratic")
+    dev = run_world(case, 2, tmp_path)
+    assert [o["placement"] for o in dev] == ["device", "device"]
+    monkeypatch.setenv("LBFGS_HIP_TEST_FAIL_IPC_OPEN", "1")
+    host = run_world(case, 2, tmp_path)
+    assert [o["placement"] for o in host] == ["host", "host"]
+    assert host[0]["rows"] == host[1]["rows"] == dev[0]["rows"]          # bitwise
+    assert host[0]["x"] == dev[0]["x"] and host[1]["x"] == dev[1]["x"]
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("lbfgs_hip_mbox_")]   # the segments' names are gone
 
 
 def test_rccl_single_rank_communicator():
@@ -62,8 +85,9 @@ def test_rccl_single_rank_communicator():
         x.free(); y.free()
 
 
+@pytest.mark.parametrize("kind", ["p2p", "p2p-host"])
 @pytest.mark.parametrize("world,n,grid", [(2, 1_300_003, 80), (3, 1_500_001, 48), (2, 3_400_001, 32)])
-def test_resident_two_loop_with_the_p2p_exchange(world, n, grid, tmp_path, monkeypatch):
+def test_resident_two_loop_with_the_p2p_exchange(world, n, grid, kind, tmp_path, monkeypatch):
     """The on-chip-resident two-loop kernel (resident.h) under the P2P communicator: workgroup 0 of every rank closes
     each of the kernel's 2m hand-offs across the ranks through the mailboxes and broadcasts the global total to its
     other workgroups.  That path is meant for ranks that own their GPU (`exclusive_device`); here two / three ranks
@@ -74,13 +98,14 @@ def test_resident_two_loop_with_the_p2p_exchange(world, n, grid, tmp_path, monke
     if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
         pytest.skip("needs the GPU")
     monkeypatch.setenv("LBFGS_WORKER_PRODUCT", "1")
-    monkeypatch.setenv("LBFGS_COMM_KIND", "p2p")
+    monkeypatch.setenv("LBFGS_COMM_KIND", kind)
     monkeypatch.setenv("LBFGS_TEST_EXCLUSIVE_DEVICE", "1")
     monkeypatch.setenv("LBFGS_HIP_RESIDENT_GRID", str(grid))
     case = dict(name="quadratic_resident", n=n, m=6, iters=14, objective="quadratic")
     outs = run_world(case, world, tmp_path)
     ref_rows, ref_x = oracle_rows(case)
     for o in outs:
+        assert o["placement"] == ("host" if kind == "p2p-host" else "device")
         assert o["rows"] == outs[0]["rows"]
         assert o["resident"] >= 10, o["resident"]
         if n > 3_000_000:
@@ -96,11 +121,41 @@ def test_resident_two_loop_with_the_p2p_exchange(world, n, grid, tmp_path, monke
     assert np.max(np.abs(x - ref_x)) <= 1e-9 * max(np.max(np.abs(ref_x)), 1e-12)
 
 
+@pytest.mark.parametrize("kind", ["p2p", "p2p-host"])
+def test_resident_p2p_on_a_near_production_grid(kind, tmp_path, monkeypatch):
+    """The persistent kernel with the exchange inside its hand-offs on (almost) the grid of the 8-GPU run: rank 0 runs it
+    on 240 of this GPU's 256 CUs -- 240 workgroups polling one another, workgroup 0 exchanging with the peer -- over a
+    shard of 3e6 elements, while a second rank with a sliver of the vector takes 8 of the CUs next to it."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs the GPU")
+    monkeypatch.setenv("LBFGS_WORKER_PRODUCT", "1")
+    monkeypatch.setenv("LBFGS_COMM_KIND", kind)
+    monkeypatch.setenv("LBFGS_TEST_EXCLUSIVE_DEVICE", "1")
+    monkeypatch.setenv("LBFGS_TEST_RESIDENT_GRIDS", "240,8")
+    n, cut = 3_000_000 + 40_960 + 5, 3_000_000
+    monkeypatch.setenv("LBFGS_TEST_BOUNDS", json.dumps([0, cut, n]))
+    case = dict(name="quadratic_resident_240", n=n, m=6, iters=12, objective="quadratic")
+    outs = run_world(case, 2, tmp_path)
+    ref_rows, ref_x = oracle_rows(case)
+    assert [o["hi"] - o["lo"] for o in outs] == [cut, n - cut]
+    for o in outs:
+        assert o["err"] == 0 and o["rows"] == outs[0]["rows"]
+        assert o["resident"] >= 9 and o["resident_elements"] == o["hi"] - o["lo"], (o["resident"], o["resident_elements"])
+    assert len(outs[0]["rows"]) == len(ref_rows)
+    for got, ref in zip(outs[0]["rows"], ref_rows):
+        assert got[:3] == ref[:3]
+        for a, b in zip(got[3:], ref[3:]):
+            assert abs(a - b) <= 1e-9 * max(abs(b), 1e-6), (got, ref)
+    x = np.concatenate([np.array(o["x"]) for o in outs])
+    assert np.max(np.abs(x - ref_x)) <= 1e-9 * max(np.max(np.abs(ref_x)), 1e-12)
+
+
+@pytest.mark.parametrize("kind", ["p2p", "p2p-host"])
 @pytest.mark.parametrize("case", [
     dict(name="quadratic3_mixed", n=1000, m=4, iters=15, objective="quadratic"),
     dict(name="owlqn3_mixed", n=1000, m=5, iters=15, objective="logistic", owl=[0.5, 100, 900]),
 ], ids=lambda c: c["name"])
-def test_ranks_may_take_different_two_loop_paths(case, tmp_path, monkeypatch):
+def test_ranks_may_take_different_two_loop_paths(case, kind, tmp_path, monkeypatch):
     """Whether a rank runs the two-loop as the persistent resident kernel or as a kernel per step is decided per rank
     (an EMPTY shard, for one, has nothing to keep on the chip).  Both forms close the same sequence of reductions with
     the same number of values each -- under OWL-QN too, where the last four sums travel together in either form -- so
@@ -109,7 +164,7 @@ def test_ranks_may_take_different_two_loop_paths(case, tmp_path, monkeypatch):
     if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
         pytest.skip("needs the GPU")
     monkeypatch.setenv("LBFGS_WORKER_PRODUCT", "1")
-    monkeypatch.setenv("LBFGS_COMM_KIND", "p2p")
+    monkeypatch.setenv("LBFGS_COMM_KIND", kind)
     monkeypatch.setenv("LBFGS_TEST_EXCLUSIVE_DEVICE", "1")
     monkeypatch.setenv("LBFGS_HIP_RESIDENT_GRID", "48")
     outs = run_world(case, 3, tmp_path)
@@ -134,7 +189,7 @@ def test_random_configurations_two_processes_p2p(seed, vector_free, tmp_path, mo
     compare_sharded_fuzz(seed, tmp_path, vector_free)
 
 
-@pytest.mark.parametrize("kind", ["p2p", "callback"])
+@pytest.mark.parametrize("kind", ["p2p", "p2p-host", "callback"])
 def test_three_processes_one_gpu_with_an_empty_shard(kind, tmp_path, monkeypatch):
     """world = 3 on one GPU: shards of 512, 488 and 0 elements (an EMPTY shard still takes part in every
     reduction and in the P2P exchange)."""

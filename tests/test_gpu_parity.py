@@ -294,6 +294,76 @@ def _check_two_loop_vs_oracle(n, m, k, end, two_loop_path, expect_resident_eleme
         hist.free(); gv.free(); d.free()
 
 
+def _check_fused_owlqn_two_loop_vs_oracle(n, m, k, end, start, stop, expect_resident_elements=None):
+    """lbfgs_hip_two_loop_owlqn -- the recursion of lbfgs.rs:569-604 started from -pg with constrain_search_direction
+    (orthantwise.rs:140-161, after lbfgs.rs:543's ||d||) folded into its last step -- against the oracle's two-loop followed
+    by the oracle's `project` on [start, stop), on identical inputs.  pg carries +0.0, -0.0 and exact ties so that the
+    signum(+-0) = 0 rule (orthantwise.rs:174-180) decides some coordinates."""
+    S, Y, ys = _random_history(n, m, 300 + n + m)
+    pg = rnd(n, 27)
+    pg[::17] = 0.0
+    pg[5::29] = -0.0
+    gamma_num, gamma_den = ys[end], O.vecdot(Y[end], Y[end])
+    d_o = -pg
+    alpha_o = np.zeros(m)
+    end_o = O.two_loop(S, Y, ys, alpha_o, d_o, gamma_num / gamma_den, m, k, end)
+    dn2_pre = O.vecdot(d_o, d_o)
+    lo, hi = min(start, n), min(stop, n)
+    O.lib().oracle_project(O._dp(d_o), O._dp(pg), lo, hi, 1)
+    dn2_post, pgd = O.vecdot(d_o, d_o), O.vecdot(pg, d_o)
+    with R.Context(n) as ctx:
+        hist = H.History(ctx, m)
+        for j in range(m):
+            hist.s(j).upload(S[j]); hist.y(j).upload(Y[j])
+        hist.set_scalars(ys=ys, alpha=np.zeros(m))
+        ctx.set_scalars(7, [gamma_num, gamma_den])
+        pgv, d = DeviceVec(ctx, pg), DeviceVec(ctx)
+        assert hist.two_loop_owlqn(d, pgv, k, end, lo, hi, 7, 8, 40) == end_o
+        d_f = d.to_numpy()
+        assert rel(d_f, d_o) <= RTOL
+        assert np.array_equal(d_f == 0.0, d_o == 0.0)         # the same coordinates projected out
+        assert np.all(d_f[lo:hi][pg[lo:hi] == 0.0] == 0.0)    # signum(+-0) = 0: nothing survives there
+        four = ctx.scalars(40, 4)
+        assert abs(four[0] - dn2_pre) <= RTOL * dn2_pre       # ||d||^2 BEFORE the projection (the step clamp's, lbfgs.rs:543)
+        assert abs(four[2] - dn2_post) <= RTOL * dn2_post     # ... after it (orthantwise.rs:160 asserts it non-zero)
+        assert abs(four[3] - pgd) <= RTOL * abs(pgd)          # the next dginit (core.rs:90)
+        _, alpha_f = hist.scalars()
+        assert rel(alpha_f, alpha_o) <= RTOL
+        # the separate entry points give the same direction (their own reduction order for the sums)
+        hist.set_scalars(alpha=np.zeros(m))
+        hist.two_loop(d, pgv, k, end, 7, 8, 12)
+        H.constrain_direction(d, pgv, lo, hi, 14)
+        assert rel(d.to_numpy(), d_f) <= 1e-12
+        if expect_resident_elements is not None:
+            assert ctx.resident_two_loops() >= 2 and ctx.resident_elements() == expect_resident_elements
+        hist.free(); pgv.free(); d.free()
+
+
+@pytest.mark.parametrize("n,m,k,end,start,stop", [(100, 6, 3, 2, 0, 100), (100, 6, 40, 3, 10, 90), (4097, 7, 100, 2, 1, 4096),
+                                                  (70001, 10, 23, 4, 30_000, 10**9), (513, 1, 5, 0, 0, 513),
+                                                  (262145, 10, 11, 0, 1000, 262_000)])
+def test_fused_owlqn_two_loop_vs_oracle(n, m, k, end, start, stop, two_loop_path):
+    """Both launch forms of the fused OWL-QN entry against the oracle (sub-ranges, bound < m, bound = 1)."""
+    _check_fused_owlqn_two_loop_vs_oracle(n, m, k, end, start, stop)
+
+
+@pytest.mark.parametrize("n,m,k,end,grid,start,stop", [
+    (60_001, 5, 9, 2, 1, 1_000, 50_000),          # the range ends just past the on-chip part (49 152 elements per workgroup)
+    (250_000, 8, 8, 7, 2, 0, 250_000),            # everything
+    (300_007, 6, 30, 4, 3, 160_001, 299_999),     # the range lies entirely in the part of q that stays in HBM
+    (197_000, 10, 3, 2, 2, 50_001, 150_002),      # ... straddles the boundary between chip and HBM (98 304)
+    (98_306, 1, 4, 0, 1, 7, 98_300),              # bound = 1: the transition is the first step
+    (131_072, 3, 2, 1, 1, 0, 49_152)])            # ... the range is exactly the on-chip part
+def test_fused_owlqn_hybrid_two_loop_vs_oracle(n, m, k, end, grid, start, stop, monkeypatch):
+    """The same in the HYBRID form of the persistent kernel (small grids so that 1e5 elements exceed "the chip"): the on-chip
+    rounds project where d is written out, the HBM rounds in their last step (resident.h res_hbm_one MODE 3)."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("a form of the HIP kernels")
+    monkeypatch.setenv("LBFGS_HIP_RESIDENT", "1")
+    monkeypatch.setenv("LBFGS_HIP_RESIDENT_GRID", str(grid))
+    _check_fused_owlqn_two_loop_vs_oracle(n, m, k, end, start, stop, expect_resident_elements=2 * 96 * 256 * grid)
+
+
 def test_two_loop_linearity_and_determinism(two_loop_path):
     """H is linear: two_loop(4*g) == 4*two_loop(g) bit for bit (power-of-two scaling commutes with rounding)."""
     n, m = 300_001, 10

@@ -1,0 +1,94 @@
+"""The chip-wide resident two-loop kernel (rust-lbfgs_amd/csrc/resident.h) assumes that it gets every CU it asks for.
+When it does not -- another resident kernel on the GPU, a CU-masked queue -- its hand-offs time out.  That must cost a
+wait, never the run: `lbfgs_hip_scalars_read` re-runs that recursion with a kernel per step (its inputs are intact) and
+the context stays on that path.  Results are checked against the CPU oracle (lbfgs.rs:569-604 as restated there)."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import rust_lbfgs_amd as R
+from oracle import oracle as O
+from rust_lbfgs_amd import objectives
+from tests.test_gpu_parity import product_library  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def run_oracle(n, m, iters, owl=None):
+    rows, x = [], np.zeros(n)
+    b = O.lbfgs().with_m(m).with_epsilon(0.0).with_max_iterations(iters)
+    if owl:
+        b = b.with_orthantwise(*owl)
+    b.minimize(x, O.logistic() if owl else O.quadratic(), lambda p: rows.append((p["fx"], p["gnorm"], p["step"])) and False)
+    return rows, x
+
+
+def run_device(ctx, n, m, iters, owl=None):
+    rows, x = [], np.zeros(n)
+    b = R.lbfgs().with_m(m).with_epsilon(0.0).with_max_iterations(iters)
+    if owl:
+        b = b.with_orthantwise(*owl)
+    b.minimize(x, objectives.Logistic() if owl else objectives.Quadratic(), lambda p: rows.append((p.fx, p.gnorm, p.step)) and False,
+               ctx=ctx)
+    return rows, x
+
+
+def close(rows_o, rows_g, xo, xg, tol=1e-10):
+    assert len(rows_o) == len(rows_g)
+    for ro, rg in zip(rows_o, rows_g):
+        for a, b in zip(ro, rg):
+            assert abs(a - b) <= tol * max(abs(a), 1e-300), (ro, rg)
+    assert np.max(np.abs(xo - xg)) <= tol * max(np.max(np.abs(xo)), 1e-300)
+
+
+@pytest.mark.parametrize("owl", [None, (0.5, 1000, 250_000)], ids=["lbfgs", "owlqn"])
+def test_a_resident_launch_that_loses_a_workgroup_is_rerun_per_step(owl, monkeypatch, capfd):
+    """LBFGS_HIP_RESIDENT_FAULT=1: the first resident launch's last workgroup never takes part (as if it had never been
+    given a CU).  The others give up after the hand-off timeout, the error word reaches the host with the results, and
+    the read that finds it re-runs the recursion with a kernel per step: same trajectory as the oracle, one warning,
+    no resident launch afterwards."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs the GPU")
+    n, m, iters = 300_007, 5, 12
+    monkeypatch.setenv("LBFGS_HIP_RESIDENT_FAULT", "1")
+    monkeypatch.setenv("LBFGS_HIP_HANDOFF_TIMEOUT_MS", "100")
+    rows_o, xo = run_oracle(n, m, iters, owl)
+    with R.Context(n) as ctx:
+        rows_g, xg = run_device(ctx, n, m, iters, owl)
+        resident = ctx.resident_two_loops()
+    close(rows_o, rows_g, xo, xg)
+    assert resident == 1, resident          # the faulty one; every later two-loop took the kernel-per-step path
+    err = capfd.readouterr().err
+    assert err.count("timed out waiting for a workgroup") == 1, err
+
+
+def test_two_contexts_on_two_streams_of_one_gpu(monkeypatch):
+    """Two independent optimisations in ONE process, each with its own context and stream, both eligible for the
+    chip-wide kernel, driven from two threads at the same time.  Whatever the dispatcher does with two kernels that each
+    want every CU -- one after the other, or a share each (then both time out once and fall back) -- both runs must
+    finish with the oracle's trajectory."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs the GPU")
+    n, m, iters = 2_000_003, 6, 25
+    monkeypatch.setenv("LBFGS_HIP_HANDOFF_TIMEOUT_MS", "300")
+    rows_o, xo = run_oracle(n, m, iters)
+    out, errs = [None, None], []
+
+    def work(i, ctx):
+        try:
+            out[i] = run_device(ctx, n, m, iters)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    with R.Context(n) as c0, R.Context(n) as c1:
+        ts = [threading.Thread(target=work, args=(i, c)) for i, c in enumerate((c0, c1))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=300)
+        assert not any(t.is_alive() for t in ts)
+    assert not errs, errs
+    for rows_g, xg in out:
+        close(rows_o, rows_g, xo, xg)

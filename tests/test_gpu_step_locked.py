@@ -38,6 +38,12 @@ CASES = {
     "config2_quadratic_n1e7_m7": (10_000_000, 7, lambda b: b.with_epsilon(0.0), O.quadratic, objectives.Quadratic, "zeros", 10),
     "config3_owlqn_logistic_n1e7_m6": (10_000_000, 6, lambda b: b.with_orthantwise(0.5, 0, None).with_epsilon(0.0), O.logistic,
                                        objectives.Logistic, "zeros", 9),
+    # twice config 3's size: 160 MB shards exceed the chip, so the persistent two-loop kernel runs in its HYBRID form on the
+    # production grid -- and the FUSED OWL-QN entry (the projection inside its last step) is what is compared (see (3b))
+    "owlqn_logistic_n2e7_m6_hybrid": (20_000_003, 6, lambda b: b.with_orthantwise(0.5, 0, None).with_epsilon(0.0), O.logistic,
+                                      objectives.Logistic, "zeros", 8),
+    "owlqn_logistic_n2e7_range_hybrid": (20_000_003, 6, lambda b: b.with_orthantwise(0.5, 3_000_001, 17_000_000).with_epsilon(0.0),
+                                         O.logistic, objectives.Logistic, "zeros", 6),
     # Powell damping (lbfgs.rs:664-689); case 1 (y replaced) fires on these, which the test asserts
     "rosenbrock_damped_m10": (1000, 10, lambda b: b.with_damping(True), O.rosenbrock, objectives.Rosenbrock, "rosenbrock", 60),
     "rosenbrock_armijo_damped": (1000, 6, lambda b: b.with_damping(True).with_linesearch_algorithm("BacktrackingArmijo"),
@@ -76,7 +82,8 @@ def test_step_locked(case):
     with R.Context(n) as ctx:
         hist = H.History(ctx, m)
         xv, gv, pgv, dv, xpv, gpv = (DeviceVec(ctx) for _ in range(6))
-        worst = dict(f=0.0, g=0.0, d=0.0, s=0.0, y=0.0, ys=0.0, ls_step=0.0, ls_f=0.0, ls_x=0.0)
+        worst = dict(f=0.0, g=0.0, d=0.0, s=0.0, y=0.0, ys=0.0, ls_step=0.0, ls_f=0.0, ls_x=0.0, d_fused=0.0, fused_sums=0.0)
+        fused_paths = set()
         done = fired = 0
         damping = bool(b.param.damping)
         ls = LineSearch(algorithm=b.param.ls_algorithm, ftol=b.param.ftol, gtol=b.param.gtol, xtol=b.param.xtol,
@@ -161,13 +168,40 @@ def test_step_locked(case):
             new_end = hist.two_loop(dv, src, st.k - 1, end_before, 7, 8, 12)
             assert new_end == st.end
             if owl:
+                dn2_unfused = ctx.scalars(12)[0]  # ||d||^2 before the projection (lbfgs.rs:543 precedes :554)
                 H.constrain_direction(dv, pgv, s0, e0, 13)
             worst["d"] = max(worst["d"], rel(dv.to_numpy(), st.vec("d")))
+            # (3b) OWL-QN: the FUSED entry the solver uses in production -- lbfgs_hip_two_loop_owlqn: the recursion with
+            #      constrain_search_direction (orthantwise.rs:140-161) folded into its last step; in the resident kernel's
+            #      write-out / its hybrid rounds' last step -- against the oracle's projected direction and its sums
+            if owl:
+                d_ref = st.vec("d")
+                pg_ref = st.vec("pg")
+                hist.set_scalars(alpha=np.zeros(m))
+                before = ctx.resident_two_loops()
+                assert hist.two_loop_owlqn(dv, pgv, st.k - 1, end_before, s0, e0, 7, 8, 16) == st.end
+                fused_paths.add("resident" if ctx.resident_two_loops() > before else "per_step")
+                d_fused = dv.to_numpy()
+                worst["d_fused"] = max(worst["d_fused"], rel(d_fused, d_ref))
+                assert np.array_equal(d_fused == 0.0, d_ref == 0.0)  # the same coordinates were projected out
+                dn2_pre, _, dn2_post, pgd = ctx.scalars(16, 4)
+                want_post, want_pgd = O.vecdot(d_ref, d_ref), O.vecdot(pg_ref, d_ref)
+                worst["fused_sums"] = max(worst["fused_sums"], abs(dn2_post - want_post) / want_post,
+                                          abs(pgd - want_pgd) / abs(want_pgd), abs(dn2_pre - dn2_unfused) / dn2_unfused)
+                if n <= 10_000_000:  # ... and ||d||^2 before the projection against the oracle's own recursion on the host
+                    d_pre = -pg_ref
+                    O.two_loop([st.hist(j, "s") for j in range(m)], [st.hist(j, "y") for j in range(m)],
+                               np.array([st.ys(j) for j in range(m)]), np.zeros(m), d_pre, st.gamma, m, st.k - 1, end_before)
+                    want_pre = O.vecdot(d_pre, d_pre)
+                    worst["fused_sums"] = max(worst["fused_sums"], abs(dn2_pre - want_pre) / want_pre)
+                del d_fused
         st.close()
         hist.free()
         for v in (xv, gv, pgv, dv, xpv, gpv):
             v.free()
     assert done >= min(8, iters - 1), done
+    if owl and os.environ.get("LBFGS_TEST_BACKEND") != "mock" and os.environ.get("LBFGS_HIP_RESIDENT", "1") != "0":
+        assert fused_paths == {"resident"}, fused_paths   # (hybrid for the 2e7 cases: the shard exceeds the chip)
     if case in DAMPED_CASES:
         assert fired >= 1, "damping case 1 (lbfgs.rs:675-680) never fired: the case does not test it"
     print(case, {k: f"{v:.2e}" for k, v in worst.items()}, "damping case 1 fired:", fired)

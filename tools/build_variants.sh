@@ -14,10 +14,6 @@ for v in $1; do
     d=$root/tools/bin/variants/m${m}u${u}
     flags="-DLH_STEP_MAP=$m -DLH_STEP_UNROLL=$u"
   fi
-  mkdir -p "$d"
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -mllvm -amdgpu-spill-vgpr-to-agpr=0 $flags \
-      -I"$root/include" "$root/rust-lbfgs_amd/csrc/lbfgs_hip.hip" -o "$d/liblbfgs_hip.so" -ldl 2>/dev/null
-  g++ -O2 -ffp-contract=off -fPIC -shared -std=c++17 -I"$root/include" "$root/rust-lbfgs_amd/csrc/host/solver.cpp" -o "$d/liblbfgs_solver.so" \
-      -L"$d" -llbfgs_hip -Wl,-rpath,'$ORIGIN'
-  echo "built $d"
+  # (same resource report + AGPR audit as the in-tree build; fails if the variant touches scratch memory)
+  python "$root/rust-lbfgs_amd/_build.py" --variant "$(basename "$d")" $flags || exit 1
 done
