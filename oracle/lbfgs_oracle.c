@@ -47,6 +47,11 @@ static double sum_pairwise(const double* t, size_t n) {
 int oracle_dot_mode(void) { return g_dot_mode; }
 double oracle_sum_terms(const double* t, size_t n) {
     if (g_dot_mode == 1) return sum_pairwise(t, n);
+    if (g_dot_mode == 2) { /* diagnostic: the reference's running sum, from the last term down */
+        double acc = 0.0;
+        for (size_t i = n; i-- > 0;) acc += t[i];
+        return acc;
+    }
     double acc = 0.0;
     for (size_t i = 0; i < n; ++i) acc += t[i];
     return acc;
@@ -60,6 +65,11 @@ void oracle_vecadd(double* y, const double* x, double c, size_t n) {
 /* math.rs:40-42  s = sum_i x_i*y_i, sequential */
 double oracle_vecdot(const double* x, const double* y, size_t n) {
     if (g_dot_mode == 1) return dot_pairwise(x, y, n);
+    if (g_dot_mode == 2) { /* diagnostic: the same terms, summed from the last one down */
+        double acc = 0.0;
+        for (size_t i = n; i-- > 0;) acc += x[i] * y[i];
+        return acc;
+    }
     double acc = 0.0;
     for (size_t i = 0; i < n; ++i) acc += x[i] * y[i];
     return acc;
@@ -113,11 +123,11 @@ int oracle_owl_range(const oracle_param* p, size_t n, size_t* start, size_t* end
 
 /* orthantwise.rs:70-79: the multiply by c is inside the sum */
 double oracle_x1norm(double c, size_t start, size_t end, const double* x) {
-    if (g_dot_mode == 1 && end > start) {  /* diagnostic: the same terms, pairwise */
+    if (g_dot_mode != 0 && end > start) {  /* diagnostic: the same terms, pairwise / in reverse */
         double* t = (double*)malloc((end - start) * sizeof(double));
         if (t) {
             for (size_t i = start; i < end; ++i) t[i - start] = c * fabs(x[i]);
-            double r = sum_pairwise(t, end - start);
+            double r = oracle_sum_terms(t, end - start);
             free(t);
             return r;
         }

@@ -107,9 +107,9 @@ typedef struct oracle_report {
 
 /* ---- math.rs:31-82 -------------------------------------------------------- */
 /* dot mode: 0 = sequential left-to-right (the reference, math.rs:41);
- * 1 = pairwise tree (diagnostic only: attributes GPU-vs-oracle differences to
- * summation order).  Mode 1 reorders EVERY sum of the restatement: vecdot, x1norm and the f of the built-in
- * objectives.  Process-global, default 0. */
+ * 1 = pairwise tree, 2 = sequential from the LAST term down (diagnostic only: two independent perturbations of the
+ * summation order, from which the tests estimate how strongly a run amplifies last-bit differences).  Modes 1 and 2
+ * reorder EVERY sum of the restatement: vecdot, x1norm and the f of the built-in objectives.  Process-global, default 0. */
 void oracle_set_dot_mode(int mode);
 int oracle_dot_mode(void);
 /* sum of a term array in the current mode (sequential = the reference; pairwise = diagnostic) */

@@ -20,7 +20,7 @@
 #include <stdlib.h>
 
 /* f = sum of per-element (per-pair) terms.  Mode 0 (the reference): running sum in index order, exactly as the cited
- * loops.  Diagnostic mode 1: the same terms summed pairwise (oracle_sum_terms), so that the summation-order
+ * loops.  Diagnostic modes 1 / 2: the same terms summed pairwise / from the last one down (oracle_sum_terms), so that the summation-order
  * sensitivity estimate of the tests also perturbs f, not only the dot products. */
 typedef struct fsum {
     double acc;
@@ -30,7 +30,7 @@ typedef struct fsum {
 static void fsum_begin(fsum* s, size_t nterms) {
     s->acc = 0.0;
     s->k = 0;
-    s->terms = (oracle_dot_mode() == 1 && nterms) ? (double*)malloc(nterms * sizeof(double)) : NULL;
+    s->terms = (oracle_dot_mode() != 0 && nterms) ? (double*)malloc(nterms * sizeof(double)) : NULL;
 }
 static inline void fsum_add(fsum* s, double t) {
     if (s->terms) s->terms[s->k++] = t;

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <cmath>
@@ -106,6 +107,15 @@ struct HostMbox {
 };
 std::map<void*, HostMbox> g_host_mbox;  // device address -> mapping
 std::mutex g_host_mbox_mu;
+
+// uncached blocks that no context is using, per device: granule buffers (lbfgs_hip_ctx_create) and device-placed P2P
+// mailboxes.  Uncached memory is never handed back to the allocator (see lbfgs_hip_ctx_create).
+std::map<int, std::vector<void*>> g_uc_pool, g_uc_mbox_pool;
+std::mutex g_uc_pool_mu;
+void uc_mbox_retire(int device, void* p) {
+    std::lock_guard<std::mutex> lk(g_uc_pool_mu);
+    g_uc_mbox_pool[device].push_back(p);
+}
 
 void host_mbox_unlink_all() {  // atexit: names of segments this process still owns
     std::lock_guard<std::mutex> lk(g_host_mbox_mu);
@@ -266,6 +276,7 @@ struct lbfgs_hip_ctx {
     size_t lj_scratch_bytes = 0;
     struct LjCells* lj_cells = nullptr;   // LJ_CELLS: the rebuildable neighbour structure (allocated on demand)
     unsigned long long* gran = nullptr;   // tagged partial granules [MAX_RED][MAX_GRID][2] (stream.h)
+    bool gran_pooled = false;             // ... in an uncached block of the process-wide pool (returned there, never freed)
     bool p2p_exclusive = false;           // lbfgs_hip_comm.exclusive_device: no other rank shares this GPU
     unsigned long long resident_attr_mask = 0;  // which resident kernels have had their dynamic-LDS limit raised on this device
     int gram_combine_resident = 1;        // LBFGS_HIP_GRAM_COMBINE_RESIDENT=0: the vector-free combine as one streaming pass over all columns
@@ -1194,13 +1205,21 @@ int lbfgs_hip_p2p_mailbox_create2(int device, int placement, void** mailbox_out,
         return LBFGS_HIP_OK;
     }
     void* p = nullptr;
-    if (e == hipSuccess) e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    if (e == hipSuccess) {  // (a retired mailbox of this process first: uncached blocks are pooled, never freed)
+        std::lock_guard<std::mutex> lk(g_uc_pool_mu);
+        auto& pool = g_uc_mbox_pool[device];
+        if (!pool.empty()) {
+            p = pool.back();
+            pool.pop_back();
+        }
+    }
+    if (e == hipSuccess && !p) e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
     if (e == hipSuccess) e = hipMemset(p, 0, bytes);  // tag 0 is never a valid epoch
     if (e == hipSuccess) e = hipDeviceSynchronize();
     hipIpcMemHandle_t hdl;
     if (e == hipSuccess) e = hipIpcGetMemHandle(&hdl, p);
     if (e != hipSuccess) {
-        if (p) (void)hipFree(p);
+        if (p) uc_mbox_retire(device, p);
         return fail(nullptr, LBFGS_HIP_ERR_COMM, "P2P mailbox: %s", hipGetErrorString(e));
     }
     memcpy(ipc_handle64_out, &hdl, HIP_IPC_HANDLE_SIZE);
@@ -1212,7 +1231,8 @@ void lbfgs_hip_p2p_mailbox_destroy(int device, void* mailbox) {
     if (!mailbox) return;
     (void)hipSetDevice(device);
     if (host_mbox_release(mailbox)) return;
-    (void)hipFree(mailbox);
+    (void)hipDeviceSynchronize();
+    uc_mbox_retire(device, mailbox);
 }
 
 int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfgs_hip_shard* shard,
@@ -1316,10 +1336,45 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     CTX_TRY(hipMalloc(&ctx->partials, (size_t)MAX_RED * MAX_GRID * sizeof(double)));
     CTX_TRY(hipMalloc(&ctx->ticket, 64));
     CTX_TRY(hipMemsetAsync(ctx->ticket, 0, 64, ctx->stream));
-    CTX_TRY(hipMalloc(&ctx->gran, (size_t)MAX_RED * MAX_GRID * 2 * sizeof(unsigned long long)));
+    {
+        // The tagged granules live in UNCACHED device memory: every access to them is an agent-scope atomic that must be
+        // coherent across the eight XCDs' private L2s anyway, and on memory the L2s never hold, such an access takes a shorter
+        // path -- a chip-wide hand-off of one sum among 256 workgroups: 2.0 us instead of 3.0 (tools/handoff_bench.hip,
+        // profiles/r03_handoff_bench.log).  LBFGS_HIP_GRAN_CACHED=1: plain hipMalloc, for A/B.
+        const size_t gbytes = (size_t)MAX_RED * MAX_GRID * 2 * sizeof(unsigned long long);
+        void* gp = nullptr;
+        // Uncached blocks are POOLED per process and device and never handed back to the allocator: memory that changes
+        // between cached and uncached use as contexts come and go was seen to go wrong (a context created right after
+        // another one had been destroyed occasionally read stale data in its first reductions -- always with vectors of
+        // 2-5 MB, the size of this block -- as long as this block was allocated and freed per context; never once it
+        // stopped being recycled: profiles/r03_uncached_granules_recycling.md).
+        const char* gc = getenv("LBFGS_HIP_GRAN_CACHED");
+        if (!(gc && *gc && atoi(gc) != 0)) {
+            std::lock_guard<std::mutex> lk(g_uc_pool_mu);
+            auto& pool = g_uc_pool[device];
+            if (!pool.empty()) {
+                gp = pool.back();
+                pool.pop_back();
+            } else if (hipExtMallocWithFlags(&gp, gbytes, hipDeviceMallocUncached) != hipSuccess) {
+                (void)hipGetLastError();
+                gp = nullptr;
+            }
+            ctx->gran_pooled = gp != nullptr;
+        }
+        if (!gp) CTX_TRY(hipMalloc(&gp, gbytes));
+        ctx->gran = (unsigned long long*)gp;
+    }
     CTX_TRY(hipMemsetAsync(ctx->gran, 0, (size_t)MAX_RED * MAX_GRID * 2 * sizeof(unsigned long long), ctx->stream));
     {
-        const DevCounters init{1u, 1u, 0ull};
+        // The first tag of a context is not 1 but a value no other context of this process starts near: a granule buffer is
+        // recycled memory, and although it is zeroed above, a poller that found a stale granule of an EARLIER context with
+        // the tag it is waiting for would take it for a partial sum (seen once the buffer moved to uncached memory: the same
+        // case failed in every full run of the GPU suite and never alone).  Tags are unique per launch within a context
+        // (stream.h DevCounters); this makes them unique across the contexts that may have owned the memory before.
+        static std::atomic<unsigned int> serial{0};
+        const unsigned int epoch0 = 1u + (unsigned int)(((unsigned long long)(serial.fetch_add(1) + 1u) * 0x9E3779B1ull) % 0xFFFFFFFEull);
+        ctx->red_count = (unsigned long long)epoch0 - 1ull;  // (the next tagged launch uses tag red_count % (2^32-1) + 1 = epoch0)
+        const DevCounters init{epoch0, 1u, 0ull};
         CTX_TRY(hipMalloc(&ctx->dev_ctr, 4096));  // (a page of its own: nothing else shares its cache lines)
         CTX_TRY(hipMemcpy(ctx->dev_ctr, &init, sizeof(init), hipMemcpyHostToDevice));
     }
@@ -1430,7 +1485,7 @@ void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* ctx) {
     for (int r = 0; r < P2P_MAX_WORLD; ++r) {
         if (!ctx->p2p_mbox[r]) continue;
         if (ctx->p2p_opened[r]) (void)hipIpcCloseMemHandle(ctx->p2p_mbox[r]);
-        else if (!host_mbox_release(ctx->p2p_mbox[r])) (void)hipFree(ctx->p2p_mbox[r]);
+        else if (!host_mbox_release(ctx->p2p_mbox[r])) uc_mbox_retire(ctx->device, ctx->p2p_mbox[r]);
     }
     if (ctx->p2p_err) (void)hipFree(ctx->p2p_err);
     for (auto& pc : ctx->prof)
@@ -1439,7 +1494,14 @@ void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* ctx) {
     if (ctx->board) (void)hipFree(ctx->board);
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
-    if (ctx->gran) (void)hipFree(ctx->gran);
+    if (ctx->gran) {
+        if (ctx->gran_pooled) {  // (uncached: back to the process-wide pool, see lbfgs_hip_ctx_create)
+            std::lock_guard<std::mutex> lk(g_uc_pool_mu);
+            g_uc_pool[ctx->device].push_back(ctx->gran);
+        } else {
+            (void)hipFree(ctx->gran);
+        }
+    }
     if (ctx->dev_ctr) (void)hipFree(ctx->dev_ctr);
     if (ctx->dot_parts) (void)hipFree(ctx->dot_parts);
     if (ctx->lj_scratch) (void)hipFree(ctx->lj_scratch);
@@ -1636,6 +1698,10 @@ int lbfgs_hip_scalars_read(lbfgs_hip_ctx* ctx, int first, int count, double* hos
                         "step and staying on that path (LBFGS_HIP_RESIDENT=0 avoids the wait)\n");
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->p2p_err, 0, sizeof(unsigned int), ctx->stream));
+        // Workgroups of that launch which only STARTED after workgroup 0 had finished (they were never resident together:
+        // that is what went wrong) read the counters workgroup 0 had already advanced, and published their partial sums
+        // under the tags of launches that are yet to come.  No granule of the aborted launch may survive it.
+        HIP_TRY(ctx, hipMemsetAsync(ctx->gran, 0, (size_t)MAX_RED * MAX_GRID * 2 * sizeof(unsigned long long), ctx->stream));
         if (ctx->mirror) *reinterpret_cast<volatile unsigned long long*>(ctx->mirror + LBFGS_HIP_BOARD_SLOTS + 3) = 0ull;
         int ne = 0;
         rc = two_loop_eager(lr.h, lr.d, lr.g, lr.k, lr.end, lr.gnum, lr.gden, lr.dn, lr.first, &ne, lr.owl, lr.owl_start, lr.owl_end);
@@ -1923,43 +1989,54 @@ int lbfgs_hip_two_loop_owlqn(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs
 // ---- the two-loop as ONE kernel with the running vector resident in registers + LDS (resident.h) ----------------
 namespace {
 #if LH_RES_TRACE
-// A/B builds only (tools/handoff_trace.sh): workgroups 0 and G/2 leave wall-clock stamps (100 MHz) of every hand-off in
-// the ticket form's partials buffer -- entry, partial published, first poll back, totals known -- which are averaged here
-// over all launches of the process and printed when the context goes.
+// A/B builds only (tools/handoff_trace.sh): every workgroup leaves wall-clock stamps (100 MHz, one clock for the whole chip)
+// of every hand-off in the ticket form's partials buffer -- arrival, partial published, totals known.  From those: how far
+// apart the workgroups ARRIVE (skew: load imbalance of the step, not a property of the hand-off), how long the hand-off
+// takes once the LAST workgroup has arrived (its true latency), and what a workgroup sees on average.
 struct ResTraceAcc {
-    double pre = 0, first_poll = 0, rest = 0, whole = 0, step = 0, polls = 0;
+    double skew = 0, after_last = 0, whole_mean = 0, sums = 0, step = 0, polls = 0, spread_out = 0;
     unsigned long long handoffs = 0, steps = 0;
-} g_res_trace[2];
-void res_trace_collect(lbfgs_hip_ctx* ctx, unsigned int first_tag, int handoffs) {
-    static unsigned long long host[2 * 64 * 8];
-    if (handoffs > 60 || hipStreamSynchronize(ctx->stream) != hipSuccess ||
-        hipMemcpy(host, ctx->partials, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess)
+} g_res_trace;
+void res_trace_collect(lbfgs_hip_ctx* ctx, unsigned int first_tag, int handoffs, int grid) {
+    static std::vector<unsigned long long> host(64 * 256 * 4);
+    if (handoffs > 60 || grid > 256 || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(host.data(), ctx->partials, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
         return;
-    for (int w = 0; w < 2; ++w) {
-        long long prev_end = 0;
-        for (int h = 0; h < handoffs; ++h) {
-            const unsigned long long* tr = host + ((size_t)w * 64 + ((first_tag + (unsigned int)h) & 63u)) * 8;
-            ResTraceAcc& a = g_res_trace[w];
-            a.pre += (double)(long long)(tr[1] - tr[0]);
-            a.first_poll += (double)(long long)(tr[2] - tr[1]);
-            a.rest += (double)(long long)(tr[3] - tr[2]);
-            a.whole += (double)(long long)(tr[3] - tr[0]);
-            a.polls += (double)tr[4];
-            a.handoffs += 1;
-            if (h > 0) { a.step += (double)((long long)tr[0] - prev_end); a.steps += 1; }
-            prev_end = (long long)tr[3];
+    long long prev_out = 0;
+    ResTraceAcc& a = g_res_trace;
+    for (int h = 0; h < handoffs; ++h) {
+        const unsigned long long* tr = host.data() + (size_t)((first_tag + (unsigned int)h) & 63u) * 256 * 4;
+        long long in_min = 0, in_max = 0, out_min = 0, out_max = 0;
+        double whole = 0, sums = 0, polls = 0;
+        for (int w = 0; w < grid; ++w) {
+            const long long t0 = (long long)tr[w * 4], t1 = (long long)tr[w * 4 + 1], t2 = (long long)tr[w * 4 + 2];
+            if (w == 0 || t0 < in_min) in_min = t0;
+            if (w == 0 || t0 > in_max) in_max = t0;
+            if (w == 0 || t2 < out_min) out_min = t2;
+            if (w == 0 || t2 > out_max) out_max = t2;
+            whole += (double)(t2 - t0);
+            sums += (double)(t1 - t0);
+            polls += (double)tr[w * 4 + 3];
         }
+        a.skew += (double)(in_max - in_min);
+        a.after_last += (double)(out_min - in_max);
+        a.spread_out += (double)(out_max - out_min);
+        a.whole_mean += whole / grid;
+        a.sums += sums / grid;
+        a.polls += polls / grid;
+        a.handoffs += 1;
+        if (h > 0) { a.step += (double)(in_min - prev_out); a.steps += 1; }
+        prev_out = out_max;
     }
 }
 void res_trace_print() {
-    for (int w = 0; w < 2; ++w) {
-        const ResTraceAcc& a = g_res_trace[w];
-        if (!a.handoffs) continue;
-        const double k = 10.0 / (double)a.handoffs;  // ticks of 10 ns -> ns per hand-off
-        fprintf(stderr, "[res-trace] workgroup %s: %llu hand-offs: whole %.0f ns = sums+publish %.0f + first poll back %.0f + until totals %.0f ; "
-                        "%.2f polls ; step between hand-offs %.0f ns\n", w ? "G/2" : "0", a.handoffs, a.whole * k, a.pre * k, a.first_poll * k,
-                a.rest * k, a.polls / (double)a.handoffs, a.steps ? a.step * 10.0 / (double)a.steps : 0.0);
-    }
+    const ResTraceAcc& a = g_res_trace;
+    if (!a.handoffs) return;
+    const double k = 10.0 / (double)a.handoffs;  // ticks of 10 ns -> ns per hand-off
+    fprintf(stderr, "[res-trace] %llu hand-offs: a workgroup spends %.0f ns in one (sums+publish %.0f, %.2f polls); workgroups ARRIVE "
+                    "%.0f ns apart; first one out %.0f ns after the LAST arrival, last one out %.0f ns later; "
+                    "streaming between hand-offs (last out -> first in) %.0f ns\n", a.handoffs, a.whole_mean * k, a.sums * k,
+            a.polls / (double)a.handoffs, a.skew * k, a.after_last * k, a.spread_out * k, a.steps ? a.step * 10.0 / (double)a.steps : 0.0);
 }
 #endif
 template <int ER, bool HYB = false>
@@ -2125,7 +2202,7 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     }
     if (rc != LBFGS_HIP_OK) return rc;
 #if LH_RES_TRACE
-    res_trace_collect(ctx, trace_first_tag, (int)handoffs);
+    res_trace_collect(ctx, trace_first_tag, (int)handoffs, grid);
 #endif
     ctx->resident_launches += 1;
     ctx->resident_elements = hybrid ? 2ull * per_round * (uint64_t)(er + el) : n;

@@ -63,6 +63,9 @@ constexpr int RES_UNROLL = 4;          // pairs whose loads are issued together 
 //      find an empty queue, and the window is ready when the coefficient is)
 #define LH_RES_PREFETCH 0
 #endif
+#ifndef LH_RES_DPP
+#define LH_RES_DPP 1  // 1: the hand-off's wave sums with DPP moves + readlane (stream.h wave_sum_dpp) instead of ds_bpermute trees
+#endif
 #ifndef LH_RES_TRACE
 #define LH_RES_TRACE 0  // 1: workgroups 0 and G/2 log wall-clock stamps of every hand-off into RedCtl::partials (tools/handoff_trace.py)
 #endif
@@ -111,8 +114,9 @@ struct ResArgs {
 //                 poll.  The mailbox is uncached and system-scope: one poller per GPU, not 256.
 // The hand-off is pure latency (nothing streams while a workgroup waits), so it is built from as few serial pieces as
 // possible: the workgroup's sums are formed with ONE barrier each (every thread adds the four wave sums itself, in
-// block_sum's order -- no second trip through LDS to broadcast), and the two sums use different LDS rows, so no barrier
-// separates the publish from the polls or one hand-off from the next: two barriers per hand-off (round 2: five).
+// block_sum's order -- no second trip through LDS to broadcast), the wave sums use DPP moves instead of ds_bpermute trees
+// (stream.h wave_sum_dpp), and the two sums use different LDS rows, so no barrier separates one hand-off from the next:
+// three barriers per hand-off (round 2: five).  The granules live in uncached memory (lbfgs_hip_ctx_create).
 // `lds`: [8][WAVES], rows 0-3 for the sums a workgroup publishes, rows 4-7 for the totals it collects.  A row is written
 // before one of the two barriers and read right after it; its next write lies behind the OTHER barrier of the same or the
 // next hand-off, which no thread passes before every thread has finished that read.
@@ -121,7 +125,11 @@ __device__ __forceinline__ void res_block_total(double (&acc)[NS], double (*rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
+#if LH_RES_DPP
+        const double w = wave_sum_dpp(acc[k]);
+#else
         const double w = wave_sum(acc[k]);
+#endif
         if (lane == 0) rows[k][wave] = w;
     }
     __syncthreads();
@@ -142,7 +150,7 @@ template <int NS>
 __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& red, const unsigned int tag, const unsigned int p2p_tag,
                                              const int parity, double (*lds)[WAVES], double* s_tot,
                                              unsigned int (*s_bits)[MAX_RED][2]) {
-    LH_TR(const long long tr0 = wall_clock64(); long long tr1 = 0, tr2 = 0; unsigned int tr_polls = 0;)
+    LH_TR(const long long tr0 = wall_clock64(); long long tr1 = 0; unsigned int tr_polls = 0;)
 #if LH_RES_SLIM
     res_block_total<NS>(acc, lds);  // (every thread holds the workgroup's sums)
 #else
@@ -160,10 +168,12 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
             __hip_atomic_store(g + 1, t | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    LH_TR(tr1 = wall_clock64();)
-#if !LH_RES_SLIM
-    __syncthreads();  // lds is reused below
-#endif
+    LH_TR(asm volatile("" ::: "memory"); tr1 = wall_clock64();)
+    // Nobody polls before its own workgroup's partial is on its way.  (Without this barrier 255 threads of every workgroup
+    // start polling while thread 0 is still publishing, and 65 000 early pollers on the 32 cache lines that hold the
+    // granules slow every store to them down: 2.5 us per hand-off against 1.7, tools/handoff_bench.hip.  In the round-2
+    // form the same barrier also keeps the two uses of `lds` apart.)
+    __syncthreads();
     double (*rows2)[WAVES] = LH_RES_SLIM ? lds + 4 : lds;
     double tot[NS];
 #pragma unroll
@@ -182,7 +192,7 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
                 }
 #pragma unroll
                 for (int k = 0; k < NS; ++k) ok = ok && (unsigned int)(lo[k] >> 32) == tag && (unsigned int)(hi[k] >> 32) == tag;
-                LH_TR(if (tr_polls++ == 0) tr2 = wall_clock64();)
+                LH_TR(tr_polls++;)
                 if (ok) break;
                 // (slow path only) give up after the timeout -- or at once if somebody already has: one missing workgroup must
                 // cost ONE timeout, not one per hand-off and workgroup
@@ -267,13 +277,12 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
     __syncthreads();  // s_tot and lds are free again
 #endif
 #if LH_RES_TRACE
-    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == (G >> 1))) {
-        unsigned long long* tr = reinterpret_cast<unsigned long long*>(red.partials) + ((size_t)(blockIdx.x ? 1 : 0) * 64 + (tag & 63u)) * 8;
+    if (threadIdx.x == 0) {  // every workgroup: [slot = tag & 63][workgroup][4] = arrival, partial published, totals known, polls
+        unsigned long long* tr = reinterpret_cast<unsigned long long*>(red.partials) + ((size_t)(tag & 63u) * 256u + blockIdx.x) * 4;
         tr[0] = (unsigned long long)tr0;
         tr[1] = (unsigned long long)tr1;
-        tr[2] = (unsigned long long)tr2;
-        tr[3] = (unsigned long long)wall_clock64();
-        tr[4] = tr_polls;
+        tr[2] = (unsigned long long)wall_clock64();
+        tr[3] = tr_polls;
     }
 #endif
 }

@@ -68,6 +68,60 @@ def run_oracle(c, mode=0):
         O.lib().oracle_set_dot_mode(0)
 
 
+PERTURBED_MODES = (1, 2)  # oracle_set_dot_mode: every sum pairwise / from the last term down
+
+
+def order_sensitivity(c, ro, eo):
+    """How strongly does THIS run amplify a mere change of summation order?  The oracle is re-run with every sum formed in
+    two other orders (pairwise; sequential from the last term down) and, iteration by iteration, the largest scaled
+    deviation of either from the reference run is the `floor` the comparison with the GPU is calibrated on (one perturbed
+    run underestimates it now and then: a sample of size one).  -> (floors, stable_prefix, all_stable):
+    floors[i] = running maximum up to iteration i; stable_prefix = iterations over which both perturbed runs take the
+    reference run's discrete decisions and stay below 1e-8; all_stable = they also end the same way."""
+    runs = [run_oracle(c, mode) for mode in PERTURBED_MODES]
+    f0 = max(abs(ro[0][3]), 1e-3) if ro else 1.0
+    g0 = max(ro[0][5], 1e-6) if ro else 1.0
+    floors, floor = [], 0.0
+    all_stable = all(e == eo and len(r) == len(ro) for r, _, e in runs)
+    for i, a in enumerate(ro):
+        scale = scales(a, f0, g0)
+        ok = True
+        for r, _, _ in runs:
+            if i >= len(r) or tuple(a[:3]) != tuple(r[i][:3]):
+                ok = False
+                break
+            floor = max(floor, max((0.0 if (u != u and v != v) else abs(u - v) / s) for u, v, s in zip(a[3:], r[i][3:], scale)))
+        if not ok or floor > 1e-8:  # chaotic for ANY summation order from here on: stop comparing
+            all_stable = False
+            break
+        floors.append(floor)
+    return floors, len(floors), all_stable
+
+
+def scales(row, f0, g0):
+    return (max(abs(row[3]), 1e-6 * f0), max(row[4], 1e-300), max(row[5], 1e-6 * g0), max(abs(row[6]), 1e-300))
+
+
+def compare_with_oracle(c, ro, eo, rp, ep, floors, all_stable, slack=1.0):
+    """The product's rows `rp` against the oracle's `ro` over the stable prefix: same discrete decisions, values within
+    max(1e-10, 20 x floor) x slack."""
+    f0 = max(abs(ro[0][3]), 1e-3) if ro else 1.0
+    g0 = max(ro[0][5], 1e-6) if ro else 1.0
+    for i, floor in enumerate(floors):
+        a = ro[i]
+        assert i < len(rp), (c, "the product stopped early", ep)
+        b = rp[i]
+        assert tuple(a[:3]) == tuple(b[:3]), (c, a, b)
+        tol = max(1e-10, 20.0 * floor) * slack
+        for u, v, s in zip(a[3:], b[3:], scales(a, f0, g0)):
+            # NaN is a legitimate value here: More-Thuente's cubic step has no guard under its sqrt (line.rs:629) and
+            # an exhausted search returns that step (SURVEY 9.4) -- the product must produce the NaN too
+            assert (u != u and v != v) or abs(u - v) <= tol * s, (c, i, a, b, floor)
+    if all_stable:
+        assert ep == eo, (c, eo, ep)
+        assert len(rp) == len(ro)
+
+
 def run_product(R, objectives, c):
     dev = {"quadratic": objectives.Quadratic, "logistic": objectives.Logistic, "rosenbrock": objectives.Rosenbrock}[c["kind"]](
         fuse_line_eval=c.get("fuse", 2))

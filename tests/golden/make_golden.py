@@ -6,8 +6,9 @@ The traces are the committed expected values for the GPU trajectory tests: per i
 Tolerance of a FREE-RUNNING trajectory: the GPU sums in a fixed tree, the reference sequentially
 (src/math.rs:41).  Both are valid f64 evaluations of the same dot products, but an L-BFGS run
 amplifies a 1e-16 perturbation as it goes.  Each case therefore carries `rtol`: 1e-10, or -- when
-the oracle itself moves by more than that under a mere change of summation order (sequential vs
-pairwise, `oracle_set_dot_mode`) -- 20x that measured sensitivity.  The strict 1e-10 bar on
+the oracle itself moves by more than that under a mere change of summation order (`oracle_set_dot_mode`:
+every sum pairwise, and every sum from its last term down; the LARGER of the two deviations counts -- one
+perturbed run is a sample of size one) -- 20x that measured sensitivity.  The strict 1e-10 bar on
 identical inputs is enforced separately by the step-locked test (tests/test_gpu_step_locked.py).
 """
 import json
@@ -110,8 +111,10 @@ def main():
         O.lib().oracle_set_dot_mode(0)
         rows, conv, err = run(c["builder"], c["evaluate"], x0, c["max_rows"])
         assert err is None, (name, err)
-        O.lib().oracle_set_dot_mode(1)
-        rows_pw, _, _ = run(c["builder"], c["evaluate"], x0, c["max_rows"])
+        perturbed = []
+        for mode in (1, 2):  # every sum pairwise / sequential from the last term down
+            O.lib().oracle_set_dot_mode(mode)
+            perturbed.append(run(c["builder"], c["evaluate"], x0, c["max_rows"])[0])
         O.lib().oracle_set_dot_mode(0)
         f_floor = 1e-6 * max(abs(rows[0]["fx"]), 1e-300)
         g_floor = 1e-6 * rows[0]["gnorm"]
@@ -121,7 +124,7 @@ def main():
         sens = 0.0
         nfull = len(rows)
         for i in range(1, len(rows) + 1):
-            s = sensitivity(rows[:i], rows_pw[:i], f_floor, g_floor)
+            s = max(sensitivity(rows[:i], rp[:i], f_floor, g_floor) if len(rp) >= i else float("inf") for rp in perturbed)
             if s > 5e-10:
                 break
             keep, sens = i, s

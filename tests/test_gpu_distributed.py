@@ -124,22 +124,27 @@ def test_resident_two_loop_with_the_p2p_exchange(world, n, grid, kind, tmp_path,
 @pytest.mark.parametrize("kind", ["p2p", "p2p-host"])
 def test_resident_p2p_on_a_near_production_grid(kind, tmp_path, monkeypatch):
     """The persistent kernel with the exchange inside its hand-offs on (almost) the grid of the 8-GPU run: rank 0 runs it
-    on 240 of this GPU's 256 CUs -- 240 workgroups polling one another, workgroup 0 exchanging with the peer -- over a
-    shard of 3e6 elements, while a second rank with a sliver of the vector takes 8 of the CUs next to it."""
+    on 224 of this GPU's 256 CUs -- 224 workgroups polling one another, workgroup 0 exchanging with the peer -- over a
+    shard of 3e6 elements, while a second rank with a sliver of the vector takes 8 of the CUs next to it.
+    (Why not 240 + 8: measured with tools/near_grid_probe.py, two PROCESSES' kernels that each want a whole CU per workgroup
+    are co-resident on one MI355X up to 232 + 8 and 247 + 1 workgroups, but not at 240 + 8 or 240 + 1 -- the dispatcher does
+    not hand the last CUs of an XCD to a second process's kernel; profiles/r03_near_grid_probe.log.  One rank per GPU, the
+    deployment this path is for, never shares.)"""
     if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
         pytest.skip("needs the GPU")
     monkeypatch.setenv("LBFGS_WORKER_PRODUCT", "1")
     monkeypatch.setenv("LBFGS_COMM_KIND", kind)
     monkeypatch.setenv("LBFGS_TEST_EXCLUSIVE_DEVICE", "1")
-    monkeypatch.setenv("LBFGS_TEST_RESIDENT_GRIDS", "240,8")
+    monkeypatch.setenv("LBFGS_TEST_RESIDENT_GRIDS", "224,8")
     n, cut = 3_000_000 + 40_960 + 5, 3_000_000
     monkeypatch.setenv("LBFGS_TEST_BOUNDS", json.dumps([0, cut, n]))
-    case = dict(name="quadratic_resident_240", n=n, m=6, iters=12, objective="quadratic")
+    case = dict(name="quadratic_resident_224", n=n, m=6, iters=12, objective="quadratic")
     outs = run_world(case, 2, tmp_path)
     ref_rows, ref_x = oracle_rows(case)
     assert [o["hi"] - o["lo"] for o in outs] == [cut, n - cut]
     for o in outs:
-        assert o["err"] == 0 and o["rows"] == outs[0]["rows"]
+        assert o["err"] == 0, (o["rank"], o["errmsg"])
+        assert o["rows"] == outs[0]["rows"]
         assert o["resident"] >= 9 and o["resident_elements"] == o["hi"] - o["lo"], (o["resident"], o["resident_elements"])
     assert len(outs[0]["rows"]) == len(ref_rows)
     for got, ref in zip(outs[0]["rows"], ref_rows):
@@ -254,7 +259,12 @@ def test_bench_contract_line(world, launch, kind, tmp_path):
         legs = j["config"]["legs"]
         assert any(v["status"] == "ok" for v in legs.values()), legs
         if launch == "plain":
-            assert legs["p2p"]["status"] == "ok" and "rccl" in legs, legs
+            # one GPU: both mailbox placements work between the two processes; RCCL cannot put two ranks on one device, so its
+            # PROBE fails and it is never measured
+            probes = j["config"]["probes"]
+            assert legs["p2p"]["status"] == "ok" and legs["p2p-host"]["status"] == "ok", legs
+            assert probes["rccl"]["status"] != "ok" and "rccl" not in legs, (probes, legs)
+            assert probes["p2p"]["mailboxes"] == "device" and probes["p2p-host"]["mailboxes"] == "host", probes
 
 
 def test_bench_survives_a_hung_leg(tmp_path):

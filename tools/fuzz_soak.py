@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off soak of the seeded random sweep on the HIP path with MANY seeds (the test suite runs seeds 0..59):
     python tools/fuzz_soak.py 60 1500
+    python tools/fuzz_soak.py --seeds 527,3119,5311      (named seeds, each under BOTH launch forms of the two-loop)
 Prints one line per failing seed and a summary; exit code 1 if any seed fails."""
 import os
 import sys
@@ -10,11 +11,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import tests.test_gpu_parity as T  # noqa: E402
 
-lo, hi = int(sys.argv[1]), int(sys.argv[2])
-bad = []
-for seed in range(lo, hi):
+if sys.argv[1] == "--seeds":
+    seeds = [int(t) for t in sys.argv[2].split(",")]
+    todo = [(sd, pth) for sd in seeds for pth in ("resident", "per_step")]
+    lo, hi = min(seeds), max(seeds) + 1
+else:
+    lo, hi = int(sys.argv[1]), int(sys.argv[2])
     # both launch forms of the two-loop in turn (tests/test_gpu_parity.py two_loop_path): one resident kernel / a kernel per step
-    path = "resident" if seed % 2 == 0 else "per_step"
+    todo = [(sd, "resident" if sd % 2 == 0 else "per_step") for sd in range(lo, hi)]
+bad = []
+for seed, path in todo:
     os.environ["LBFGS_HIP_RESIDENT"] = "1" if path == "resident" else "0"
     try:
         T.test_random_configurations_match_oracle(seed, path)
