@@ -63,6 +63,9 @@ constexpr int RES_UNROLL = 4;          // pairs whose loads are issued together 
 //      find an empty queue, and the window is ready when the coefficient is)
 #define LH_RES_PREFETCH 0
 #endif
+#ifndef LH_RES_PLAIN_WO
+#define LH_RES_PLAIN_WO 0  // 1: without OWL-QN, too, the last step stores q as it completes it (A/B: slower, see ResRegStep)
+#endif
 #ifndef LH_RES_DPP
 #define LH_RES_DPP 1  // 1: the hand-off's wave sums with DPP moves + readlane (stream.h wave_sum_dpp) instead of ds_bpermute trees
 #endif
@@ -422,31 +425,7 @@ struct ResGroups {
             ResGroups<G + 1, NG, NT, MODE>::template init<NEED_FIRST>(p_first, p_stride, gp, sp, acc);
         }
     }
-    // d = project(q) ; acc2 += d.d ; acc3 += pg.d  (OWL-QN: see res_one's note)
-    static __device__ __forceinline__ void store_owl(const uint32_t p_first, const uint32_t p_stride, double* dp, const double* pgp,
-                                                     const ResOwl& ow, double* acc) {
-        if constexpr (G < NG) {
-            const uint32_t o0 = res_opaque(p_first);
-            d2 pg[RES_UNROLL];
-#pragma unroll
-            for (int u = 0; u < RES_UNROLL; ++u) pg[u] = ld16_at<NT>(pgp, o0 + (uint32_t)(G * RES_UNROLL + u) * p_stride);
-            asm volatile("" ::: "memory");
-            d2 q[RES_UNROLL] = {acc_get<G * RES_UNROLL + 0>(), acc_get<G * RES_UNROLL + 1>(), acc_get<G * RES_UNROLL + 2>(),
-                                acc_get<G * RES_UNROLL + 3>()};
-#pragma unroll
-            for (int u = 0; u < RES_UNROLL; ++u) {
-                const uint32_t o = o0 + (uint32_t)(G * RES_UNROLL + u) * p_stride;
-                const uint64_t gi = ow.gofs + 2ull * (o >> 4);
-                q[u].x = res_project(q[u].x, pg[u].x, gi, ow);
-                acc[2] += q[u].x * q[u].x; acc[3] += pg[u].x * q[u].x;
-                q[u].y = res_project(q[u].y, pg[u].y, gi + 1, ow);
-                acc[2] += q[u].y * q[u].y; acc[3] += pg[u].y * q[u].y;
-                st16_at<NT>(dp, o, q[u]);
-            }
-            res_pin_sums<2>(acc + 2);
-            ResGroups<G + 1, NG, NT, MODE>::store_owl(p_first, p_stride, dp, pgp, ow, acc);
-        }
-    }
+    // d = q (the plain case; under OWL-QN the last step writes q out itself: ResRegStep WO)
     static __device__ __forceinline__ void store(const uint32_t p_first, const uint32_t p_stride, double* dp) {
         if constexpr (G < NG) {
             const uint32_t o0 = res_opaque(p_first);
@@ -521,11 +500,35 @@ __device__ __forceinline__ void res_shift(ResWin& w, const d2 (&fu)[RES_UNROLL],
 #pragma unroll
     for (int u = 0; u < RES_UNROLL; ++u) { w.u[RES_AHEAD - 1][u] = fu[u]; w.v[RES_AHEAD - 1][u] = fv[u]; }
 }
-template <int G, int ER, bool NT, int MODE>
+// WO (the LAST step only, MODE 2): where the step leaves q.  0: on the chip, as every other step does (the plain case: d is
+// written by a pass of stores after the last hand-off).  2: in d, under OWL-QN, with the orthant projection
+// (orthantwise.rs:140-161) applied on the way out: the step streams v = pg anyway, so pg is not read a second time (25
+// instead of 26 passes at m = 6); acc0 stays ||d||^2 BEFORE the projection (lbfgs.rs:543 precedes :554), acc2 / acc3 sum
+// ||d||^2 and pg.d of the projected direction.  (1: the plain case stored the same way -- measured 1.5-3.6 % SLOWER than
+// the separate pass at 3e6 ... 1.25e7 elements, profiles/r03_resident_fused_writeout_ab.log; kept for A/B builds only.)
+struct ResOut {
+    double* d;
+    ResOwl ow;
+};
+template <int WO>
+__device__ __forceinline__ void res_project_pair(d2& q, const d2 pg, const uint64_t gi, const ResOwl& ow, double* acc) {
+    if constexpr (WO == 2) {
+        q.x = res_project(q.x, pg.x, gi, ow);
+        acc[2] += q.x * q.x; acc[3] += pg.x * q.x;
+        q.y = res_project(q.y, pg.y, gi + 1, ow);
+        acc[2] += q.y * q.y; acc[3] += pg.y * q.y;
+    }
+}
+template <int MODE, int WO>
+__device__ __forceinline__ void res_pin_step(double* acc) {
+    res_pin_sums<(MODE == 2 ? 2 : 1)>(acc);
+    if constexpr (WO == 2) res_pin_sums<2>(acc + 2);
+}
+template <int G, int ER, bool NT, int MODE, int WO>
 struct ResRegStep {
     static constexpr int NG = ER / RES_UNROLL;
     static __device__ __forceinline__ void run(ResWin& w, const ResPos& ps, const double* up, const double* vp, const double c,
-                                               const double gamma, double* acc) {
+                                               const double gamma, double* acc, const ResOut& out) {
         if constexpr (G < NG) {
             d2 fu[RES_UNROLL], fv[RES_UNROLL];
             ResFetch<ER, NT, MODE != 1>::template any<G + RES_AHEAD>(ps, up, vp, fu, fv);
@@ -537,13 +540,27 @@ struct ResRegStep {
             res_one<MODE>(q1, w.u[0][1], w.v[0][1], c, gamma, acc);
             res_one<MODE>(q2, w.u[0][2], w.v[0][2], c, gamma, acc);
             res_one<MODE>(q3, w.u[0][3], w.v[0][3], c, gamma, acc);
-            acc_put<G * RES_UNROLL + 0>(q0);
-            acc_put<G * RES_UNROLL + 1>(q1);
-            acc_put<G * RES_UNROLL + 2>(q2);
-            acc_put<G * RES_UNROLL + 3>(q3);
-            res_pin_sums<(MODE == 2 ? 2 : 1)>(acc);
+            if constexpr (WO == 0) {
+                acc_put<G * RES_UNROLL + 0>(q0);
+                acc_put<G * RES_UNROLL + 1>(q1);
+                acc_put<G * RES_UNROLL + 2>(q2);
+                acc_put<G * RES_UNROLL + 3>(q3);
+            } else {  // the last step: q leaves the chip here
+                const uint32_t o0 = res_opaque(ps.p_first * 16u), os = ps.p_stride * 16u;
+                const uint32_t oa = o0 + (uint32_t)(G * RES_UNROLL + 0) * os, ob = o0 + (uint32_t)(G * RES_UNROLL + 1) * os,
+                               oc = o0 + (uint32_t)(G * RES_UNROLL + 2) * os, od = o0 + (uint32_t)(G * RES_UNROLL + 3) * os;
+                res_project_pair<WO>(q0, w.v[0][0], out.ow.gofs + 2ull * (oa >> 4), out.ow, acc);
+                res_project_pair<WO>(q1, w.v[0][1], out.ow.gofs + 2ull * (ob >> 4), out.ow, acc);
+                res_project_pair<WO>(q2, w.v[0][2], out.ow.gofs + 2ull * (oc >> 4), out.ow, acc);
+                res_project_pair<WO>(q3, w.v[0][3], out.ow.gofs + 2ull * (od >> 4), out.ow, acc);
+                st16_at<NT>(out.d, oa, q0);
+                st16_at<NT>(out.d, ob, q1);
+                st16_at<NT>(out.d, oc, q2);
+                st16_at<NT>(out.d, od, q3);
+            }
+            res_pin_step<MODE, WO>(acc);
             res_shift(w, fu, fv);
-            ResRegStep<G + 1, ER, NT, MODE>::run(w, ps, up, vp, c, gamma, acc);
+            ResRegStep<G + 1, ER, NT, MODE, WO>::run(w, ps, up, vp, c, gamma, acc, out);
         }
     }
 };
@@ -552,10 +569,12 @@ struct ResRegStep {
 // on-chip group of this step is worked on -- every step has at least one LDS group -- so that those loads have returned
 // when this step's own last operands have: a wave's loads return in order, and the polls of the hand-off that follows
 // must not queue behind a window of HBM loads.
-template <int ER, bool NT, int MODE, bool EARLY>
+template <int ER, bool NT, int MODE, bool EARLY, int WO = 0>
 __device__ __forceinline__ void res_step(ResWin& w, d2* q_lds, const ResPos& ps, const double* up, const double* vp, const double c,
-                                         const double gamma, double* acc, ResWin& wnext, const double* nup, const double* nvp) {
-    ResRegStep<0, ER, NT, MODE>::run(w, ps, up, vp, c, gamma, acc);
+                                         const double gamma, double* acc, ResWin& wnext, const double* nup, const double* nvp,
+                                         const ResOut& out = ResOut{}) {
+    static_assert(WO == 0 || MODE == 2, "only the last step writes q out");
+    ResRegStep<0, ER, NT, MODE, WO>::run(w, ps, up, vp, c, gamma, acc, out);
     const uint32_t tid = threadIdx.x, NL = ps.EL / RES_UNROLL;
     for (uint32_t j = 0; j < NL; ++j) {
         if constexpr (EARLY) {
@@ -574,9 +593,14 @@ __device__ __forceinline__ void res_step(ResWin& w, d2* q_lds, const ResPos& ps,
             if (!(p < ps.n2)) { uu = d2{0.0, 0.0}; vv = d2{0.0, 0.0}; }  // padding pairs stay 0 and add 0
             d2 q = q_lds[(size_t)(j * RES_UNROLL + u) * BLOCK + tid];
             res_one<MODE>(q, uu, vv, c, gamma, acc);
-            q_lds[(size_t)(j * RES_UNROLL + u) * BLOCK + tid] = q;
+            if constexpr (WO == 0) {
+                q_lds[(size_t)(j * RES_UNROLL + u) * BLOCK + tid] = q;
+            } else {  // the last step: q leaves the chip here (padding pairs: q = 0, nothing to store)
+                res_project_pair<WO>(q, vv, out.ow.gofs + 2ull * p, out.ow, acc);
+                if (p < ps.n2) st16<NT>(out.d, p, q);
+            }
         }
-        res_pin_sums<(MODE == 2 ? 2 : 1)>(acc);
+        res_pin_step<MODE, WO>(acc);
         res_shift(w, fu, fv);
     }
 }
@@ -817,8 +841,10 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         } else if (mode == 1) {
             res_step<ER, NT, 1, EARLY>(win, q_lds, ps, st.u, st.u, c, gamma, acc, wnext, nup, nvp);
             if constexpr (HYB) res_step_hbm<NT, 1>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.u, c, gamma, acc, ow);
-        } else {
-            res_step<ER, NT, 2, EARLY>(win, q_lds, ps, st.u, st.v, c, gamma, acc, wnext, nup, nvp);
+        } else {  // the last step: q goes out to d as it is completed (projected on the way under OWL-QN)
+            const ResOut out{a.d, ow};
+            if (a.owl) res_step<ER, NT, 2, EARLY, 2>(win, q_lds, ps, st.u, st.v, c, gamma, acc, wnext, nup, nvp, out);
+            else res_step<ER, NT, 2, EARLY, LH_RES_PLAIN_WO>(win, q_lds, ps, st.u, st.v, c, gamma, acc, wnext, nup, nvp, out);
             if constexpr (HYB) {
                 if (a.owl) res_step_hbm<NT, 3>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc, ow);  // (projected here)
                 else res_step_hbm<NT, 2>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc, ow);
@@ -853,24 +879,10 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         if constexpr (PF == 1) { if (si + 1 < a.nsteps) prefetch(si + 1); }
     }
 
-    // ---- d = q (OWL-QN: projected, with the sums of the projected direction) ; totals
+    // ---- OWL-QN: d has been written by the last step (res_step WO = 2); what is left: the odd element and the hand-off of
+    // the four sums (||d||^2 before the projection, --, ||d||^2 and pg.d after it).  Plain: d = q, a pass of stores.
     if (a.owl) {
         const double* pgp = a.step[a.nsteps - 1].v;  // the last step's v is pg
-        // (acc0: ||d||^2 before the projection, complete; acc2, acc3: the hybrid rounds' share so far, 0 otherwise)
-        ResGroups<0, NG, NT, 0>::store_owl(b_first, b_stride, a.d, pgp, ow, acc);
-        for (uint32_t e = 0; e < EL; ++e) {
-            const uint32_t p = p_first + (ER + e) * p_stride;
-            if (p < n2) {
-                const d2 pg = ld16<NT>(pgp, p);
-                d2 q = q_lds[(size_t)e * BLOCK + tid];
-                const uint64_t gi = a.gofs + 2ull * p;
-                q.x = res_project(q.x, pg.x, gi, ow);
-                acc[2] += q.x * q.x; acc[3] += pg.x * q.x;
-                q.y = res_project(q.y, pg.y, gi + 1, ow);
-                acc[2] += q.y * q.y; acc[3] += pg.y * q.y;
-                st16<NT>(a.d, p, q);
-            }
-        }
         if (tail_owner) {
             const double pgt = pgp[a.n - 1];
             q_tail = res_project(q_tail, pgt, a.gofs + a.n - 1, ow);
@@ -885,10 +897,12 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         acc[1] = t4[2];
         acc[2] = t4[3];
     } else {
-        ResGroups<0, NG, NT, 0>::store(b_first, b_stride, a.d);
-        for (uint32_t e = 0; e < EL; ++e) {
-            const uint32_t p = p_first + (ER + e) * p_stride;
-            if (p < n2) st16<NT>(a.d, p, q_lds[(size_t)e * BLOCK + tid]);
+        if constexpr (LH_RES_PLAIN_WO == 0) {
+            ResGroups<0, NG, NT, 0>::store(b_first, b_stride, a.d);
+            for (uint32_t e = 0; e < EL; ++e) {
+                const uint32_t p = p_first + (ER + e) * p_stride;
+                if (p < n2) st16<NT>(a.d, p, q_lds[(size_t)e * BLOCK + tid]);
+            }
         }
         if (tail_owner) a.d[a.n - 1] = q_tail;
     }
