@@ -324,11 +324,14 @@ dist.destroy_process_group()
 '''
 
 
-def test_p2p_exchange_times_out_instead_of_hanging(tmp_path):
+@pytest.mark.parametrize("placement", ["device", "host"])
+def test_p2p_exchange_times_out_instead_of_hanging(placement, tmp_path, monkeypatch):
     """A peer that never arrives: the bounded spin gives up after p2p_timeout_s and the NEXT scalar read fails with
-    LBFGS_HIP_ERR_COMM -- through the host mirror (in-kernel exchange) and through the copy path alike."""
+    LBFGS_HIP_ERR_COMM -- through the host mirror (in-kernel exchange) and through the copy path alike, with the mailboxes
+    in device memory and in host shared memory."""
     if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
         pytest.skip("needs the GPU")
+    monkeypatch.setenv("LBFGS_HIP_P2P_MAILBOX", placement)
     import subprocess
     import sys
 

@@ -13,7 +13,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["LBFGS_WORKER_PRODUCT"] = "1"
-os.environ["LBFGS_COMM_KIND"] = "p2p"
+os.environ.setdefault("LBFGS_COMM_KIND", "p2p")   # (LBFGS_COMM_KIND=p2p-host: mailboxes in host shared memory)
 os.environ["LBFGS_TEST_EXCLUSIVE_DEVICE"] = "1"
 from tests.test_distributed_cpu import oracle_rows, run_world  # noqa: E402
 
