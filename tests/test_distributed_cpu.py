@@ -213,6 +213,37 @@ def test_three_ranks_uneven_shards(tmp_path):
     assert np.max(np.abs(x - ref_x)) <= 1e-9 * max(np.max(np.abs(ref_x)), 1e-12)
 
 
+def test_explicit_shard_bounds(tmp_path, monkeypatch):
+    """`sharded_context(bounds=...)`: shards need not be even -- a large one, a sliver and an EMPTY one; OWL-QN's range straddles
+    the first boundary.  Same trajectory as the single-rank oracle; invalid bounds are refused."""
+    monkeypatch.setenv("LBFGS_TEST_BOUNDS", json.dumps([0, 2817, 3001, 3001]))
+    case = dict(name="owlqn_bounds", n=3001, m=6, iters=20, objective="logistic", owl=[0.5, 700, 2900])
+    outs = run_world(case, 3, tmp_path)
+    ref_rows, ref_x = oracle_rows(case)
+    assert [(o["lo"], o["hi"]) for o in outs] == [(0, 2817), (2817, 3001), (3001, 3001)]
+    assert outs[0]["rows"] == outs[1]["rows"] == outs[2]["rows"] and all(o["err"] == 0 for o in outs)
+    assert len(outs[0]["rows"]) == len(ref_rows)
+    for got, ref in zip(outs[0]["rows"], ref_rows):
+        assert got[:3] == ref[:3]
+        for a, b in zip(got[3:], ref[3:]):
+            assert abs(a - b) <= 1e-9 * max(abs(b), 1e-6), (got, ref)
+    x = np.concatenate([np.array(o["x"]) for o in outs])
+    assert np.max(np.abs(x - ref_x)) <= 1e-9 * max(np.max(np.abs(ref_x)), 1e-12)
+    import rust_lbfgs_amd as R  # noqa: F401
+    from rust_lbfgs_amd import dist as D
+
+    class FakeDist:  # (bounds are validated before anything touches a process group)
+        pass
+
+    import torch.distributed as tdist
+
+    monkeypatch.setattr(tdist, "get_rank", lambda g=None: 0)
+    monkeypatch.setattr(tdist, "get_world_size", lambda g=None: 2)
+    for bad in ([0, 10], [1, 5, 10], [0, 7, 5, 10][:3], [0, 11, 10]):
+        with pytest.raises(ValueError):
+            D.sharded_context(10, kind="callback", bounds=bad)
+
+
 def test_eight_ranks_as_in_the_metric(tmp_path):
     """world = 8, the rank count BASELINE.json's metric names: eight contiguous 256-aligned shards (the last one
     short), OWL-QN range straddling several shard boundaries, every rank holding the same global scalars."""
