@@ -116,6 +116,22 @@ void uc_mbox_retire(int device, void* p) {
     std::lock_guard<std::mutex> lk(g_uc_pool_mu);
     g_uc_mbox_pool[device].push_back(p);
 }
+// Peers' device-placed mailboxes stay mapped for the life of the process, for the same reason: a peer that pools its
+// mailbox exports the same IPC handle again, and an address range that was mapped uncached is not unmapped and handed
+// to the allocator for something else.  Keyed by the 64 handle bytes.
+std::map<std::string, void*> g_ipc_open;
+hipError_t ipc_open_cached(const hipIpcMemHandle_t& hdl, void** out) {
+    const std::string key(reinterpret_cast<const char*>(&hdl), sizeof(hdl));
+    std::lock_guard<std::mutex> lk(g_uc_pool_mu);
+    auto it = g_ipc_open.find(key);
+    if (it != g_ipc_open.end()) {
+        *out = it->second;
+        return hipSuccess;
+    }
+    const hipError_t e = hipIpcOpenMemHandle(out, hdl, hipIpcMemLazyEnablePeerAccess);
+    if (e == hipSuccess) g_ipc_open[key] = *out;
+    return e;
+}
 
 void host_mbox_unlink_all() {  // atexit: names of segments this process still owns
     std::lock_guard<std::mutex> lk(g_host_mbox_mu);
@@ -1447,8 +1463,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
             hipIpcMemHandle_t hdl;
             memcpy(&hdl, hraw, sizeof(hdl));
             // (LBFGS_HIP_TEST_FAIL_IPC_OPEN=1: tests of the host-placement fallback pretend the mapping is refused)
-            hipError_t e = getenv("LBFGS_HIP_TEST_FAIL_IPC_OPEN") ? hipErrorInvalidValue
-                                                                  : hipIpcOpenMemHandle(&p, hdl, hipIpcMemLazyEnablePeerAccess);
+            hipError_t e = getenv("LBFGS_HIP_TEST_FAIL_IPC_OPEN") ? hipErrorInvalidValue : ipc_open_cached(hdl, &p);
             if (e != hipSuccess) {
                 int rc = fail(nullptr, LBFGS_HIP_ERR_COMM, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
                 lbfgs_hip_ctx_destroy(ctx);
@@ -1484,7 +1499,7 @@ void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* ctx) {
     if (ctx->nccl && g_rccl.ok) g_rccl.CommDestroy(ctx->nccl);
     for (int r = 0; r < P2P_MAX_WORLD; ++r) {
         if (!ctx->p2p_mbox[r]) continue;
-        if (ctx->p2p_opened[r]) (void)hipIpcCloseMemHandle(ctx->p2p_mbox[r]);
+        if (ctx->p2p_opened[r]) continue;  // (a peer's mailbox: stays mapped, see ipc_open_cached)
         else if (!host_mbox_release(ctx->p2p_mbox[r])) uc_mbox_retire(ctx->device, ctx->p2p_mbox[r]);
     }
     if (ctx->p2p_err) (void)hipFree(ctx->p2p_err);

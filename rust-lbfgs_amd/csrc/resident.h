@@ -20,8 +20,9 @@
 // kernels.  After a step every workgroup publishes its partial sum(s) as tagged 8-byte
 // granules (tag = the step's sequence number; agent-scope atomics on both sides, no fence: stream.h) into a double
 // buffer indexed by the step's parity, and then EVERY workgroup collects all G partials -- thread t polls workgroup t's
-// granules -- and adds them up in the fixed order of stream.h's reducer (wave tree, waves in order).  All workgroups
-// therefore hold the same bits for the total and form the same coefficient; no broadcast step is needed.  A workgroup can
+// granules -- and adds them up in one fixed order (each wave's 64 values by stream.h wave_sum_dpp, then the waves in
+// order).  All workgroups therefore hold the same bits for the total and form the same coefficient; no broadcast step
+// is needed.  (That order is this kernel's own: not the launch-per-step reducer's ds_bpermute tree.)  A workgroup can
 // be at most one step ahead of any other (it needs everybody's partial of step s to leave step s), so two buffers
 // suffice.  All G workgroups must be resident at once: the grid is at most one workgroup per CU (the LDS share makes it
 // exactly one), the kernel is launched alone on its stream, and every spin is bounded by a wall-clock timeout that raises
@@ -209,7 +210,8 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
 #pragma unroll
             for (int k = 0; k < NS; ++k) tot[k] += __longlong_as_double((long long)((hi[k] << 32) | (lo[k] & 0xffffffffULL)));
         }
-        // the reducer's order: thread-strided partials, wave tree, waves in order
+        // a fixed order: thread-strided partials, each wave's sum (stream.h wave_sum_dpp: rows of 16 as trees, the four rows
+        // in order), the waves in order -- the same in every workgroup, so all of them hold the same bits
 #if LH_RES_SLIM
         res_block_total<NS>(tot, rows2);
         if (multi) {  // (workgroup 0 only) p2p_exchange works on LDS
