@@ -298,6 +298,8 @@ struct lbfgs_hip_ctx {
     int gram_combine_resident = 1;        // LBFGS_HIP_GRAM_COMBINE_RESIDENT=0: the vector-free combine as one streaming pass over all columns
     int lj_build_fp32 = 1;                // LBFGS_HIP_LJ_BUILD_FP32=0: the LJ_CELLS list from double-precision candidate tests
     size_t resident_nt_bytes = (size_t)16 << 20;  // LBFGS_HIP_RESIDENT_NT_MB
+    size_t resident_plain_bytes = (size_t)256 << 20;  // LBFGS_HIP_RESIDENT_PLAIN_MB: hybrid: so much of the HBM part of q keeps the default
+                                          // cache policy and stays in the 256 MiB Infinity Cache between steps (resident.h res_hbm_rounds)
     int resident_hybrid = 1;              // LBFGS_HIP_RESIDENT_HYBRID=0: shards that do not fit the chip take the kernel-per-step path
     uint64_t resident_elements = 0;       // elements of q the last resident launch kept on the chip (all of them unless hybrid)
     int resident_grid = 0;                // LBFGS_HIP_RESIDENT_GRID: workgroups of the resident kernel (0 = one per CU); tests
@@ -1333,6 +1335,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     if (const char* e = getenv("LBFGS_HIP_HANDOFF_TIMEOUT_MS")) ctx->handoff_timeout_ticks = (unsigned long long)std::max(1, atoi(e)) * 100000ULL;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_NT_MB")) ctx->resident_nt_bytes = (size_t)std::max(0, atoi(e)) << 20;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_HYBRID")) ctx->resident_hybrid = atoi(e) != 0;
+    if (const char* e = getenv("LBFGS_HIP_RESIDENT_PLAIN_MB")) ctx->resident_plain_bytes = (size_t)std::max(0, atoi(e)) << 20;
     if (const char* e = getenv("LBFGS_HIP_GRAPH")) ctx->graph_max_bytes = atoi(e) ? ~(size_t)0 : 0;
     if (const char* e = getenv("LBFGS_HIP_GRAPH_MAX_MB")) ctx->graph_max_bytes = (size_t)atoll(e) << 20;
     if (const char* e = getenv("LBFGS_HIP_NT_STORE_THRESHOLD_MB")) ctx->nt_store_threshold_bytes = (size_t)atoll(e) << 20;
@@ -2166,6 +2169,9 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     ra.pairs_per_thread = (uint32_t)E;
     ra.lds_pairs = el;
     ra.hbm_pairs = eh;
+    // the slice of the HBM part of q that is kept out of the `nt` stream (resident.h res_hbm_rounds): so many MiB of it
+    ra.hbm_plain_pairs = eh ? (uint32_t)std::min<uint64_t>(eh, (ctx->resident_plain_bytes + per_round * 16 - 1) / (per_round * 16)) : 0u;
+    if (ctx->resident_plain_bytes == 0) ra.hbm_plain_pairs = 0;
     int ns = 0;
     auto add = [&](const double* u, const double* v, int j, int mode_b, int scale, int aidx, int last) {
         ResStep& st = ra.step[ns++];

@@ -47,7 +47,9 @@ constexpr int RES_UNROLL = 4;          // pairs whose loads are issued together 
 #define LH_RES_P2P_ONE_HOP 0  // several ranks: every workgroup reads the ranks' totals from the mailbox itself (no local broadcast hop)
 #endif
 #ifndef LH_RES_HBM_ALTERNATE
-#define LH_RES_HBM_ALTERNATE 0  // hybrid: odd steps sweep the HBM rounds from the top down (what a step wrote last, the next reads first)
+#define LH_RES_HBM_ALTERNATE 1  // hybrid: odd steps sweep the HBM rounds from the top down (what a step wrote last, the next reads
+                                // first).  Pays together with the cache slice of res_hbm_rounds: a slice larger than the Infinity
+                                // Cache then degrades gracefully instead of thrashing (profiles/r03_hybrid_cache_slice_ab.log)
 #endif
 #ifndef LH_RES_HBM_UNROLL
 #define LH_RES_HBM_UNROLL 4
@@ -103,6 +105,7 @@ struct ResArgs {
     uint32_t pairs_per_thread;  // E: 16-byte pairs each thread owns (registers first, then LDS, then -- hybrid -- HBM)
     uint32_t lds_pairs;         // of which in LDS (a multiple of RES_UNROLL)
     uint32_t hbm_pairs;         // hybrid: the rounds beyond registers + LDS, whose part of q lives in `d` itself (0: none)
+    uint32_t hbm_plain_pairs;   // ... of which the first so many are accessed with the default cache policy (res_hbm_rounds)
     int nsteps;
     int fault_drop_last;        // tests (LBFGS_HIP_RESIDENT_FAULT=1): the last workgroup leaves at once, as if it had never been
                                 // given a CU -- the others time out in their first hand-off and the host falls back
@@ -641,20 +644,20 @@ struct ResHbmGroup {
     d2 q[RES_HBM_UNROLL], u[RES_HBM_UNROLL], v[RES_HBM_UNROLL];
 };
 // (full rounds only: no bounds checks, no branches)
-template <bool NT, bool NEEDV>
+template <bool NT, bool QNT, bool NEEDV>
 __device__ __forceinline__ void res_hbm_fetch(ResHbmGroup& g, const uint32_t e, const ResPos& ps, const double* qsrc,
                                               const double* up, const double* vp) {
     const uint32_t p0 = res_opaque(ps.p_first + e * ps.p_stride);
 #pragma unroll
     for (int k = 0; k < RES_HBM_UNROLL; ++k) {
         const uint32_t p = p0 + (uint32_t)k * ps.p_stride;
-        g.q[k] = ld16<NT>(qsrc, p);
+        g.q[k] = ld16<QNT>(qsrc, p);
         g.u[k] = ld16<NT>(up, p);
         if constexpr (NEEDV) g.v[k] = ld16<NT>(vp, p);
         else g.v[k] = g.u[k];
     }
 }
-template <bool NT, int MODE>
+template <bool NT, bool QNT, int MODE>
 __device__ __forceinline__ void res_hbm_work(ResHbmGroup& g, const uint32_t e, const ResPos& ps, const double qsign, double* d,
                                              const double c, const double gamma, double* acc, const ResOwl& ow) {
     const uint32_t p0 = res_opaque(ps.p_first + e * ps.p_stride);
@@ -665,32 +668,32 @@ __device__ __forceinline__ void res_hbm_work(ResHbmGroup& g, const uint32_t e, c
         q.y = q.y * qsign;
         const uint32_t p = p0 + (uint32_t)k * ps.p_stride;
         res_hbm_one<MODE>(q, g.u[k], g.v[k], c, gamma, acc, ow, p);
-        st16<NT>(d, p, q);
+        st16<QNT>(d, p, q);
     }
     res_hbm_pin<MODE>(acc);
 }
 // rounds [e_begin, e_end) of this thread; every round before the shard's last one is full for every thread, so groups of
 // RES_HBM_UNROLL rounds below `e_full` run without checks and the (at most RES_HBM_UNROLL) rounds after them one at a
 // time.  `rev`: sweep from the high addresses down (the groups in descending order, the last rounds first).
-template <bool NT, int MODE>
+template <bool NT, bool QNT, int MODE>
 __device__ __forceinline__ void res_hbm_tail(const uint32_t e_full, const uint32_t e_end, const ResPos& ps, const double* qsrc,
                                              const double qsign, double* d, const double* up, const double* vp, const double c,
                                              const double gamma, double* acc, const ResOwl& ow) {
     for (uint32_t e = e_full; e < e_end; ++e) {  // the last few rounds, the ragged one among them
         const uint32_t p = ps.p_first + e * ps.p_stride;
         if (p < ps.n2) {
-            d2 q = ld16<NT>(qsrc, p);
+            d2 q = ld16<QNT>(qsrc, p);
             const d2 uu = ld16<NT>(up, p);
             d2 vv = uu;
             if constexpr (MODE != 1) vv = ld16<NT>(vp, p);
             q.x = q.x * qsign;
             q.y = q.y * qsign;
             res_hbm_one<MODE>(q, uu, vv, c, gamma, acc, ow, p);
-            st16<NT>(d, p, q);
+            st16<QNT>(d, p, q);
         }
     }
 }
-template <bool NT, int MODE>
+template <bool NT, bool QNT, int MODE>
 __device__ __forceinline__ void res_step_hbm(const uint32_t e_begin, const uint32_t e_end, const bool rev, const ResPos& ps,
                                              const double* qsrc, const double qsign, double* d, const double* up, const double* vp,
                                              const double c, const double gamma, double* acc, const ResOwl& ow) {
@@ -698,7 +701,7 @@ __device__ __forceinline__ void res_step_hbm(const uint32_t e_begin, const uint3
     asm volatile("" ::: "memory");
     const uint32_t ngroups = (e_end - 1 - e_begin) / RES_HBM_UNROLL;  // groups made of full rounds only
     const uint32_t e_full = e_begin + ngroups * RES_HBM_UNROLL;
-    if (rev) res_hbm_tail<NT, MODE>(e_full, e_end, ps, qsrc, qsign, d, up, vp, c, gamma, acc, ow);
+    if (rev) res_hbm_tail<NT, QNT, MODE>(e_full, e_end, ps, qsrc, qsign, d, up, vp, c, gamma, acc, ow);
     if (ngroups > 0) {
         ResHbmGroup ga, gb;  // two buffers, used alternately: the next group's 12 loads fly while one is worked on
         const uint32_t last = ngroups - 1;
@@ -706,21 +709,41 @@ __device__ __forceinline__ void res_step_hbm(const uint32_t e_begin, const uint3
             const uint32_t k = min(i, last);
             return e_begin + (rev ? last - k : k) * RES_HBM_UNROLL;
         };
-        res_hbm_fetch<NT, MODE != 1>(ga, first_round(0), ps, qsrc, up, vp);
+        res_hbm_fetch<NT, QNT, MODE != 1>(ga, first_round(0), ps, qsrc, up, vp);
         uint32_t i = 0;
         for (;;) {
-            res_hbm_fetch<NT, MODE != 1>(gb, first_round(i + 1), ps, qsrc, up, vp);
+            res_hbm_fetch<NT, QNT, MODE != 1>(gb, first_round(i + 1), ps, qsrc, up, vp);
             asm volatile("" ::: "memory");
-            res_hbm_work<NT, MODE>(ga, first_round(i), ps, qsign, d, c, gamma, acc, ow);
+            res_hbm_work<NT, QNT, MODE>(ga, first_round(i), ps, qsign, d, c, gamma, acc, ow);
             if (++i >= ngroups) break;
-            res_hbm_fetch<NT, MODE != 1>(ga, first_round(i + 1), ps, qsrc, up, vp);
+            res_hbm_fetch<NT, QNT, MODE != 1>(ga, first_round(i + 1), ps, qsrc, up, vp);
             asm volatile("" ::: "memory");
-            res_hbm_work<NT, MODE>(gb, first_round(i), ps, qsign, d, c, gamma, acc, ow);
+            res_hbm_work<NT, QNT, MODE>(gb, first_round(i), ps, qsign, d, c, gamma, acc, ow);
             if (++i >= ngroups) break;
         }
     }
-    if (!rev) res_hbm_tail<NT, MODE>(e_full, e_end, ps, qsrc, qsign, d, up, vp, c, gamma, acc, ow);
+    if (!rev) res_hbm_tail<NT, QNT, MODE>(e_full, e_end, ps, qsrc, qsign, d, up, vp, c, gamma, acc, ow);
     asm volatile("" ::: "memory");
+}
+
+// The HBM rounds of one step.  Rounds [e0, ep) -- the "cache slice" of q -- are read and written with the DEFAULT cache
+// policy, rounds [ep, e1) with the `nt` hint like the history vectors.  MI355X's 256 MiB Infinity Cache sits between the
+// L2s and HBM: what carries `nt` passes through it without staying, so a slice of q of about its size that is NOT marked
+// `nt` is still there when the next step reads it again -- and is rewritten there -- instead of making the round trip to
+// HBM (ResArgs::hbm_plain_pairs; 0 = everything streamed).  Measured (profiles/r03_hybrid_cache_slice_ab.log): the
+// two-loop kernel at n = 1e8, m = 10 9.71 -> 9.26 ms with a 256 MiB slice and the alternating sweep; 5e7: 4.58 -> 4.07;
+// 2.5e7: 1.98 -> 1.80; a slice beyond 256 MiB without the alternating sweep thrashes (10.0 ms).
+template <bool NT, int MODE>
+__device__ __forceinline__ void res_hbm_rounds(const uint32_t e0, const uint32_t ep, const uint32_t e1, const bool rev, const ResPos& ps,
+                                               const double* qsrc, const double qsign, double* d, const double* up, const double* vp,
+                                               const double c, const double gamma, double* acc, const ResOwl& ow) {
+    if (rev) {
+        res_step_hbm<NT, NT, MODE>(ep, e1, true, ps, qsrc, qsign, d, up, vp, c, gamma, acc, ow);
+        if constexpr (NT) res_step_hbm<NT, false, MODE>(e0, ep, true, ps, qsrc, qsign, d, up, vp, c, gamma, acc, ow);
+    } else {
+        if constexpr (NT) res_step_hbm<NT, false, MODE>(e0, ep, false, ps, qsrc, qsign, d, up, vp, c, gamma, acc, ow);
+        res_step_hbm<NT, NT, MODE>(ep, e1, false, ps, qsrc, qsign, d, up, vp, c, gamma, acc, ow);
+    }
 }
 
 // ER = pairs per thread held in (accumulation) registers: a multiple of RES_UNROLL, at most 60.
@@ -772,6 +795,7 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
     }
     // hybrid rounds: q stays in HBM (the first step reads it from g); only the first numerator needs them here
     const uint32_t EH0 = ER + EL, EH1 = ER + EL + (HYB ? a.hbm_pairs : 0u);
+    const uint32_t EHP = NT ? EH0 + (HYB ? min(a.hbm_plain_pairs, a.hbm_pairs) : 0u) : EH0;  // (see res_hbm_rounds)
     if (HYB && need_first) {
         for (uint32_t e = EH0; e < EH1; ++e) {
             const uint32_t p = p_first + e * p_stride;
@@ -839,17 +863,17 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         const double* nvp = a.step[sn].v ? a.step[sn].v : nup;
         if (mode == 0) {
             res_step<ER, NT, 0, EARLY>(win, q_lds, ps, st.u, st.v, c, gamma, acc, wnext, nup, nvp);
-            if constexpr (HYB) res_step_hbm<NT, 0>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc, ow);
+            if constexpr (HYB) res_hbm_rounds<NT, 0>(EH0, EHP, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc, ow);
         } else if (mode == 1) {
             res_step<ER, NT, 1, EARLY>(win, q_lds, ps, st.u, st.u, c, gamma, acc, wnext, nup, nvp);
-            if constexpr (HYB) res_step_hbm<NT, 1>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.u, c, gamma, acc, ow);
+            if constexpr (HYB) res_hbm_rounds<NT, 1>(EH0, EHP, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.u, c, gamma, acc, ow);
         } else {  // the last step: q goes out to d as it is completed (projected on the way under OWL-QN)
             const ResOut out{a.d, ow};
             if (a.owl) res_step<ER, NT, 2, EARLY, 2>(win, q_lds, ps, st.u, st.v, c, gamma, acc, wnext, nup, nvp, out);
             else res_step<ER, NT, 2, EARLY, LH_RES_PLAIN_WO>(win, q_lds, ps, st.u, st.v, c, gamma, acc, wnext, nup, nvp, out);
             if constexpr (HYB) {
-                if (a.owl) res_step_hbm<NT, 3>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc, ow);  // (projected here)
-                else res_step_hbm<NT, 2>(EH0, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc, ow);
+                if (a.owl) res_hbm_rounds<NT, 3>(EH0, EHP, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc, ow);  // (projected here)
+                else res_hbm_rounds<NT, 2>(EH0, EHP, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc, ow);
             }
         }
         if constexpr (EARLY) win = wnext;
