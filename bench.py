@@ -478,7 +478,10 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
                 roof.update(achieved=ach, frac=ach / HBM_PEAK_GBPS, kernel="two_loop_resident_kernel<ER,NT>",
                             launches=nr, avg_ms=avg_ms, bytes_per_launch=nbytes, resident_elements=n_res,
                             note="algorithmic bytes of THIS kernel: (4m+1) n-vector passes over the elements of q it keeps "
-                                 "on the chip, (8m-1) over the rest (hybrid: shards larger than ~1.25e7 elements)")
+                                 "on the chip, (8m-1) over the rest (hybrid: shards larger than ~1.25e7 elements).  In the hybrid "
+                                 "form a 256 MiB slice of the rest keeps the default cache policy and is served by the Infinity "
+                                 "Cache between steps: those bytes are requested by the kernel (and counted here and by "
+                                 "`traffic`, which counts what leaves the L2s) but do not all reach HBM")
             elif ns:
                 avg_ms = ms_step / ns
                 ach = 32.0 * n_local / (avg_ms * 1e-3) / 1e9  # 3 reads + 1 write of f64 per element

@@ -92,3 +92,52 @@ def test_two_contexts_on_two_streams_of_one_gpu(monkeypatch):
     assert not errs, errs
     for rows_g, xg in out:
         close(rows_o, rows_g, xo, xg)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# environment knobs: every setting that selects another code path must give the oracle's trajectory
+# ------------------------------------------------------------------------------------------------------------
+_ORACLE_RUNS = {}
+KNOBS = [
+    {},                                                   # defaults
+    {"LBFGS_HIP_GRAN_CACHED": "1"},                       # granules in plain hipMalloc memory
+    {"LBFGS_HIP_RESIDENT_PLAIN_MB": "0"},                 # hybrid: no cache slice, everything streamed
+    {"LBFGS_HIP_RESIDENT_PLAIN_MB": "1"},                 # hybrid: a slice of 32 rounds, the rest `nt` (both halves of res_hbm_rounds)
+    {"LBFGS_HIP_RESIDENT_HYBRID": "0"},                   # shards beyond the chip: kernel per step
+    {"LBFGS_HIP_RESIDENT": "0"},                          # never the persistent kernel
+    {"LBFGS_HIP_RESIDENT": "0", "LBFGS_HIP_DEFER_SUMS": "0"},
+    {"LBFGS_HIP_RESIDENT": "0", "LBFGS_HIP_GRAPH": "1"},
+    {"LBFGS_HIP_HANDOFF": "ticket"},                      # arrival-counter reductions (the persistent kernel is not eligible)
+    {"LBFGS_HIP_NO_MIRROR": "1"},                         # scalar reads by copy
+    {"LBFGS_HIP_RESIDENT_NT_MB": "100000"},               # the persistent kernel without `nt` hints
+]
+
+
+@pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join(f"{a[10:]}={b}" for a, b in k.items()) or "defaults")
+@pytest.mark.parametrize("shape", ["on_chip", "hybrid_streaming"])
+def test_every_knob_setting_follows_the_oracle(knobs, shape, monkeypatch):
+    """on_chip: n = 300 007 on the default grid (the whole running vector in registers + LDS).  hybrid_streaming: n = 3.3e6
+    on 8 workgroups -- 26 MB vectors carry the `nt` hints, and 8 workgroups hold 3.9e5 elements, so 88 % of q lives in HBM:
+    the form n = 1e8 takes on a whole GPU, cache slice and alternating sweep included."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs the GPU")
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    if shape == "on_chip":
+        n, m, iters = 300_007, 6, 12
+    else:
+        n, m, iters = 3_300_001, 5, 9
+        monkeypatch.setenv("LBFGS_HIP_RESIDENT_GRID", "8")
+    if (n, m, iters) not in _ORACLE_RUNS:
+        _ORACLE_RUNS[(n, m, iters)] = run_oracle(n, m, iters)
+    rows_o, xo = _ORACLE_RUNS[(n, m, iters)]
+    with R.Context(n) as ctx:
+        rows_g, xg = run_device(ctx, n, m, iters)
+        resident, on_chip = ctx.resident_two_loops(), ctx.resident_elements()
+    close(rows_o, rows_g, xo, xg)
+    eligible = knobs.get("LBFGS_HIP_RESIDENT") != "0" and knobs.get("LBFGS_HIP_HANDOFF") != "ticket"
+    if shape == "hybrid_streaming" and knobs.get("LBFGS_HIP_RESIDENT_HYBRID") == "0":
+        eligible = False
+    assert (resident > 0) == eligible, (resident, knobs)
+    if eligible and shape == "hybrid_streaming":
+        assert on_chip == 2 * 96 * 256 * 8
