@@ -94,7 +94,7 @@ def parse(argv=None):
     ap.add_argument("--total-budget", type=float, default=520.0,
                     help="N>1: wall-clock budget of the whole run (s): probes and legs get their timeouts from what is left of it")
     ap.add_argument("--probe-timeout", type=float, default=30.0,
-                    help="N>1: bound on one communicator probe (s); the first probe gets twice that (it pays the box's cold start)")
+                    help="N>1: bound on one communicator probe (s); the first probe and rccl's get twice that (the box's cold start; RCCL's first communicator)")
     ap.add_argument("--no-vector-free", action="store_true",
                     help="skip the extra measurement of the vector-free (Gram) two-loop extension")
     ap.add_argument("--line-eval", type=int, default=2, choices=[0, 1, 2],
@@ -910,7 +910,8 @@ def supervisor_main(a):
     passed = []
     for i, leg in enumerate(comms):
         t0 = time.monotonic()
-        tmo = decided(min(a.probe_timeout * (2.0 if i == 0 else 1.0), left() - RESERVE))
+        # (the first probe also pays for paging the libraries in; RCCL's first communicator over 8 GPUs takes its time)
+        tmo = decided(min(a.probe_timeout * (2.0 if (i == 0 or leg == "rccl") else 1.0), left() - RESERVE))
         if tmo < 3.0:
             probes[leg] = {"status": "skipped: budget spent", "seconds": 0.0}
             continue

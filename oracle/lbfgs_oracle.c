@@ -44,9 +44,21 @@ static double sum_pairwise(const double* t, size_t n) {
     size_t h = n / 2;
     return sum_pairwise(t, h) + sum_pairwise(t + h, n - h);
 }
+/* DIAGNOSTIC ONLY (dot modes 3 and 4): K running sums, term i into sum i % K, joined by a pairwise tree -- the shape a
+ * vector unit gives a sum (K = 4) and the shape of a wavefront's lanes (K = 64).  x == NULL: the terms are y[i] alone. */
+static double sum_strided(const double* x, const double* y, size_t n, int K) {
+    double acc[64];
+    for (int k = 0; k < K; ++k) acc[k] = 0.0;
+    for (size_t i = 0; i < n; ++i) acc[i % (size_t)K] += x ? x[i] * y[i] : y[i];
+    for (int w = 1; w < K; w *= 2)
+        for (int k = 0; k + w < K; k += 2 * w) acc[k] += acc[k + w];
+    return acc[0];
+}
 int oracle_dot_mode(void) { return g_dot_mode; }
 double oracle_sum_terms(const double* t, size_t n) {
     if (g_dot_mode == 1) return sum_pairwise(t, n);
+    if (g_dot_mode == 3) return sum_strided(NULL, t, n, 4);
+    if (g_dot_mode == 4) return sum_strided(NULL, t, n, 64);
     if (g_dot_mode == 2) { /* diagnostic: the reference's running sum, from the last term down */
         double acc = 0.0;
         for (size_t i = n; i-- > 0;) acc += t[i];
@@ -65,6 +77,8 @@ void oracle_vecadd(double* y, const double* x, double c, size_t n) {
 /* math.rs:40-42  s = sum_i x_i*y_i, sequential */
 double oracle_vecdot(const double* x, const double* y, size_t n) {
     if (g_dot_mode == 1) return dot_pairwise(x, y, n);
+    if (g_dot_mode == 3) return sum_strided(x, y, n, 4);
+    if (g_dot_mode == 4) return sum_strided(x, y, n, 64);
     if (g_dot_mode == 2) { /* diagnostic: the same terms, summed from the last one down */
         double acc = 0.0;
         for (size_t i = n; i-- > 0;) acc += x[i] * y[i];

@@ -107,9 +107,11 @@ typedef struct oracle_report {
 
 /* ---- math.rs:31-82 -------------------------------------------------------- */
 /* dot mode: 0 = sequential left-to-right (the reference, math.rs:41);
- * 1 = pairwise tree, 2 = sequential from the LAST term down (diagnostic only: two independent perturbations of the
- * summation order, from which the tests estimate how strongly a run amplifies last-bit differences).  Modes 1 and 2
- * reorder EVERY sum of the restatement: vecdot, x1norm and the f of the built-in objectives.  Process-global, default 0. */
+ * 1 = pairwise tree, 2 = sequential from the LAST term down, 3 / 4 = 4 / 64 interleaved running sums joined by a tree
+ * (diagnostic only: independent perturbations of the summation order, from which the tests estimate how strongly a run
+ * amplifies last-bit differences; a run whose terms are all equal -- Rosenbrock from its standard start -- is blind to
+ * mode 2).  Modes 1-4 reorder EVERY sum of the restatement: vecdot, x1norm and the f of the built-in objectives.
+ * Process-global, default 0. */
 void oracle_set_dot_mode(int mode);
 int oracle_dot_mode(void);
 /* sum of a term array in the current mode (sequential = the reference; pairwise = diagnostic) */

@@ -53,11 +53,23 @@ def oracle_objective(c):
     return {"quadratic": O.quadratic, "logistic": O.logistic, "rosenbrock": O.rosenbrock}[c["kind"]]()
 
 
-def run_oracle(c, mode=0):
-    """-> (rows, x, error code or 0)"""
+def last_bit_neighbour(x0, k):
+    """x0 with every non-zero element moved to one of its two neighbouring doubles (seeded choice): the smallest change of
+    the starting point there is.  A run that takes this far from the unperturbed one amplifies ANY last-bit difference."""
+    r = np.random.default_rng(7919 * k + 13)
+    up = r.random(x0.shape[0]) < 0.5
+    x = np.where(up, np.nextafter(x0, np.inf), np.nextafter(x0, -np.inf))
+    return np.where(x0 == 0.0, 0.0, x)
+
+
+def run_oracle(c, mode=0, neighbour=0):
+    """-> (rows, x, error code or 0).  mode: the summation order (oracle_set_dot_mode); neighbour k > 0: start from the k-th
+    last-bit neighbour of x0 instead."""
     O.lib().oracle_set_dot_mode(mode)
     try:
         rows, x = [], x0_of(c)
+        if neighbour:
+            x = last_bit_neighbour(x, neighbour)
         try:
             configure(O.lbfgs(), c).minimize(x, oracle_objective(c), lambda p: rows.append(
                 (p["niter"], p["neval"], p["ncall"], p["fx"], p["xnorm"], p["gnorm"], p["step"])) and False)
@@ -68,17 +80,25 @@ def run_oracle(c, mode=0):
         O.lib().oracle_set_dot_mode(0)
 
 
-PERTURBED_MODES = (1, 2)  # oracle_set_dot_mode: every sum pairwise / from the last term down
+CHAOS = 1e-9  # a run whose own scatter under last-bit changes exceeds this amplifies them a million-fold: no parity case from there on
+NEIGHBOURS = (1, 2)  # ... and the reference's own order from two last-bit neighbours of x0 (last_bit_neighbour)
+PERTURBED_MODES = (1, 2, 3, 4)  # oracle_set_dot_mode: every sum pairwise / from the last term down / 4 / 64 interleaved running sums
 
 
 def order_sensitivity(c, ro, eo):
     """How strongly does THIS run amplify a mere change of summation order?  The oracle is re-run with every sum formed in
-    two other orders (pairwise; sequential from the last term down) and, iteration by iteration, the largest scaled
-    deviation of either from the reference run is the `floor` the comparison with the GPU is calibrated on (one perturbed
-    run underestimates it now and then: a sample of size one).  -> (floors, stable_prefix, all_stable):
-    floors[i] = running maximum up to iteration i; stable_prefix = iterations over which both perturbed runs take the
-    reference run's discrete decisions and stay below 1e-8; all_stable = they also end the same way."""
+    four other orders (pairwise; sequential from the last term down; 4 and 64 interleaved running sums) and, iteration by
+    iteration, the largest scaled deviation of any of them from the reference run is the `floor` the comparison with the GPU
+    is calibrated on (a small sample underestimates it now and then; a run whose terms are all equal -- Rosenbrock from its
+    standard start -- does not even notice the reversed order, and the other orders move such sums far less than they move
+    sums of unequal terms).  Two more re-runs keep the reference's order and start from last-bit neighbours of x0 instead
+    (every element moved to an adjacent double): what a run makes of THAT is its amplification of last-bit differences
+    whatever the structure of its sums.  -> (floors, stable_prefix, all_stable):
+    floors[i] = running maximum up to iteration i; stable_prefix = iterations over which all perturbed runs take the
+    reference run's discrete decisions and stay below CHAOS; all_stable = they also end the same way."""
     runs = [run_oracle(c, mode) for mode in PERTURBED_MODES]
+    if np.any(x0_of(c) != 0.0):
+        runs += [run_oracle(c, 0, neighbour=k) for k in NEIGHBOURS]
     f0 = max(abs(ro[0][3]), 1e-3) if ro else 1.0
     g0 = max(ro[0][5], 1e-6) if ro else 1.0
     floors, floor = [], 0.0
@@ -91,7 +111,7 @@ def order_sensitivity(c, ro, eo):
                 ok = False
                 break
             floor = max(floor, max((0.0 if (u != u and v != v) else abs(u - v) / s) for u, v, s in zip(a[3:], r[i][3:], scale)))
-        if not ok or floor > 1e-8:  # chaotic for ANY summation order from here on: stop comparing
+        if not ok or floor > CHAOS:  # the reference itself is beyond ten times the parity bar from here on: stop comparing
             all_stable = False
             break
         floors.append(floor)

@@ -832,9 +832,9 @@ def test_lj38_damped_device_objective():
 @pytest.mark.parametrize("seed", range(60))
 def test_random_configurations_match_oracle(seed, two_loop_path):
     """The seeded random sweep of tests/fuzz_common.py on the HIP path: same error code, same discrete decisions
-    (neval, ncall) and values within the run's calibrated tolerance (20x the oracle's own sensitivity to the
-    summation order -- the larger of two perturbed re-runs, tests/fuzz_common.py order_sensitivity --, floor 1e-10) for as
-    long as the oracle itself is insensitive to that order."""
+    (neval, ncall) and values within the run's calibrated tolerance (20x the oracle's own sensitivity to last-bit
+    changes -- the largest of six perturbed re-runs: four other summation orders, two last-bit neighbours of x0;
+    tests/fuzz_common.py order_sensitivity --, floor 1e-10) for as long as the oracle itself is insensitive to them."""
     from tests import fuzz_common as F
 
     c = F.make_case(seed)

@@ -110,3 +110,46 @@ def test_doc_example_max_iterations():
     seen = []
     O.lbfgs().with_max_iterations(5).minimize(x, O.rosenbrock(), lambda p: seen.append(p["niter"]) and False)
     assert seen == [1, 2, 3, 4, 5]
+
+
+def test_diagnostic_summation_orders():
+    """`oracle_set_dot_mode` 1-4 only re-order sums (the tests' summation-order sensitivity estimate rests on that):
+    each mode against the same order written out in Python, mode 0 against the reference's running sum (math.rs:41)."""
+    r = np.random.default_rng(5)
+    for n in (1, 2, 5, 63, 64, 65, 257, 1000):
+        x, y = r.standard_normal(n) * 10.0 ** r.integers(-3, 4, n), r.standard_normal(n)
+        t = x * y
+
+        def strided(K):
+            acc = [0.0] * K
+            for i in range(n):
+                acc[i % K] += t[i]
+            w = 1
+            while w < K:
+                for k in range(0, K - w, 2 * w):
+                    acc[k] += acc[k + w]
+                w *= 2
+            return acc[0]
+
+        def pairwise(a):
+            if len(a) <= 32:
+                s = 0.0
+                for v in a:
+                    s += v
+                return s
+            h = len(a) // 2
+            return pairwise(a[:h]) + pairwise(a[h:])
+
+        def seq(a):
+            s = 0.0
+            for v in a:
+                s += v
+            return s
+
+        want = {0: seq(t), 1: pairwise(list(t)), 2: seq(t[::-1]), 3: strided(4), 4: strided(64)}
+        try:
+            for mode, w in want.items():
+                O.lib().oracle_set_dot_mode(mode)
+                assert O.vecdot(x, y) == w, (n, mode)
+        finally:
+            O.lib().oracle_set_dot_mode(0)
