@@ -78,7 +78,9 @@ def parse(argv=None):
     ap.add_argument("--no-prof", action="store_true", help="do not time kernels with HIP events in the timed region")
     ap.add_argument("--prof-every", type=int, default=5,
                     help="time kernels with HIP events on every k-th step of the timed region only: an event pair per "
-                         "kernel costs ~1.5 us of stream time, 11 %% of an iteration at 100 MB shards when always on")
+                         "kernel costs ~1.5 us of stream time, 11 %% of an iteration at 100 MB shards when always on -- and "
+                         "pairs around EVERY kernel read the long kernels ~6 %% short (the time reappears between the "
+                         "pairs; rocprofv3 agrees with the sparse sampling, profiles/EXPERIMENTS.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=20_000_000, help="sample size of the sampled CPU baseline (~10 s on one core)")
     ap.add_argument("--no-cpu-full", action="store_true",
