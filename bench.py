@@ -219,7 +219,7 @@ def cpu_baseline_child_main(a):
 def start_cpu_baseline(a):
     """-> Popen of the child above (never touches a GPU), or None."""
     args = [sys.executable, os.path.join(ROOT, "bench.py"), "--_cpu-baseline-child", "--dim", str(a.n), "--hist", str(a.m),
-            "--cpu-n", str(a.cpu_n)]
+            "--cpu-n", str(min(a.cpu_n, a.n))]
     if a.no_cpu_full:
         args.append("--no-cpu-full")
     env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
@@ -380,6 +380,96 @@ def make_context(env, kind):
     return ctx, kind
 
 
+def loaded_build_id():
+    """lbfgs_hip_build_id() of the library this process measures with"""
+    from rust_lbfgs_amd import _ffi
+
+    try:
+        return _ffi.load().lbfgs_hip_build_id().decode()
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def traffic_lookup(n_local, m, kernel, build_id=None, profiles_dir=None):
+    """roofline.traffic: HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS
+    command (tools/profile_round.sh; rocprofv3 counters cannot be collected from inside this process).  A file counts only
+    if it was taken at this shard size, this m and for this kernel (strict: a near-by size is a different measurement);
+    the record names the build the passes were made with and whether that is the build measuring now."""
+    import glob
+
+    if build_id is None:
+        build_id = loaded_build_id()
+    out, best = {}, None
+    for path in sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "pmc_traffic*.json"))):
+        try:
+            pm = json.load(open(path))
+            if (pm["n_local"] == n_local and pm.get("m", 10) == m
+                    and pm.get("kernel", "stream_kernel").split("<")[0] == kernel.split("<")[0]):
+                cur = pm.get("build_id") is not None and pm.get("build_id") == build_id
+                if best is None or (cur and not best[0]):
+                    best = (cur, pm, path)
+        except Exception:  # noqa: BLE001
+            pass
+    if best is not None:
+        cur, pm, path = best
+        out = {"traffic": pm["traffic_bytes_per_launch"] / 1e9,
+               "traffic_unit": "GB per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)",
+               "traffic_source": pm.get("_source"), "traffic_file": os.path.relpath(path, ROOT),
+               "traffic_build_id": pm.get("build_id"), "traffic_is_current": bool(cur), "loaded_build_id": build_id}
+    return out
+
+
+COMM_COUNTERS = ("two_loops", "two_loop_exchanges", "allreduce_launches", "p2p_exchanges")
+COMM_CLASSED = ("timed_exchanges", "exchange_us", "local_wait_us")
+
+
+def comm_counters_add(acc, before, after):
+    """acc += (after - before) over the counters of Context.comm_info()"""
+    acc = acc or {**{k: 0 for k in COMM_COUNTERS}, **{k: {"other": 0, "two_loop": 0} for k in COMM_CLASSED}}
+    for k in COMM_COUNTERS:
+        acc[k] += after[k] - before[k]
+    for k in COMM_CLASSED:
+        for c in ("other", "two_loop"):
+            acc[k][c] += after[k][c] - before[k][c]
+    return acc
+
+
+def exchange_figures(ctx, ci_sum, roof):
+    """What the communicator of this rank really spans and what one cross-rank exchange costs, over the timed regions
+    (lbfgs_hip_ctx_comm_info; `ci_sum`: the counters accumulated over the timed regions).  The figures also go into `roof`
+    (roofline.exchange_us_mean, roofline.exchanges_per_two_loop): they are what a scaling shortfall is attributed with."""
+    try:
+        ci = ctx.comm_info()
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] comm_info unavailable: {e}", file=sys.stderr)
+        return None
+    comm = {k: ci[k] for k in ("kind", "world", "rank", "ranks_seen", "rank_seen", "mailbox_placement", "peers_device",
+                               "peers_host", "exclusive_device", "resident_fallbacks")}
+    z = ci_sum or comm_counters_add(None, ci, ci)
+    d = lambda k: z[k]  # noqa: E731
+    dd = lambda k, c: z[k][c]  # noqa: E731
+    two_loops, tl_x = d("two_loops"), d("two_loop_exchanges")
+    comm["exchanges_per_two_loop"] = (tl_x / two_loops) if two_loops else None
+    timed = dd("timed_exchanges", "two_loop")
+    if timed:
+        comm["exchange_us_mean"] = dd("exchange_us", "two_loop") / timed
+        comm["local_wait_us_mean"] = dd("local_wait_us", "two_loop") / timed
+        comm["exchange_timing"] = ("measured on the device by the workgroup that closes a reduction across ranks (wall clock): "
+                                   "stores to every peer's mailbox + wait for every peer's values; exchanges inside two-loops only")
+    elif ci["kind"] == "rccl" and roof.get("per_iteration_ms", {}).get("allreduce_launches"):
+        pi = roof["per_iteration_ms"]
+        comm["exchange_us_mean"] = pi["allreduce"] / pi["allreduce_launches"] * 1e3
+        comm["local_wait_us_mean"] = None
+        comm["exchange_timing"] = "HIP events around the grouped ncclAllReduce launches on the compute stream (all of them, not only the two-loop's)"
+    else:
+        comm["exchange_us_mean"] = comm["local_wait_us_mean"] = None
+    other = dd("timed_exchanges", "other")
+    comm["exchange_us_mean_outside_two_loop"] = (dd("exchange_us", "other") / other) if other else None
+    roof["exchange_us_mean"] = comm["exchange_us_mean"]
+    roof["exchanges_per_two_loop"] = comm["exchanges_per_two_loop"]
+    return comm
+
+
 def measure(env, ctx, label, vector_free=False, repeats=1):
     """`repeats` times: a fresh state, W warm-up steps (history full), then exactly K timed steps between barriers;
     max over ranks.  Every rank executes the same barriers and collectives even if its own run failed, so a failure
@@ -396,11 +486,13 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
     if vector_free:
         builder = builder.with_vector_free(True)
     x0 = np.zeros(ctx.n_local)
-    hold = {"state": None, "restarts": 0}
+    hold = {"state": None, "restarts": 0, "vf_fallbacks": 0}
     prefill = max(0, a.m + 2 - a.warmup)  # history must be full (bound = m) before anything is timed
 
     def fresh():
         if hold["state"] is not None:
+            if vector_free:
+                hold["vf_fallbacks"] += hold["state"].vector_free_fallbacks()
             hold["state"].close()
             hold["state"] = None
         hold["state"] = builder.build(x0, objectives.Quadratic(fuse_line_eval=a.line_eval), ctx=ctx)
@@ -418,6 +510,7 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
 
     ok = 1.0
     dts, ncalls = [], 0
+    ci_sum = None  # the communicator's counters over the TIMED regions only (history full: steady-state exchange counts)
     auto = repeats <= 0
     nrep = 5 if auto else repeats
     rep = -1
@@ -432,6 +525,7 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
                     ctx.prof_enable(True)
                     ctx.prof_reset()
                     ctx.prof_enable(False)
+                ci_before = ctx.comm_info()
         except R.LbfgsError as e:
             print(f"[bench] rank {env.rank}: {label} failed in warm-up: {e}", file=sys.stderr)
             ok = 0.0
@@ -448,6 +542,11 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
             ok = 0.0
         env.barrier(ctx)
         dt = time.perf_counter() - t0
+        try:
+            if ok:
+                ci_sum = comm_counters_add(ci_sum, ci_before, ctx.comm_info())
+        except R.LbfgsError as e:
+            print(f"[bench] rank {env.rank}: comm_info failed: {e}", file=sys.stderr)
         dts.append(env.reduce(dt, "MAX"))
         ok = env.reduce(ok, "MIN")
         if ok != 1.0:
@@ -493,18 +592,7 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
                 # HBM bytes per launch: rocprofv3 PMC counters cannot be collected from inside this process; the
                 # figure is taken from the committed counter passes of THIS command (tools/profile_round.sh) when
                 # they were made at this shard size and for this kernel, and the record names them -- otherwise null
-                import glob
-
-                for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_traffic*.json"))):
-                    try:
-                        pm = json.load(open(path))
-                        if (pm["n_local"] == n_local and pm.get("m", 10) == a.m
-                                and pm.get("kernel", "stream_kernel").split("<")[0] == roof["kernel"].split("<")[0]):
-                            roof["traffic"] = pm["traffic_bytes_per_launch"] / 1e9
-                            roof["traffic_unit"] = "GB per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)"
-                            roof["traffic_source"] = pm.get("_source")
-                    except Exception:  # noqa: BLE001
-                        pass
+                roof.update(traffic_lookup(n_local, a.m, roof["kernel"]))
             if nt:
                 t_tl = ms_all / nt
                 # 8*b passes of 8 bytes is the fused minimum that respects the dot->axpy dependency;
@@ -533,10 +621,11 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
             roof["per_iteration_ms"] = {
                 "two_loop": ms_all / sampled, "history_update": ms_upd / sampled, "line_eval": ms_eval / sampled,
                 "allreduce": ms_comm / sampled, "allreduce_launches": nc / sampled, "sampled_steps": nt}
+        comm = exchange_figures(ctx, ci_sum, roof)
         srt = sorted(dts)
         med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
         first = prefill + a.warmup + 1  # LbfgsState::propagate calls count from 1 (the first is a no-op: lbfgs.rs:507-510)
-        res = dict(label=label, value=a.steps / med, ms_per_step=med / a.steps * 1e3, roofline=roof, n_local=n_local,
+        res = dict(label=label, value=a.steps / med, ms_per_step=med / a.steps * 1e3, roofline=roof, n_local=n_local, comm=comm,
                    prefill=prefill, trials=ncalls / max(a.steps * len(dts), 1), restarts=hold["restarts"],
                    repeats=[round(a.steps / d, 3) for d in dts], best=a.steps / srt[0], timed_s=sum(dts),
                    window={"first_iteration": first, "last_iteration": first + a.steps - 1,
@@ -545,6 +634,10 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
                                    "later iterations of this problem need fewer line-search trials and read faster"})
     if hold["state"] is not None:
         try:
+            if vector_free:
+                hold["vf_fallbacks"] += hold["state"].vector_free_fallbacks()
+                if res is not None:
+                    res["vector_free_fallbacks"] = hold["vf_fallbacks"]
             hold["state"].close()
         except Exception:  # noqa: BLE001
             pass
@@ -594,6 +687,9 @@ def compose(a, world, results, ext, legs=None):
            "extension_vector_free_two_loop": ext}
     if legs is not None:
         cfg["legs"] = legs
+    if best.get("comm"):
+        cfg["comm_info"] = best["comm"]
+        cfg["ranks_seen"] = best["comm"]["ranks_seen"]
     return {
         "metric": "L-BFGS iters/sec (two-loop HBM GB/s in roofline) at n=1e8, m=10",
         "value": best["value"],
@@ -667,6 +763,9 @@ def worker_main(a):
                 if rv is not None:
                     tl = rv["roofline"].get("two_loop", {})
                     ext[label] = {"iters_per_sec": round(rv["value"], 3), "two_loop_ms": tl.get("ms"),
+                                  "fallbacks": rv.get("vector_free_fallbacks"),
+                                  "fallbacks_note": "iterations (warm-up included) whose coefficient-space direction failed its "
+                                                    "run-time ||d||^2 check and was redone by the exact recursion",
                                   "two_loop_passes": 4 * a.m + 3, "repeats_iters_per_sec": rv["repeats"]}
         ctx.close()
 
@@ -789,7 +888,11 @@ def supervisor_main(a):
     world = int(os.environ["WORLD_SIZE"]) if under_launcher else a.gpus
     a.gpus = world
     probes, report, lines = {}, {}, []
-    state = {"done": False}
+    state = {"done": False, "cpu_child": None}
+    # The CPU baseline (the reference is single-threaded: one pinned core, the N = 1 configuration) runs BESIDE the legs: this
+    # process touches no GPU and would otherwise idle for the whole budget.  Rank 0's supervisor only.
+    if rank == 0 and not a.no_cpu_baseline:
+        state["cpu_child"] = start_cpu_baseline(a)
 
     def final_line():
         """the best measurement so far as the run's line (None if there is none)"""
@@ -809,7 +912,18 @@ def supervisor_main(a):
         cfg["launch"] = ("torch.distributed.run ranks as supervisors, one child rank each per job"
                          if under_launcher else "self-launched: one torch.distributed.run child per job")
         cfg["budget"] = {"total_s": a.total_budget, "used_s": round(time.monotonic() - t_start, 1)}
+        cfg["ranks_seen"] = (cfg.get("comm_info") or {}).get("ranks_seen")
         return best
+
+    def attach_cpu_baseline(best, wait_s):
+        """the baseline child's result into the line (it has had the whole run to finish; `wait_s` more at most)"""
+        child, state["cpu_child"] = state["cpu_child"], None
+        if child is None or best is None:
+            return
+        cb = collect_cpu_baseline(child, a, timeout=max(0.5, wait_s))
+        cb["where"] = ("rank 0's supervisor process (no GPU), started before the first probe and timed while the legs ran; the "
+                       "reference is single-threaded, so this is the N = 1 figure whatever --gpus says")
+        best["cpu_baseline"] = cb
 
     def on_signal(signum, _frame):
         # the driver (or torch.distributed.run, on its behalf) wants this run to end NOW: end the running job and hand over
@@ -827,8 +941,14 @@ def supervisor_main(a):
                   file=sys.stderr)
             if best is not None:
                 best["config"]["interrupted_by_signal"] = int(signum)
+                attach_cpu_baseline(best, 0.5)  # (only if it has finished: no time to wait now)
                 os.write(real_stdout, (json.dumps(best) + "\n").encode())
                 rc = 0
+        if state["cpu_child"] is not None:
+            try:
+                state["cpu_child"].kill()
+            except OSError:
+                pass
         os._exit(rc)
 
     signal.signal(signal.SIGTERM, on_signal)
@@ -942,6 +1062,13 @@ def supervisor_main(a):
         status, j = run_job(leg, False, tmo, vector_free=vf)
         report[leg] = {"status": status, "seconds": round(time.monotonic() - t0, 1), "timeout_s": round(tmo, 1),
                        "iters_per_sec": round(j["value"], 3) if j else None}
+        if j:  # what the leg's communicator really spanned and what an exchange cost it (lbfgs_hip_ctx_comm_info on rank 0)
+            ci = j["config"].get("comm_info") or {}
+            report[leg].update(ranks_seen=ci.get("ranks_seen"), mailboxes_mapped=(ci.get("peers_device"), ci.get("peers_host")),
+                               mailbox_placement=ci.get("mailbox_placement"), exchange_us_mean=ci.get("exchange_us_mean"),
+                               local_wait_us_mean=ci.get("local_wait_us_mean"),
+                               exchanges_per_two_loop=ci.get("exchanges_per_two_loop"),
+                               two_loop_ms=((j.get("roofline") or {}).get("two_loop") or {}).get("ms"))
         if j:
             lines.append((leg, j))
         if rank == 0:
@@ -981,7 +1108,11 @@ def supervisor_main(a):
             print("bench.py: no communicator leg produced a result: " + json.dumps({"probes": probes, "legs": report}), file=sys.stderr)
             rc = 1
         else:
+            attach_cpu_baseline(best, left() + 60.0)  # (normally long finished; the driver's limit is 80 s past the budget)
             os.write(real_stdout, (json.dumps(best) + "\n").encode())
+    if state["cpu_child"] is not None:
+        state["cpu_child"].kill()
+        state["cpu_child"] = None
     if dist is not None:
         ok = [rc]
         dist.broadcast_object_list(ok, src=0)

@@ -39,10 +39,13 @@
 extern "C" {
 #endif
 
-/* 2: lbfgs_hip_objective.skin, lbfgs_hip_comm.exclusive_device, LBFGS_HIP_K_TWOLOOP_RESIDENT (all round 2, unversioned then),
+/* 3: lbfgs_hip_ctx_comm_info / lbfgs_hip_comm_info (round 4); lbfgs_hip_sync, lbfgs_hip_vec_download and
+ *    lbfgs_hip_history_scalars_read report device errors (and recover from a timed-out resident two-loop) like
+ *    lbfgs_hip_scalars_read.
+ * 2: lbfgs_hip_objective.skin, lbfgs_hip_comm.exclusive_device, LBFGS_HIP_K_TWOLOOP_RESIDENT (all round 2, unversioned then),
  *    mailbox placements, lbfgs_hip_build_id.  A caller compares lbfgs_hip_abi_version() with the constant it was built
  *    against before anything else (rust-lbfgs_amd/_ffi.py, integration/rust-shim, tests/support/c_caller.c do). */
-#define LBFGS_HIP_ABI_VERSION 2
+#define LBFGS_HIP_ABI_VERSION 3
 #define LBFGS_HIP_BOARD_SLOTS 256
 
 /* status codes */
@@ -127,9 +130,38 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
                          const lbfgs_hip_comm* comm, void* stream);
 void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* ctx);
 const char* lbfgs_hip_last_error(const lbfgs_hip_ctx* ctx); /* ctx may be NULL: creation errors */
+/* waits for the stream; returns the device error, if any, like lbfgs_hip_scalars_read (a resident two-loop that timed out
+ * is re-run with a kernel per step first) */
 int lbfgs_hip_sync(lbfgs_hip_ctx* ctx);
 void* lbfgs_hip_stream(lbfgs_hip_ctx* ctx); /* hipStream_t */
 int lbfgs_hip_get_shard(const lbfgs_hip_ctx* ctx, lbfgs_hip_shard* out);
+/* What the communicator of this context really spans, and what its exchanges cost -- so that a multi-GPU measurement can be
+ * cross-checked ("did RCCL see N ranks?") and a scaling shortfall attributed ("how long does one exchange take?").
+ * Synchronises the stream. */
+typedef struct lbfgs_hip_comm_info {
+    int32_t kind;               /* LBFGS_HIP_COMM_* */
+    int32_t world, rank;        /* the shard this context was created with */
+    int32_t ranks_seen;         /* RCCL: ncclCommCount of the communicator (ctx_create fails unless it equals world);
+                                   P2P: mailboxes this rank can reach = its own + the peers' it mapped; none: 1; callback: 0
+                                   (the library sees no peer itself) */
+    int32_t rank_seen;          /* RCCL: ncclCommUserRank; otherwise rank */
+    int32_t mailbox_placement;  /* P2P: LBFGS_HIP_MAILBOX_DEVICE / _HOST of this rank's own mailbox; otherwise -1 */
+    int32_t peers_device, peers_host; /* P2P: peers' mailboxes mapped, by placement */
+    int32_t exclusive_device;   /* lbfgs_hip_comm.exclusive_device as given */
+    int32_t _pad;
+    uint64_t two_loops;          /* two-loop recursions enqueued so far (any launch form) */
+    uint64_t two_loop_exchanges; /* cross-rank exchanges enqueued inside them (world > 1; 2*bound or 2*bound+1 each) */
+    uint64_t allreduce_launches; /* stand-alone all-reduces enqueued (RCCL / callback / the P2P kernel) */
+    uint64_t p2p_exchanges;      /* P2P exchanges enqueued so far, in-kernel ones included */
+    uint64_t resident_fallbacks; /* resident two-loops that timed out and were re-run with a kernel per step */
+    /* measured ON THE DEVICE by the one workgroup that closes a reduction across ranks (P2P only; wall clock, 100 MHz),
+     * class [0] = exchanges outside a two-loop, [1] = inside one: */
+    uint64_t timed_exchanges[2]; /* exchanges the figures below cover */
+    double exchange_us[2];       /* total time inside the exchange proper: stores to every peer's mailbox + wait for every
+                                    peer's values (includes waiting for a peer that arrives later) */
+    double local_wait_us[2];     /* total time that workgroup waited for this GPU's other workgroups before it */
+} lbfgs_hip_comm_info;
+int lbfgs_hip_ctx_comm_info(lbfgs_hip_ctx* ctx, lbfgs_hip_comm_info* out);
 /* launch geometry override for tuning (0 = default): blocks, i.e. workgroups per launch */
 int lbfgs_hip_set_grid(lbfgs_hip_ctx* ctx, int blocks);
 /* which code path the two-loop recursions of this context took so far: how many ran as the single on-chip-resident
@@ -243,7 +275,11 @@ int lbfgs_hip_two_loop_owlqn(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs
  * kernel runs lbfgs.rs:582-601 on 2m+1 coefficients, one pass forms d.  4m+3 passes and 2 all-reduces
  * instead of 8m+1 and 2m+1.  Mathematically identical; rounding differs (tests bound it by 1e-10 against
  * the exact recursion).  Requires that it is called after EVERY history update (the Gram matrix is
- * maintained incrementally) and m <= 10.  Same arguments and outputs as lbfgs_hip_two_loop. */
+ * maintained incrementally) and m <= 10.  Same arguments and outputs as lbfgs_hip_two_loop, plus a run-time check of the
+ * coefficient-space arithmetic: board[dnorm_slot+2] = ||d||^2 as the Gram entries PREDICT it (delta^T G delta; NaN if a
+ * coefficient is not finite) next to board[dnorm_slot] = ||d||^2 summed over the direction itself.  When the two differ by
+ * more than rounding (the solver: 1e-8 relative) the Gram entries have lost the digits the recursion needs -- a run that
+ * blows up, or one converged to rounding level -- and the caller forms this direction again with lbfgs_hip_two_loop_from. */
 int lbfgs_hip_two_loop_gram(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
                             int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int* new_end);
 /* the same recursion as the reference's UNFUSED sequence of primitives (10*bound+2 passes);

@@ -146,6 +146,10 @@ int lbfgs_state_download(lbfgs_state* st, int which, double* host);
 void* lbfgs_state_devptr(lbfgs_state* st, int which);
 lbfgs_hip_vec* lbfgs_state_vec(lbfgs_state* st, int which); /* borrowed handle (e.g. Problem::search_direction) */
 int lbfgs_state_info(lbfgs_state* st, uint64_t* k, uint64_t* end, double* step, double* gamma);
+/* EXTENSION (lbfgs_param.vector_free): iterations so far whose coefficient-space direction failed the run-time check --
+ * the ||d||^2 its Gram arithmetic predicts against the ||d||^2 summed over the direction itself, 1e-8 relative, or a
+ * coefficient that is not finite -- and was formed again by the exact recursion (lbfgs.rs:569-604) */
+int lbfgs_state_vector_free_fallbacks(lbfgs_state* st, uint64_t* count);
 /* 16 hex digits: hash of the sources and flags liblbfgs_solver.so was built from (see lbfgs_hip_build_id) */
 const char* lbfgs_solver_build_id(void);
 lbfgs_hip_history* lbfgs_state_history(lbfgs_state* st);

@@ -10,7 +10,7 @@ use std::os::raw::{c_char, c_int, c_void};
 
 /// `LBFGS_HIP_ABI_VERSION` of the `include/lbfgs_hip.h` these declarations mirror; `Context::new` refuses a library
 /// that reports another one (struct layouts are shared by value).
-pub const LBFGS_HIP_ABI_VERSION: i32 = 2;
+pub const LBFGS_HIP_ABI_VERSION: i32 = 3;
 pub const LBFGS_HIP_OK: c_int = 0;
 pub const LBFGS_ERR_EVALUATE: c_int = -1;
 pub const LBFGS_PANIC_OWLQN_RANGE: c_int = -20;
@@ -144,6 +144,30 @@ pub struct lbfgs_report {
     pub neval: u64,
 }
 
+/// `lbfgs_hip_comm_info` (include/lbfgs_hip.h): what the communicator spans and what its exchanges cost.
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct lbfgs_hip_comm_info {
+    pub kind: i32,
+    pub world: i32,
+    pub rank: i32,
+    pub ranks_seen: i32,
+    pub rank_seen: i32,
+    pub mailbox_placement: i32,
+    pub peers_device: i32,
+    pub peers_host: i32,
+    pub exclusive_device: i32,
+    pub _pad: i32,
+    pub two_loops: u64,
+    pub two_loop_exchanges: u64,
+    pub allreduce_launches: u64,
+    pub p2p_exchanges: u64,
+    pub resident_fallbacks: u64,
+    pub timed_exchanges: [u64; 2],
+    pub exchange_us: [f64; 2],
+    pub local_wait_us: [f64; 2],
+}
+
 extern "C" {
     // ---- include/lbfgs_hip.h: context, vectors, scalar board --------------------------------------
     pub fn lbfgs_hip_abi_version() -> c_int;
@@ -171,6 +195,7 @@ extern "C" {
     pub fn lbfgs_hip_vecdiff(z: *mut lbfgs_hip_vec, x: *const lbfgs_hip_vec, y: *const lbfgs_hip_vec) -> c_int;
     pub fn lbfgs_hip_vec2norm_sq(x: *const lbfgs_hip_vec, out_slot: c_int) -> c_int;
     pub fn lbfgs_hip_path_stats(ctx: *mut lbfgs_hip_ctx, resident_two_loops: *mut u64, resident_elements: *mut u64) -> c_int;
+    pub fn lbfgs_hip_ctx_comm_info(ctx: *mut lbfgs_hip_ctx, out: *mut lbfgs_hip_comm_info) -> c_int;
     pub fn lbfgs_hip_vec2norm(x: *const lbfgs_hip_vec, scratch_slot: c_int, out: *mut f64) -> c_int;
     pub fn lbfgs_hip_vec2norminv(x: *const lbfgs_hip_vec, scratch_slot: c_int, out: *mut f64) -> c_int;
     // ---- fused hot path ------------------------------------------------------------------------

@@ -24,7 +24,7 @@ LS_MORETHUENTE, LS_BT_ARMIJO, LS_BT_STRONGWOLFE, LS_BT_WOLFE = 0, 1, 2, 3
 EVAL_HOST, EVAL_DEVICE, EVAL_BUILTIN = 0, 1, 2
 COMM_NONE, COMM_RCCL, COMM_CALLBACK, COMM_P2P = 0, 1, 2, 3
 MAILBOX_AUTO, MAILBOX_DEVICE, MAILBOX_HOST = -1, 0, 1
-ABI_VERSION = 2  # LBFGS_HIP_ABI_VERSION of the include/lbfgs_hip.h these declarations were written against
+ABI_VERSION = 3  # LBFGS_HIP_ABI_VERSION of the include/lbfgs_hip.h these declarations were written against
 OBJ_QUADRATIC, OBJ_LOGISTIC, OBJ_ROSENBROCK, OBJ_LJ_ALLPAIRS, OBJ_LJ_NEIGHBORS, OBJ_LJ_CELLS = 1, 2, 3, 4, 5, 6
 (K_TWOLOOP_STEP, K_TWOLOOP_EDGE, K_UPDATE, K_LINE, K_EVAL, K_OWLQN, K_BLAS1, K_COMM, K_TWOLOOP_ALL,
  K_TWOLOOP_RESIDENT) = range(10)
@@ -44,6 +44,16 @@ class Comm(C.Structure):
     _fields_ = [("kind", C.c_int32), ("exclusive_device", C.c_int32), ("rccl_unique_id", C.c_void_p),
                 ("callback", ALLREDUCE_CB), ("callback_user", C.c_void_p),
                 ("p2p_mailbox", C.c_void_p), ("p2p_handles", C.c_void_p), ("p2p_timeout_s", C.c_double)]
+
+
+class CommInfo(C.Structure):
+    """lbfgs_hip_comm_info: what the communicator really spans and what its exchanges cost (lbfgs_hip_ctx_comm_info)."""
+    _fields_ = [("kind", C.c_int32), ("world", C.c_int32), ("rank", C.c_int32), ("ranks_seen", C.c_int32),
+                ("rank_seen", C.c_int32), ("mailbox_placement", C.c_int32), ("peers_device", C.c_int32),
+                ("peers_host", C.c_int32), ("exclusive_device", C.c_int32), ("_pad", C.c_int32),
+                ("two_loops", C.c_uint64), ("two_loop_exchanges", C.c_uint64), ("allreduce_launches", C.c_uint64),
+                ("p2p_exchanges", C.c_uint64), ("resident_fallbacks", C.c_uint64),
+                ("timed_exchanges", C.c_uint64 * 2), ("exchange_us", C.c_double * 2), ("local_wait_us", C.c_double * 2)]
 
 
 class Objective(C.Structure):
@@ -94,6 +104,7 @@ HIP_SYMBOLS = """
 lbfgs_hip_abi_version lbfgs_hip_build_id lbfgs_hip_device_count lbfgs_hip_rccl_unique_id lbfgs_hip_p2p_mailbox_create
 lbfgs_hip_p2p_mailbox_create2 lbfgs_hip_p2p_mailbox_destroy lbfgs_hip_ctx_p2p_seal lbfgs_hip_ctx_create lbfgs_hip_ctx_destroy
 lbfgs_hip_last_error lbfgs_hip_sync lbfgs_hip_stream lbfgs_hip_get_shard lbfgs_hip_set_grid lbfgs_hip_path_stats
+lbfgs_hip_ctx_comm_info
 lbfgs_hip_vec_alloc lbfgs_hip_vec_free lbfgs_hip_vec_upload lbfgs_hip_vec_download lbfgs_hip_vec_fill
 lbfgs_hip_vec_ptr lbfgs_hip_vec_swap
 lbfgs_hip_scalars_read lbfgs_hip_scalars_write lbfgs_hip_scalars_ptr lbfgs_hip_scalars_allreduce
@@ -116,7 +127,7 @@ lbfgs_hip_prof_enable lbfgs_hip_prof_reset lbfgs_hip_prof_read
 SOLVER_SYMBOLS = """
 lbfgs_param_default lbfgs_build lbfgs_is_converged lbfgs_propagate lbfgs_get_report lbfgs_state_free
 lbfgs_state_error lbfgs_state_ls_error lbfgs_line_search lbfgs_state_download lbfgs_state_devptr lbfgs_state_info
-lbfgs_state_history lbfgs_state_vec lbfgs_minimize lbfgs_solver_build_id
+lbfgs_state_history lbfgs_state_vec lbfgs_minimize lbfgs_solver_build_id lbfgs_state_vector_free_fallbacks
 lbfgs_problem_new lbfgs_problem_evaluate lbfgs_problem_update_search_direction lbfgs_problem_dginit
 lbfgs_problem_dg_unchecked lbfgs_problem_save_state lbfgs_problem_revert lbfgs_problem_take_line_step
 lbfgs_problem_update_orthant_new_point lbfgs_problem_constrain_search_direction lbfgs_problem_norms
@@ -145,6 +156,7 @@ def declare(L):
         "lbfgs_hip_get_shard": (i, [vp, C.POINTER(Shard)]),
         "lbfgs_hip_set_grid": (i, [vp, i]),
         "lbfgs_hip_path_stats": (i, [vp, C.POINTER(u64), C.POINTER(u64)]),
+        "lbfgs_hip_ctx_comm_info": (i, [vp, C.POINTER(CommInfo)]),
         "lbfgs_hip_vec_alloc": (i, [vp, C.POINTER(vp)]),
         "lbfgs_hip_vec_free": (None, [vp]),
         "lbfgs_hip_vec_upload": (i, [vp, dp, u64]),
@@ -211,6 +223,7 @@ def declare(L):
         "lbfgs_state_download": (i, [vp, i, dp]),
         "lbfgs_state_devptr": (vp, [vp, i]),
         "lbfgs_state_info": (i, [vp, C.POINTER(u64), C.POINTER(u64), dp, dp]),
+        "lbfgs_state_vector_free_fallbacks": (i, [vp, C.POINTER(u64)]),
         "lbfgs_state_history": (vp, [vp]),
         "lbfgs_state_vec": (vp, [vp, i]),
         "lbfgs_problem_new": (i, [C.POINTER(vp), vp, C.POINTER(Param), dp, C.POINTER(Evaluator)]),
@@ -296,10 +309,29 @@ def load():
     _one_hip_runtime()
     # liblbfgs_solver.so names liblbfgs_hip.so as a dependency (rpath $ORIGIN); RTLD_LOCAL keeps the
     # lbfgs_hip_* symbols out of the global namespace
-    lib = declare(C.CDLL(solver, mode=C.RTLD_LOCAL))
-    got = lib.lbfgs_hip_abi_version()
+    raw = C.CDLL(solver, mode=C.RTLD_LOCAL)
+    # the ABI version FIRST, through a declaration of its own: an older library lacks symbols declare() asks for, and
+    # "rebuild" is a better answer than an AttributeError about one of them
+    try:
+        raw.lbfgs_hip_abi_version.restype = C.c_int
+        raw.lbfgs_hip_abi_version.argtypes = []
+        got = raw.lbfgs_hip_abi_version()
+    except AttributeError:
+        got = None
     if got != ABI_VERSION:  # struct layouts are shared by value: never talk to a library with another one
         raise ImportError(f"{hip} has ABI version {got}, this package was written against {ABI_VERSION}: rebuild "
                           "(python -c 'import rust_lbfgs_amd as r; r.build()')")
+    lib = declare(raw)
+    if os.path.realpath(libdir) == os.path.realpath(HERE) and os.environ.get("LBFGS_HIP_ALLOW_STALE") != "1":
+        # In-tree libraries must belong to the checked-out sources (builds are content-addressed: _build.py).  A library of
+        # the same ABI built from other sources -- older kernels -- is refused, not trusted; prebuilt libraries somewhere
+        # else (LBFGS_HIP_LIB_DIR: deployments, A/B builds) carry whatever id they were built with and are taken as they are.
+        from . import _build
+
+        have = (lib.lbfgs_hip_build_id().decode(), lib.lbfgs_solver_build_id().decode())
+        want = (_build.hip_build_id(), _build.solver_build_id())
+        if have != want:
+            raise ImportError(f"{hip} / {solver} carry build ids {have}, the checked-out sources hash to {want}: rebuild "
+                              "(python -c 'import rust_lbfgs_amd as r; r.build()'), or set LBFGS_HIP_ALLOW_STALE=1 to load them anyway")
     _LIB = lib
     return _LIB

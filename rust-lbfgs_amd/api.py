@@ -128,6 +128,22 @@ class Context:
         self.check(self._L.lbfgs_hip_path_stats(self._h, None, C.byref(e)))
         return e.value
 
+    def comm_info(self):
+        """lbfgs_hip_ctx_comm_info as a dict: what the communicator really spans (`ranks_seen`: RCCL's own ncclCommCount, or
+        the P2P mailboxes this rank mapped) and what its exchanges cost, measured on the device (class 0 = outside a
+        two-loop, 1 = inside one).  Synchronises the stream."""
+        ci = _ffi.CommInfo()
+        self.check(self._L.lbfgs_hip_ctx_comm_info(self._h, C.byref(ci)))
+        out = {k: getattr(ci, k) for k, _ in _ffi.CommInfo._fields_ if not k.startswith("_") and k not in (
+            "timed_exchanges", "exchange_us", "local_wait_us")}
+        out["kind"] = {_ffi.COMM_NONE: "none", _ffi.COMM_RCCL: "rccl", _ffi.COMM_CALLBACK: "callback", _ffi.COMM_P2P: "p2p"}.get(ci.kind, ci.kind)
+        out["mailbox_placement"] = {_ffi.MAILBOX_DEVICE: "device", _ffi.MAILBOX_HOST: "host"}.get(ci.mailbox_placement)
+        if ci.kind == _ffi.COMM_CALLBACK:
+            out["ranks_seen"] = None  # (the all-reduce is the caller's: the library sees no peer itself)
+        for k in ("timed_exchanges", "exchange_us", "local_wait_us"):
+            out[k] = {"other": getattr(ci, k)[0], "two_loop": getattr(ci, k)[1]}
+        return out
+
     def set_grid(self, blocks):
         self.check(self._L.lbfgs_hip_set_grid(self._h, blocks))
 
@@ -381,6 +397,13 @@ class LbfgsState:
         s, g = C.c_double(), C.c_double()
         self._check(self._L.lbfgs_state_info(self._h, C.byref(k), C.byref(e), C.byref(s), C.byref(g)))
         return dict(k=k.value, end=e.value, step=s.value, gamma=g.value)
+
+    def vector_free_fallbacks(self):
+        """EXTENSION (with_vector_free): iterations so far whose coefficient-space direction failed its run-time ||d||^2 check
+        and was formed again by the exact recursion."""
+        c = C.c_uint64()
+        self._check(self._L.lbfgs_state_vector_free_fallbacks(self._h, C.byref(c)))
+        return c.value
 
     def history_scalars(self):
         ys, al = np.zeros(self.m), np.zeros(self.m)

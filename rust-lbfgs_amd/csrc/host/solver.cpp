@@ -186,6 +186,7 @@ struct lbfgs_state {
     uint64_t k = 0;
     uint64_t ncall = 0;
     double last_gamma = 0.0;
+    uint64_t vector_free_fallbacks = 0;  // iterations whose vector-free direction failed its ||d||^2 check and was redone exactly
     double dginit_next = 0.0;  // g.d of the direction just built (fused into the two-loop's last kernel)
     bool dginit_valid = false;
     // deferred trial points (lbfgs_hip_objective_line_probe): trials of the running search leave x/gx unwritten;
@@ -870,10 +871,26 @@ int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
     }
     int new_end = st->end;
     bool projected = false;  // constrain_search_direction already applied by the two-loop's last step?
-    if (st->vars.vector_free)
+    bool exact = !st->vars.vector_free;
+    if (st->vars.vector_free) {
+        // EXTENSION: the recursion in coefficient space.  Its arithmetic works on Gram entries -- sums over whole vectors --
+        // and loses the digits the recursion needs when a run blows up or has converged to rounding level; nothing in the
+        // direction itself shows that.  The guard: the coefficient kernel predicts ||d||^2 = delta^T G delta from the same
+        // Gram entries, the combine pass sums the real ||d||^2; when the two differ by more than 1e-8 (or a coefficient is not
+        // finite) the coefficient-space arithmetic is not to be trusted and THIS iteration's direction is formed again by the
+        // exact recursion (lbfgs.rs:569-604).  The read below waits for the combine kernel the next read would wait for anyway.
         TRYB(st, lbfgs_hip_two_loop_gram(st->hist, st->d_next, st->grad_for_direction(), st->k - 1, st->end, S_UPD + 1,
                                          S_UPD + 2, S_DNORM2, &new_end));
-    else if (st->owlqn()) {  // :554 folded into the last step (it streams pg anyway); slots S_DNORM2C follow S_DNORM2
+        double chk[3] = {0.0, 0.0, 0.0};
+        TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_DNORM2, 3, chk));
+        const double dn2 = chk[0], pred = chk[2];
+        if (!(std::fabs(pred - dn2) <= 1e-8 * std::fabs(dn2))) {  // (NaN on either side: not trusted)
+            st->vector_free_fallbacks += 1;
+            exact = true;
+        }
+    }
+    if (!exact) {
+    } else if (st->owlqn()) {  // :554 folded into the last step (it streams pg anyway); slots S_DNORM2C follow S_DNORM2
         static_assert(S_DNORM2C == S_DNORM2 + 2, "two_loop_owlqn writes 4 adjacent slots");
         TRYB(st, lbfgs_hip_two_loop_owlqn(st->hist, st->d_next, st->pg, st->k - 1, st->end, S_UPD + 1, S_UPD + 2, S_DNORM2,
                                           st->owl_start, st->owl_end, &new_end));
@@ -955,6 +972,12 @@ lbfgs_hip_vec* lbfgs_state_vec(lbfgs_state* st, int which) { return st ? pick(st
 void* lbfgs_state_devptr(lbfgs_state* st, int which) {
     lbfgs_hip_vec* v = st ? pick(st, which) : nullptr;
     return v ? lbfgs_hip_vec_ptr(v) : nullptr;
+}
+
+int lbfgs_state_vector_free_fallbacks(lbfgs_state* st, uint64_t* count) {
+    if (!st || !count) return LBFGS_ERR_PARAM;
+    *count = st->vector_free_fallbacks;
+    return LBFGS_OK;
 }
 
 int lbfgs_state_info(lbfgs_state* st, uint64_t* k, uint64_t* end, double* step, double* gamma) {

@@ -49,6 +49,8 @@ struct Rccl {
     int (*GetUniqueId)(nccl_unique_id_t*) = nullptr;
     int (*CommInitRank)(nccl_comm_t*, int, nccl_unique_id_t, int) = nullptr;
     int (*CommDestroy)(nccl_comm_t) = nullptr;
+    int (*CommCount)(const nccl_comm_t, int*) = nullptr;     // what RCCL itself says the communicator spans ...
+    int (*CommUserRank)(const nccl_comm_t, int*) = nullptr;  // ... and who this process is in it
     int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
@@ -78,6 +80,8 @@ bool rccl_load(std::string* err) {
     LH_SYM(GetUniqueId, "ncclGetUniqueId")
     LH_SYM(CommInitRank, "ncclCommInitRank")
     LH_SYM(CommDestroy, "ncclCommDestroy")
+    LH_SYM(CommCount, "ncclCommCount")
+    LH_SYM(CommUserRank, "ncclCommUserRank")
     LH_SYM(AllReduce, "ncclAllReduce")
     LH_SYM(GroupStart, "ncclGroupStart")
     LH_SYM(GroupEnd, "ncclGroupEnd")
@@ -215,6 +219,7 @@ struct P2PArgs {
     DevCounters* ctr;
     double* val[MAX_RED];
     int count;
+    unsigned int xchg_class;
 };
 
 __global__ __launch_bounds__(64) void p2p_allreduce_kernel(const P2PArgs a) {
@@ -223,9 +228,21 @@ __global__ __launch_bounds__(64) void p2p_allreduce_kernel(const P2PArgs a) {
     if ((int)threadIdx.x < a.count) vals[threadIdx.x] = *a.val[threadIdx.x];
     __syncthreads();
     const unsigned int epoch = a.ctr->p2p_epoch;
+    DevXchg* const xs = dev_xchg(a.ctr, a.xchg_class);
+    DevXchg x{};
+    long long t1 = 0;
+    if (threadIdx.x == 0) {
+        x = *xs;
+        t1 = wall_clock64();
+    }
     p2p_exchange(a.ctl, epoch, vals, a.count, bits);
     if ((int)threadIdx.x < a.count) *a.val[threadIdx.x] = vals[threadIdx.x];
-    if (threadIdx.x == 0) a.ctr->p2p_epoch = next_epoch(epoch);
+    if (threadIdx.x == 0) {
+        a.ctr->p2p_epoch = next_epoch(epoch);
+        x.p2p_ticks += (unsigned long long)(wall_clock64() - t1);
+        x.count += 1ull;
+        *xs = x;
+    }
 }
 
 // ------------------------------------------------------------------------------------ objects
@@ -276,6 +293,12 @@ struct lbfgs_hip_ctx {
     lbfgs_hip_shard shard{};
     int comm_kind = LBFGS_HIP_COMM_NONE;
     nccl_comm_t nccl = nullptr;
+    int rccl_ranks_seen = 0, rccl_rank_seen = -1;   // ncclCommCount / ncclCommUserRank of `nccl` (checked against the shard)
+    int p2p_peers_device = 0, p2p_peers_host = 0;    // peers' mailboxes mapped at context creation, by placement
+    unsigned long long two_loop_calls = 0;           // two-loop recursions enqueued (any form) ...
+    unsigned long long two_loop_exchanges = 0;       // ... and the cross-rank exchanges enqueued inside them (world > 1)
+    unsigned long long allreduce_calls = 0;          // stand-alone all-reduces enqueued (RCCL / callback / P2P kernel)
+    int xchg_class = 0;                              // 1 while a two-loop recursion is being enqueued (RedCtl::xchg_class)
     lbfgs_hip_allreduce_cb cb = nullptr;
     void* cb_user = nullptr;
     // P2P communicator
@@ -285,6 +308,12 @@ struct lbfgs_hip_ctx {
     unsigned int* p2p_err = nullptr;      // device error flag: 1 = a P2P spin timed out, 2 = a workgroup's partials never arrived
     unsigned long long p2p_timeout_ticks = 0;
     unsigned long long handoff_timeout_ticks = 1000000000ULL;  // bound on every cross-workgroup spin (wall_clock64: 100 MHz)
+    // ... except in a context's FIRST resident launches: until one of them has been seen to complete, a hand-off waits 50 ms
+    // at most (LBFGS_HIP_RESIDENT_FIRST_TIMEOUT_MS), so that a device which cannot hold the grid resident -- partitioned, shared
+    // with another resident kernel, CU-masked in a way the probes miss -- costs milliseconds, not the full timeout, before the
+    // kernel-per-step path takes over (lbfgs_hip_scalars_read)
+    unsigned long long first_timeout_ticks = 5000000ULL;
+    bool resident_proven = false;
     double* board = nullptr;         // LBFGS_HIP_BOARD_SLOTS doubles + 2 ping-pong dots
     double* partials = nullptr;      // MAX_RED * MAX_GRID
     unsigned int* ticket = nullptr;
@@ -300,6 +329,7 @@ struct lbfgs_hip_ctx {
     size_t resident_nt_bytes = (size_t)16 << 20;  // LBFGS_HIP_RESIDENT_NT_MB
     size_t resident_plain_bytes = (size_t)256 << 20;  // LBFGS_HIP_RESIDENT_PLAIN_MB: hybrid: so much of the HBM part of q keeps the default
                                           // cache policy and stays in the 256 MiB Infinity Cache between steps (resident.h res_hbm_rounds)
+    int resident_touch = -1;              // LBFGS_HIP_RESIDENT_TOUCH: rounds a waiting workgroup touches ahead (resident.h TOUCHING; -1 = by shard size)
     int resident_hybrid = 1;              // LBFGS_HIP_RESIDENT_HYBRID=0: shards that do not fit the chip take the kernel-per-step path
     uint64_t resident_elements = 0;       // elements of q the last resident launch kept on the chip (all of them unless hybrid)
     int resident_grid = 0;                // LBFGS_HIP_RESIDENT_GRID: workgroups of the resident kernel (0 = one per CU); tests
@@ -319,7 +349,7 @@ struct lbfgs_hip_ctx {
         bool owl = false;
     } last_res;
     unsigned long long resident_fallbacks = 0;  // how often that happened
-    int resident_fault = 0;               // LBFGS_HIP_RESIDENT_FAULT=1 (tests): the next resident launch loses its last workgroup
+    int resident_fault = 0;               // LBFGS_HIP_RESIDENT_FAULT=k (tests): the k-th resident launch of this context loses its last workgroup
     bool defer_inner_sums = true;         // LBFGS_HIP_DEFER_SUMS=0: the two-loop's inner dots are reduced by their own kernels (A/B)
     double* dot_parts = nullptr;          // 2 x MAX_GRID: workgroup partials of the two-loop's inner dot products (ping-pong)
     DevCounters* dev_ctr = nullptr;       // device-resident sequence numbers (stream.h); the three fields below shadow them
@@ -377,6 +407,7 @@ struct lbfgs_hip_history {
     double* gram = nullptr;        // (2m+1)^2
     double* gram_rows = nullptr;   // 3*(2m+1), contiguous (one all-reduce message)
     double* gram_delta = nullptr;  // 2m+1
+    double* gram_pred = nullptr;   // 1: ||d||^2 predicted by the coefficient-space arithmetic (gram_coef_kernel)
 };
 
 namespace {
@@ -442,6 +473,7 @@ int fill_handoff(lbfgs_hip_ctx* ctx, RedCtl& red, int nred) {
     red.gran = ctx->gran;
     red.err = ctx->p2p_err;
     red.timeout_ticks = ctx->handoff_timeout_ticks;  // (10 s of the 100 MHz wall clock unless LBFGS_HIP_HANDOFF_TIMEOUT_MS says otherwise)
+    red.xchg_class = (unsigned int)ctx->xchg_class;
     red.ctr = ctx->dev_ctr;
     red.tagged = (ctx->handoff_ticket || nred > RED_PTRS) ? 0u : 1u;
     if (red.tagged) {
@@ -463,6 +495,7 @@ P2PCtl next_p2p(lbfgs_hip_ctx* ctx) {
     c.world = ctx->shard.world;
     c.rank = ctx->shard.rank;
     ctx->p2p_count += 1;
+    if (ctx->xchg_class) ctx->two_loop_exchanges += 1;
     c.err = ctx->p2p_err;
     c.timeout_ticks = ctx->p2p_timeout_ticks;
     return c;
@@ -477,6 +510,8 @@ int allreduce(lbfgs_hip_ctx* ctx, double* const* ptrs, int count) {
         if (idx >= 0 && idx < LBFGS_HIP_BOARD_SLOTS + 2) ctx->mirror_valid[idx] = false;
     }
     ProfScope ps(ctx, LBFGS_HIP_K_COMM);
+    ctx->allreduce_calls += 1;
+    if (ctx->xchg_class && ctx->comm_kind != LBFGS_HIP_COMM_P2P) ctx->two_loop_exchanges += 1;  // (P2P: next_p2p counts)
     if (ctx->comm_kind == LBFGS_HIP_COMM_RCCL) {
         // coalesce runs of consecutive addresses into one message each; group them into one launch
         int rc = g_rccl.GroupStart();
@@ -502,6 +537,7 @@ int allreduce(lbfgs_hip_ctx* ctx, double* const* ptrs, int count) {
         a.ctr = ctx->dev_ctr;
         for (int i = 0; i < count; ++i) a.val[i] = ptrs[i];
         a.count = count;
+        a.xchg_class = (unsigned int)ctx->xchg_class;
         hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(1), dim3(64), 0, ctx->stream, a);
         HIP_TRY(ctx, hipGetLastError());
         return LBFGS_HIP_OK;
@@ -631,6 +667,9 @@ struct GramArgs {
     double* G;             // nb x nb, basis order [s_0..s_{m-1}, y_0..y_{m-1}, g]
     const double* rows;    // 3 x nb in POSITION order of the rows kernel
     double* delta;         // nb coefficients out (basis order)
+    double* pred;          // out: ||d||^2 = delta^T G delta as the GRAM arithmetic sees it (NaN if a coefficient is not finite):
+                           // the combine pass sums the real ||d||^2; a mismatch says the coefficient-space recursion has lost its
+                           // digits (lbfgs_hip_two_loop_gram, board[dnorm_slot + 2])
     double* alpha;         // history alpha[m] (kept for API parity, lbfgs.rs:587)
     const double* ys;      // history ys[m]: the STORED y.s (lbfgs.rs:656) -- under Powell damping it is the
                            // pre-damping value and differs from the Gram entry of the damped y
@@ -680,6 +719,15 @@ __global__ __launch_bounds__(64) void gram_coef_kernel(const GramArgs a) {
         }
         for (int t = 0; t < nb; ++t) a.delta[t] = delta[t];
         for (int it = 0; it < a.bound; ++it) a.alpha[a.order[it]] = alpha[a.order[it]];
+        double dd = 0.0;  // delta^T G delta, row by row
+        bool finite = true;
+        for (int i = 0; i < nb; ++i) {
+            double row = 0.0;
+            for (int t = 0; t < nb; ++t) row += G[i * nb + t] * delta[t];
+            dd += delta[i] * row;
+            finite = finite && (delta[i] - delta[i] == 0.0);
+        }
+        *a.pred = finite ? dd : __longlong_as_double(0x7ff8000000000000LL);
     }
 }
 
@@ -1038,7 +1086,8 @@ bool gram_rows_resident(lbfgs_hip_ctx* ctx, const double* const* in, int nb, con
 }
 
 // -> 1 launched, 0 not eligible (the caller streams all columns at once), < 0 error.  dn: ||d||^2, g.d
-int gram_combine_resident(lbfgs_hip_ctx* ctx, const double* const* cols, int nb, double* d, const double* delta, double* dn) {
+int gram_combine_resident(lbfgs_hip_ctx* ctx, const double* const* cols, int nb, double* d, const double* delta, const double* pred,
+                          double* dn) {
     if (!ctx->resident_on || !ctx->gram_combine_resident || ctx->handoff_ticket || ctx->capturing || ctx->grid_override > 0 ||
         nb > GC_MAX_COLS)
         return 0;
@@ -1065,12 +1114,14 @@ int gram_combine_resident(lbfgs_hip_ctx* ctx, const double* const* cols, int nb,
     GramCombArgs a{};
     for (int j = 0; j < nb; ++j) a.in[j] = cols[j];
     a.d = d; a.delta = delta; a.n = n; a.nb = nb;
+    a.pred = pred;
+    a.lead = ctx->shard.offset == 0 ? 1 : 0;  // (the rank that owns element 0 carries the prediction into the third sum)
     a.total_rounds = (uint32_t)total;
     a.tile_rounds = (uint32_t)tile;
     RedCtl red{};
     bool in_kernel_exchange = false;
-    double* outs2[2] = {dn, dn + 1};
-    const int rc_p = prep_red(ctx, red, 2, outs2, nullptr, 0, &in_kernel_exchange);
+    double* outs2[3] = {dn, dn + 1, dn + 2};
+    const int rc_p = prep_red(ctx, red, 3, outs2, nullptr, 0, &in_kernel_exchange);
     if (rc_p != LBFGS_HIP_OK) return rc_p;
     {
         ProfScope ps(ctx, LBFGS_HIP_K_TWOLOOP_STEP);
@@ -1078,7 +1129,7 @@ int gram_combine_resident(lbfgs_hip_ctx* ctx, const double* const* cols, int nb,
     }
     HIP_TRY(ctx, hipGetLastError());
     if (!in_kernel_exchange) {
-        const int rc = allreduce(ctx, outs2, 2);
+        const int rc = allreduce(ctx, outs2, 3);
         if (rc != LBFGS_HIP_OK) return rc;
     }
     return 1;
@@ -1127,7 +1178,7 @@ int two_loop_gram_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
         if (rc != LBFGS_HIP_OK) return rc;
     }
     // scalar recursion on the coefficients
-    ga.G = h->gram; ga.rows = h->gram_rows; ga.delta = h->gram_delta; ga.alpha = h->alpha; ga.ys = h->ys;
+    ga.G = h->gram; ga.rows = h->gram_rows; ga.delta = h->gram_delta; ga.pred = h->gram_pred; ga.alpha = h->alpha; ga.ys = h->ys;
     ga.gnum = gnum; ga.gden = gden; ga.m = M; ga.bound = bound;
     ga.row_basis[0] = end; ga.row_basis[1] = M + end; ga.row_basis[2] = 2 * M;
     for (int i = 0; i < bound; ++i) ga.order[i] = ((e1 - 1 - i) % M + M) % M;
@@ -1142,7 +1193,7 @@ int two_loop_gram_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
         const double* cols[2 * M + 1];
         for (int b = 0; b < M; ++b) { cols[b] = h->s[b]->p; cols[M + b] = h->y[b]->p; }
         cols[2 * M] = g->p;
-        const int rr = gram_combine_resident(ctx, cols, 2 * M + 1, d->p, h->gram_delta, dn);
+        const int rr = gram_combine_resident(ctx, cols, 2 * M + 1, d->p, h->gram_delta, h->gram_pred, dn);
         if (rr != 0) return rr < 0 ? rr : LBFGS_HIP_OK;
     }
     OpGramCombine<M> cmb{};
@@ -1150,7 +1201,8 @@ int two_loop_gram_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_v
     cmb.in[2 * M] = g->p;
     cmb.out[0] = d->p;
     cmb.delta = h->gram_delta;
-    double* outs2[2] = {dn, dn + 1};
+    cmb.pred = h->gram_pred;
+    double* outs2[3] = {dn, dn + 1, dn + 2};
     return launch(ctx, LBFGS_HIP_K_TWOLOOP_STEP, cmb, outs2);
 }
 }  // namespace
@@ -1210,9 +1262,9 @@ int lbfgs_hip_p2p_mailbox_create2(int device, int placement, void** mailbox_out,
     const size_t bytes = P2P_MBOX_WORDS * sizeof(unsigned long long);
     if (placement == LBFGS_HIP_MAILBOX_HOST) {
         if (e != hipSuccess) return fail(nullptr, LBFGS_HIP_ERR_COMM, "P2P mailbox: %s", hipGetErrorString(e));
-        static unsigned int serial = 0;
+        static std::atomic<unsigned int> serial{0};
         char name[48];
-        snprintf(name, sizeof(name), "/lbfgs_hip_mbox_%ld_%u_%08x", (long)getpid(), serial++, (unsigned int)std::chrono::steady_clock::now().time_since_epoch().count());
+        snprintf(name, sizeof(name), "/lbfgs_hip_mbox_%ld_%u_%08x", (long)getpid(), serial.fetch_add(1), (unsigned int)std::chrono::steady_clock::now().time_since_epoch().count());
         std::string err;
         void* dev = host_mbox_map(name, bytes, true, &err);
         if (!dev) return fail(nullptr, LBFGS_HIP_ERR_COMM, "P2P mailbox (host placement): %s", err.c_str());
@@ -1333,8 +1385,10 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     if (const char* e = getenv("LBFGS_HIP_GRAM_COMBINE_RESIDENT")) ctx->gram_combine_resident = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_LJ_BUILD_FP32")) ctx->lj_build_fp32 = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_HANDOFF_TIMEOUT_MS")) ctx->handoff_timeout_ticks = (unsigned long long)std::max(1, atoi(e)) * 100000ULL;
+    if (const char* e = getenv("LBFGS_HIP_RESIDENT_FIRST_TIMEOUT_MS")) ctx->first_timeout_ticks = (unsigned long long)std::max(1, atoi(e)) * 100000ULL;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_NT_MB")) ctx->resident_nt_bytes = (size_t)std::max(0, atoi(e)) << 20;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_HYBRID")) ctx->resident_hybrid = atoi(e) != 0;
+    if (const char* e = getenv("LBFGS_HIP_RESIDENT_TOUCH")) ctx->resident_touch = std::min(LH_RES_TOUCH, std::max(-1, atoi(e)));
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_PLAIN_MB")) ctx->resident_plain_bytes = (size_t)std::max(0, atoi(e)) << 20;
     if (const char* e = getenv("LBFGS_HIP_GRAPH")) ctx->graph_max_bytes = atoi(e) ? ~(size_t)0 : 0;
     if (const char* e = getenv("LBFGS_HIP_GRAPH_MAX_MB")) ctx->graph_max_bytes = (size_t)atoll(e) << 20;
@@ -1395,6 +1449,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
         ctx->red_count = (unsigned long long)epoch0 - 1ull;  // (the next tagged launch uses tag red_count % (2^32-1) + 1 = epoch0)
         const DevCounters init{epoch0, 1u, 0ull};
         CTX_TRY(hipMalloc(&ctx->dev_ctr, 4096));  // (a page of its own: nothing else shares its cache lines)
+        CTX_TRY(hipMemset(ctx->dev_ctr, 0, 4096));  // (the DevXchg records behind the counters start at zero)
         CTX_TRY(hipMemcpy(ctx->dev_ctr, &init, sizeof(init), hipMemcpyHostToDevice));
     }
     CTX_TRY(hipMalloc(&ctx->dot_parts, 2 * (size_t)MAX_GRID * sizeof(double)));
@@ -1438,6 +1493,18 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
             lbfgs_hip_ctx_destroy(ctx);
             return r;
         }
+        // what RCCL itself reports must be the shard this context was given (a communicator that spans fewer ranks than the
+        // vector is sharded over would silently produce partial sums)
+        int cnt = 0, urank = -1;
+        const int rc1 = g_rccl.CommCount(ctx->nccl, &cnt), rc2 = g_rccl.CommUserRank(ctx->nccl, &urank);
+        if (rc1 != 0 || rc2 != 0 || cnt != ctx->shard.world || urank != ctx->shard.rank) {
+            int r = fail(nullptr, LBFGS_HIP_ERR_COMM, "the RCCL communicator reports %d ranks / rank %d (status %d, %d), the shard says %d / %d",
+                         cnt, urank, rc1, rc2, ctx->shard.world, ctx->shard.rank);
+            lbfgs_hip_ctx_destroy(ctx);
+            return r;
+        }
+        ctx->rccl_ranks_seen = cnt;
+        ctx->rccl_rank_seen = urank;
         ctx->comm_kind = LBFGS_HIP_COMM_RCCL;
     } else if (kind == LBFGS_HIP_COMM_P2P) {
         const int W = ctx->shard.world, me = ctx->shard.rank;
@@ -1461,12 +1528,14 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
                     return rc;
                 }
                 ctx->p2p_mbox[r] = (unsigned long long*)p;  // (released through the registry: p2p_opened stays false)
+                ctx->p2p_peers_host += 1;
                 continue;
             }
             hipIpcMemHandle_t hdl;
             memcpy(&hdl, hraw, sizeof(hdl));
             // (LBFGS_HIP_TEST_FAIL_IPC_OPEN=1: tests of the host-placement fallback pretend the mapping is refused)
-            hipError_t e = getenv("LBFGS_HIP_TEST_FAIL_IPC_OPEN") ? hipErrorInvalidValue : ipc_open_cached(hdl, &p);
+            const char* fail_hook = getenv("LBFGS_HIP_TEST_FAIL_IPC_OPEN");
+            hipError_t e = (fail_hook && atoi(fail_hook) != 0) ? hipErrorInvalidValue : ipc_open_cached(hdl, &p);
             if (e != hipSuccess) {
                 int rc = fail(nullptr, LBFGS_HIP_ERR_COMM, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
                 lbfgs_hip_ctx_destroy(ctx);
@@ -1474,6 +1543,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
             }
             ctx->p2p_mbox[r] = (unsigned long long*)p;
             ctx->p2p_opened[r] = true;
+            ctx->p2p_peers_device += 1;
         }
         const double tmo = comm->p2p_timeout_s > 0 ? comm->p2p_timeout_s : 5.0;
         ctx->p2p_timeout_ticks = (unsigned long long)(tmo * 1e8);  // wall_clock64 runs at 100 MHz
@@ -1555,10 +1625,11 @@ int lbfgs_hip_ctx_p2p_seal(lbfgs_hip_ctx* ctx, int* placement_out) {
 
 const char* lbfgs_hip_last_error(const lbfgs_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+static int settle(lbfgs_hip_ctx* ctx);  // (below, with the board: waits for the stream and looks at the device error word)
+
 int lbfgs_hip_sync(lbfgs_hip_ctx* ctx) {
     if (!ctx) return LBFGS_HIP_ERR_ARG;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return LBFGS_HIP_OK;
+    return settle(ctx);
 }
 
 void* lbfgs_hip_stream(lbfgs_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
@@ -1573,6 +1644,51 @@ int lbfgs_hip_path_stats(lbfgs_hip_ctx* ctx, uint64_t* resident_two_loops, uint6
     if (!ctx) return LBFGS_HIP_ERR_ARG;
     if (resident_two_loops) *resident_two_loops = ctx->resident_launches;
     if (resident_elements) *resident_elements = ctx->resident_elements;
+    return LBFGS_HIP_OK;
+}
+
+int lbfgs_hip_ctx_comm_info(lbfgs_hip_ctx* ctx, lbfgs_hip_comm_info* out) {
+    if (!ctx || !out) return LBFGS_HIP_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    out->kind = ctx->comm_kind;
+    out->world = ctx->shard.world;
+    out->rank = ctx->shard.rank;
+    out->mailbox_placement = -1;
+    out->exclusive_device = ctx->p2p_exclusive ? 1 : 0;
+    switch (ctx->comm_kind) {
+        case LBFGS_HIP_COMM_RCCL:  // what ncclCommCount / ncclCommUserRank answered when the context was made
+            out->ranks_seen = ctx->rccl_ranks_seen;
+            out->rank_seen = ctx->rccl_rank_seen;
+            break;
+        case LBFGS_HIP_COMM_P2P: {  // mailboxes this rank can reach: its own + every peer's it mapped
+            out->ranks_seen = 1 + ctx->p2p_peers_device + ctx->p2p_peers_host;
+            out->rank_seen = ctx->shard.rank;
+            out->peers_device = ctx->p2p_peers_device;
+            out->peers_host = ctx->p2p_peers_host;
+            std::lock_guard<std::mutex> lk(g_host_mbox_mu);
+            out->mailbox_placement = g_host_mbox.count(ctx->p2p_mbox[ctx->shard.rank]) ? LBFGS_HIP_MAILBOX_HOST : LBFGS_HIP_MAILBOX_DEVICE;
+            break;
+        }
+        default:  // none / callback: the library sees no peer itself
+            out->ranks_seen = ctx->comm_kind == LBFGS_HIP_COMM_NONE ? 1 : 0;
+            out->rank_seen = ctx->shard.rank;
+            break;
+    }
+    out->two_loops = ctx->two_loop_calls;
+    out->two_loop_exchanges = ctx->two_loop_exchanges;
+    out->allreduce_launches = ctx->allreduce_calls;
+    out->p2p_exchanges = ctx->p2p_count;
+    out->resident_fallbacks = ctx->resident_fallbacks;
+    // the device's own figures (stream.h DevXchg): waits for the stream
+    DevXchg x[2];
+    const int rc = settle(ctx);
+    if (rc != LBFGS_HIP_OK) return rc;
+    HIP_TRY(ctx, hipMemcpy(x, reinterpret_cast<const char*>(ctx->dev_ctr) + DEV_XCHG_OFFSET, sizeof(x), hipMemcpyDeviceToHost));
+    for (int c = 0; c < 2; ++c) {
+        out->timed_exchanges[c] = x[c].count;
+        out->exchange_us[c] = (double)x[c].p2p_ticks * 0.01;   // wall_clock64 ticks of 10 ns
+        out->local_wait_us[c] = (double)x[c].local_ticks * 0.01;
+    }
     return LBFGS_HIP_OK;
 }
 
@@ -1621,6 +1737,7 @@ int lbfgs_hip_vec_upload(lbfgs_hip_vec* v, const double* host, uint64_t count) {
     if (count != ctx->shard.n_local) return fail(ctx, LBFGS_HIP_ERR_ARG, "upload of %llu elements into a shard of %llu",
                                                  (unsigned long long)count, (unsigned long long)ctx->shard.n_local);
     if (count == 0) return LBFGS_HIP_OK;
+    ctx->last_res.valid = false;  // (an input of the latest resident two-loop may change: it cannot be re-run any more)
     HIP_TRY(ctx, hipMemcpyAsync(v->p, host, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host buffer may be pageable and reused by the caller
     return LBFGS_HIP_OK;
@@ -1632,6 +1749,10 @@ int lbfgs_hip_vec_download(const lbfgs_hip_vec* v, double* host, uint64_t count)
     if (count != ctx->shard.n_local) return fail(ctx, LBFGS_HIP_ERR_ARG, "download of %llu elements from a shard of %llu",
                                                  (unsigned long long)count, (unsigned long long)ctx->shard.n_local);
     if (count == 0) return LBFGS_HIP_OK;
+    // what the stream has produced so far must be sound before it is handed out: a timed-out resident two-loop is re-run with
+    // a kernel per step first (its d is an output the caller may be asking for), any other device error is returned
+    const int rc_s = settle(ctx);
+    if (rc_s != LBFGS_HIP_OK) return rc_s;
     HIP_TRY(ctx, hipMemcpyAsync(host, v->p, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return LBFGS_HIP_OK;
@@ -1697,6 +1818,57 @@ static int scalars_read_once(lbfgs_hip_ctx* ctx, int first, int count, double* h
     return LBFGS_HIP_OK;
 }
 
+// The resident two-loop kernel waited in vain for a workgroup: it was not given every CU it asked for (another
+// kernel-resident process or stream on this GPU, a CU-masked queue, a partitioned device).  Nothing is lost: its inputs are
+// intact (every call that could change them clears last_res).  Clear the error word, never use that kernel again in this
+// context, and run the recursion with a kernel per step.
+static int recover_resident(lbfgs_hip_ctx* ctx) {
+    const lbfgs_hip_ctx::LastResident lr = ctx->last_res;
+    ctx->last_res.valid = false;
+    ctx->resident_ok = 0;
+    ctx->resident_fallbacks += 1;
+    fprintf(stderr, "[lbfgs_hip] warning: the on-chip-resident two-loop kernel timed out waiting for a workgroup (the GPU is "
+                    "shared with another resident kernel, the device is partitioned, or the queue is CU-masked); re-running this "
+                    "two-loop with a kernel per step and staying on that path (LBFGS_HIP_RESIDENT=0 avoids the wait)\n");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->p2p_err, 0, sizeof(unsigned int), ctx->stream));
+    // Workgroups of that launch which only STARTED after workgroup 0 had finished (they were never resident together:
+    // that is what went wrong) read the counters workgroup 0 had already advanced, and published their partial sums
+    // under the tags of launches that are yet to come.  No granule of the aborted launch may survive it.
+    HIP_TRY(ctx, hipMemsetAsync(ctx->gran, 0, (size_t)MAX_RED * MAX_GRID * 2 * sizeof(unsigned long long), ctx->stream));
+    if (ctx->mirror) *reinterpret_cast<volatile unsigned long long*>(ctx->mirror + LBFGS_HIP_BOARD_SLOTS + 3) = 0ull;
+    int ne = 0;
+    return two_loop_eager(lr.h, lr.d, lr.g, lr.k, lr.end, lr.gnum, lr.gden, lr.dn, lr.first, &ne, lr.owl, lr.owl_start, lr.owl_end);
+}
+
+// Every entry point that hands results of the stream to the caller without going through the board comes here first
+// (lbfgs_hip_sync, lbfgs_hip_vec_download, lbfgs_hip_history_scalars_read): wait for the stream, read the device error
+// word, recover from a timed-out resident two-loop (then wait again), return any other error.
+static int settle(lbfgs_hip_ctx* ctx) {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        unsigned int flag = 0;
+        if (ctx->p2p_err) {
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned + LBFGS_HIP_BOARD_SLOTS, ctx->p2p_err, sizeof(unsigned int), hipMemcpyDeviceToHost,
+                                        ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            memcpy(&flag, ctx->pinned + LBFGS_HIP_BOARD_SLOTS, sizeof(flag));
+        } else {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        if (flag == 0u) {
+            if (ctx->last_res.valid) ctx->resident_proven = true;  // (the latest launch was a resident two-loop, and it completed)
+            return LBFGS_HIP_OK;
+        }
+        if (flag == 2u && attempt == 0 && ctx->last_res.valid && ctx->comm_kind == LBFGS_HIP_COMM_NONE) {
+            const int rc = recover_resident(ctx);
+            if (rc != LBFGS_HIP_OK) return rc;
+            continue;
+        }
+        return device_error(ctx, flag);
+    }
+    return LBFGS_HIP_OK;
+}
+
 int lbfgs_hip_scalars_read(lbfgs_hip_ctx* ctx, int first, int count, double* host) {
     if (!ctx || !host || !slot_ok(first, count)) return LBFGS_HIP_ERR_ARG;
     if (count == 0) return lbfgs_hip_sync(ctx);
@@ -1704,31 +1876,13 @@ int lbfgs_hip_scalars_read(lbfgs_hip_ctx* ctx, int first, int count, double* hos
     int rc = scalars_read_once(ctx, first, count, host, &flag);
     if (rc != LBFGS_HIP_OK) return rc;
     if (flag == 2u && ctx->last_res.valid && ctx->comm_kind == LBFGS_HIP_COMM_NONE) {
-        // The resident two-loop kernel waited in vain for a workgroup: it was not given every CU it asked for (another
-        // kernel-resident process or stream on this GPU, a CU-masked queue).  Nothing is lost: its inputs are intact.  Clear
-        // the error word, never use that kernel again in this context, and run the recursion with a kernel per step.
-        const lbfgs_hip_ctx::LastResident lr = ctx->last_res;
-        ctx->last_res.valid = false;
-        ctx->resident_ok = 0;
-        ctx->resident_fallbacks += 1;
-        fprintf(stderr, "[lbfgs_hip] warning: the on-chip-resident two-loop kernel timed out waiting for a workgroup (the GPU is "
-                        "shared with another resident kernel, or the queue is CU-masked); re-running this two-loop with a kernel per "
-                        "step and staying on that path (LBFGS_HIP_RESIDENT=0 avoids the wait)\n");
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->p2p_err, 0, sizeof(unsigned int), ctx->stream));
-        // Workgroups of that launch which only STARTED after workgroup 0 had finished (they were never resident together:
-        // that is what went wrong) read the counters workgroup 0 had already advanced, and published their partial sums
-        // under the tags of launches that are yet to come.  No granule of the aborted launch may survive it.
-        HIP_TRY(ctx, hipMemsetAsync(ctx->gran, 0, (size_t)MAX_RED * MAX_GRID * 2 * sizeof(unsigned long long), ctx->stream));
-        if (ctx->mirror) *reinterpret_cast<volatile unsigned long long*>(ctx->mirror + LBFGS_HIP_BOARD_SLOTS + 3) = 0ull;
-        int ne = 0;
-        rc = two_loop_eager(lr.h, lr.d, lr.g, lr.k, lr.end, lr.gnum, lr.gden, lr.dn, lr.first, &ne, lr.owl, lr.owl_start, lr.owl_end);
-        if (rc != LBFGS_HIP_OK) return rc;
+        if ((rc = recover_resident(ctx)) != LBFGS_HIP_OK) return rc;
         flag = 0;
         rc = scalars_read_once(ctx, first, count, host, &flag);
         if (rc != LBFGS_HIP_OK) return rc;
     }
     if (flag) return device_error(ctx, flag);
+    if (ctx->last_res.valid) ctx->resident_proven = true;  // (the read waited for the latest launch: a resident two-loop that completed)
     return LBFGS_HIP_OK;
 }
 
@@ -1736,6 +1890,7 @@ int lbfgs_hip_scalars_write(lbfgs_hip_ctx* ctx, int first, int count, const doub
     if (!ctx || !host || !slot_ok(first, count)) return LBFGS_HIP_ERR_ARG;
     if (count == 0) return LBFGS_HIP_OK;
     for (int i = 0; i < count; ++i) ctx->mirror_valid[first + i] = false;
+    ctx->last_res.valid = false;  // (gamma or the first numerator of the latest resident two-loop may change)
     memcpy(ctx->pinned, host, count * sizeof(double));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->board + first, ctx->pinned, count * sizeof(double), hipMemcpyHostToDevice,
                                 ctx->stream));
@@ -1924,6 +2079,8 @@ int lbfgs_hip_history_scalars_read(lbfgs_hip_history* h, double* ys, double* alp
     if (!h) return LBFGS_HIP_ERR_ARG;
     lbfgs_hip_ctx* ctx = h->ctx;
     if (2 * h->m > LBFGS_HIP_BOARD_SLOTS) return LBFGS_HIP_ERR_ARG;
+    const int rc_s = settle(ctx);  // (alpha is an output of the two-loop: see lbfgs_hip_vec_download)
+    if (rc_s != LBFGS_HIP_OK) return rc_s;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pinned, h->ys, 2 * (size_t)h->m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ys) memcpy(ys, ctx->pinned, h->m * sizeof(double));
@@ -1934,6 +2091,7 @@ int lbfgs_hip_history_scalars_read(lbfgs_hip_history* h, double* ys, double* alp
 int lbfgs_hip_history_scalars_write(lbfgs_hip_history* h, const double* ys, const double* alpha) {
     if (!h) return LBFGS_HIP_ERR_ARG;
     lbfgs_hip_ctx* ctx = h->ctx;
+    ctx->last_res.valid = false;  // (ys is an input of the latest resident two-loop)
     if (ys) HIP_TRY(ctx, hipMemcpyAsync(h->ys, ys, h->m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if (alpha) HIP_TRY(ctx, hipMemcpyAsync(h->alpha, alpha, h->m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2014,6 +2172,15 @@ namespace {
 struct ResTraceAcc {
     double skew = 0, after_last = 0, whole_mean = 0, sums = 0, step = 0, polls = 0, spread_out = 0;
     unsigned long long handoffs = 0, steps = 0;
+    // per workgroup: how late it arrives (ticks after the FIRST arrival of the same hand-off), how often it is the last / the
+    // first one in, where it ran (XCC_ID << 16 | HW_ID[15:0]) and on how many launches that differed from the launch before
+    double late[256] = {0}, late_sq[256] = {0};
+    unsigned long long last_cnt[256] = {0}, first_cnt[256] = {0}, hw_moves[256] = {0};
+    unsigned int hw[256] = {0};
+    bool hw_seen = false;
+    int grid = 0;
+    double skew_by_handoff[64] = {0};  // by position within the launch (0 = the first hand-off of a launch)
+    unsigned long long n_by_handoff[64] = {0};
 } g_res_trace;
 void res_trace_collect(lbfgs_hip_ctx* ctx, unsigned int first_tag, int handoffs, int grid) {
     static std::vector<unsigned long long> host(64 * 256 * 4);
@@ -2022,20 +2189,31 @@ void res_trace_collect(lbfgs_hip_ctx* ctx, unsigned int first_tag, int handoffs,
         return;
     long long prev_out = 0;
     ResTraceAcc& a = g_res_trace;
+    a.grid = grid;
     for (int h = 0; h < handoffs; ++h) {
         const unsigned long long* tr = host.data() + (size_t)((first_tag + (unsigned int)h) & 63u) * 256 * 4;
         long long in_min = 0, in_max = 0, out_min = 0, out_max = 0;
+        int w_first = 0, w_last = 0;
         double whole = 0, sums = 0, polls = 0;
         for (int w = 0; w < grid; ++w) {
             const long long t0 = (long long)tr[w * 4], t1 = (long long)tr[w * 4 + 1], t2 = (long long)tr[w * 4 + 2];
-            if (w == 0 || t0 < in_min) in_min = t0;
-            if (w == 0 || t0 > in_max) in_max = t0;
+            if (w == 0 || t0 < in_min) { in_min = t0; w_first = w; }
+            if (w == 0 || t0 > in_max) { in_max = t0; w_last = w; }
             if (w == 0 || t2 < out_min) out_min = t2;
             if (w == 0 || t2 > out_max) out_max = t2;
             whole += (double)(t2 - t0);
             sums += (double)(t1 - t0);
-            polls += (double)tr[w * 4 + 3];
+            polls += (double)(tr[w * 4 + 3] & 0xffffffffull);
         }
+        for (int w = 0; w < grid; ++w) {
+            const double l = (double)((long long)tr[w * 4] - in_min);
+            a.late[w] += l;
+            a.late_sq[w] += l * l;
+        }
+        a.last_cnt[w_last] += 1;
+        a.first_cnt[w_first] += 1;
+        a.skew_by_handoff[h] += (double)(in_max - in_min);
+        a.n_by_handoff[h] += 1;
         a.skew += (double)(in_max - in_min);
         a.after_last += (double)(out_min - in_max);
         a.spread_out += (double)(out_max - out_min);
@@ -2046,6 +2224,15 @@ void res_trace_collect(lbfgs_hip_ctx* ctx, unsigned int first_tag, int handoffs,
         if (h > 0) { a.step += (double)(in_min - prev_out); a.steps += 1; }
         prev_out = out_max;
     }
+    {   // placement of the workgroups in this launch (any hand-off's stamps carry it)
+        const unsigned long long* tr = host.data() + (size_t)(first_tag & 63u) * 256 * 4;
+        for (int w = 0; w < grid; ++w) {
+            const unsigned int hw = (unsigned int)(tr[w * 4 + 3] >> 32) & 0xfff00u;  // xcc, se, sh, cu (not pipe / simd / wave)
+            if (a.hw_seen && hw != a.hw[w]) a.hw_moves[w] += 1;
+            a.hw[w] = hw;
+        }
+        a.hw_seen = true;
+    }
 }
 void res_trace_print() {
     const ResTraceAcc& a = g_res_trace;
@@ -2055,6 +2242,64 @@ void res_trace_print() {
                     "%.0f ns apart; first one out %.0f ns after the LAST arrival, last one out %.0f ns later; "
                     "streaming between hand-offs (last out -> first in) %.0f ns\n", a.handoffs, a.whole_mean * k, a.sums * k,
             a.polls / (double)a.handoffs, a.skew * k, a.after_last * k, a.spread_out * k, a.steps ? a.step * 10.0 / (double)a.steps : 0.0);
+    // ---- is the arrival skew SYSTEMATIC (the same workgroups / XCDs / CUs late every time) or random?
+    const int G = a.grid;
+    const double H = (double)a.handoffs;
+    double mean_all = 0, between = 0, within = 0;
+    for (int w = 0; w < G; ++w) mean_all += a.late[w] / H;
+    mean_all /= G;
+    for (int w = 0; w < G; ++w) {
+        const double mw = a.late[w] / H;
+        between += (mw - mean_all) * (mw - mean_all);
+        within += a.late_sq[w] / H - mw * mw;
+    }
+    between /= G; within /= G;
+    unsigned long long moves = 0;
+    for (int w = 0; w < G; ++w) moves += a.hw_moves[w];
+    fprintf(stderr, "[res-skew] grid %d: mean lateness (after the first arrival) %.0f ns; variance between workgroups %.3g ns^2, within a "
+                    "workgroup (hand-off to hand-off) %.3g ns^2 => %.0f %% of the variance is systematic per workgroup; workgroup->CU "
+                    "placement changed %llu times between consecutive launches (of %d workgroups x launches)\n", G, mean_all * 10.0,
+            between * 100.0, within * 100.0, 100.0 * between / std::max(between + within, 1e-300), moves, G);
+    // by XCC (8 on MI355X) and by shader engine within it
+    double xl[16] = {0}; unsigned long long xlast[16] = {0}; int xn[16] = {0};
+    for (int w = 0; w < G; ++w) {
+        const int x = (a.hw[w] >> 16) & 15;
+        xl[x] += a.late[w] / H; xlast[x] += a.last_cnt[w]; xn[x] += 1;
+    }
+    for (int x = 0; x < 16; ++x)
+        if (xn[x])
+            fprintf(stderr, "[res-skew] xcc %d: %3d workgroups, mean lateness %5.0f ns, last one in %5.1f %% of the hand-offs\n", x, xn[x],
+                    xl[x] / xn[x] * 10.0, 100.0 * (double)xlast[x] / H);
+    {   // by position within the launch
+        char buf[1024]; int o = 0;
+        for (int h = 0; h < 64 && a.n_by_handoff[h]; ++h)
+            o += snprintf(buf + o, sizeof(buf) - (size_t)o, " %.0f", a.skew_by_handoff[h] * 10.0 / (double)a.n_by_handoff[h]);
+        fprintf(stderr, "[res-skew] skew by hand-off position within the launch (ns):%s\n", buf);
+    }
+    // the 12 latest and the 12 earliest workgroups
+    std::vector<int> order(G);
+    for (int w = 0; w < G; ++w) order[w] = w;
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return a.late[x] > a.late[y]; });
+    auto row = [&](int w) {
+        const double mw = a.late[w] / H, sd = std::sqrt(std::max(0.0, a.late_sq[w] / H - mw * mw));
+        fprintf(stderr, "[res-skew]   wg %3d  xcc %u se %u sh %u cu %2u  late %5.0f +- %4.0f ns  last %5.1f %%  first %5.1f %%\n", w,
+                (a.hw[w] >> 16) & 15, (a.hw[w] >> 13) & 7, (a.hw[w] >> 12) & 1, (a.hw[w] >> 8) & 15, mw * 10.0, sd * 10.0,
+                100.0 * (double)a.last_cnt[w] / H, 100.0 * (double)a.first_cnt[w] / H);
+    };
+    for (int i = 0; i < std::min(G, 12); ++i) row(order[i]);
+    fprintf(stderr, "[res-skew]   ...\n");
+    for (int i = std::max(0, G - 12); i < G; ++i) row(order[i]);
+    if (const char* path = getenv("LBFGS_HIP_TRACE_FILE")) {  // every workgroup, for offline reading
+        if (FILE* f = fopen(path, "a")) {
+            fprintf(f, "# grid %d handoffs %llu\nwg,xcc,se,sh,cu,late_ns,late_sd_ns,last_frac,first_frac,placement_moves\n", G, a.handoffs);
+            for (int w = 0; w < G; ++w) {
+                const double mw = a.late[w] / H, sd = std::sqrt(std::max(0.0, a.late_sq[w] / H - mw * mw));
+                fprintf(f, "%d,%u,%u,%u,%u,%.0f,%.0f,%.4f,%.4f,%llu\n", w, (a.hw[w] >> 16) & 15, (a.hw[w] >> 13) & 7, (a.hw[w] >> 12) & 1,
+                        (a.hw[w] >> 8) & 15, mw * 10.0, sd * 10.0, (double)a.last_cnt[w] / H, (double)a.first_cnt[w] / H, a.hw_moves[w]);
+            }
+            fclose(f);
+        }
+    }
 }
 #endif
 template <int ER, bool HYB = false>
@@ -2172,6 +2417,9 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     // the slice of the HBM part of q that is kept out of the `nt` stream (resident.h res_hbm_rounds): so many MiB of it
     ra.hbm_plain_pairs = eh ? (uint32_t)std::min<uint64_t>(eh, (ctx->resident_plain_bytes + per_round * 16 - 1) / (per_round * 16)) : 0u;
     if (ctx->resident_plain_bytes == 0) ra.hbm_plain_pairs = 0;
+    // rounds a waiting workgroup touches behind the window (resident.h TOUCHING): 16 of two vectors fill an XCD's L2, which
+    // pays from ~64 rounds per thread up; shorter steps want 8 (profiles/r04_touch_sweep.log)
+    ra.touch_rounds = (uint32_t)(ctx->resident_touch >= 0 ? ctx->resident_touch : (E >= 64 ? 16 : 8));
     int ns = 0;
     auto add = [&](const double* u, const double* v, int j, int mode_b, int scale, int aidx, int last) {
         ResStep& st = ra.step[ns++];
@@ -2185,8 +2433,7 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
         add(h->s[jat(i)]->p, h->y[jat(i - 1)]->p, jat(i), 1, 0, i, 0);
     add(h->s[jat(0)]->p, g->p, jat(0), 1, 0, 0, 1);  // last step: ||d||^2 and g.d
     ra.nsteps = ns;
-    ra.fault_drop_last = ctx->resident_fault > 0 ? 1 : 0;
-    if (ctx->resident_fault > 0) ctx->resident_fault -= 1;
+    ra.fault_drop_last = (ctx->resident_fault > 0 && --ctx->resident_fault == 0) ? 1 : 0;  // (the k-th resident launch of the context)
 
     RedCtl red{};
     bool in_kernel_exchange = false;
@@ -2196,12 +2443,19 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
 #endif
     const int rc_p = prep_red(ctx, red, owl ? 4 : 2, outs2, nullptr, 0, &in_kernel_exchange);
     if (rc_p != LBFGS_HIP_OK) return rc_p;
+    // until a resident launch of this context has been seen to complete, a missing workgroup costs milliseconds (see
+    // lbfgs_hip_ctx::first_timeout_ticks); one rank only: with peers a hand-off also waits for THEIR start-up
+    if (!ctx->resident_proven && ctx->comm_kind == LBFGS_HIP_COMM_NONE)
+        red.timeout_ticks = std::min(red.timeout_ticks, ctx->first_timeout_ticks);
     // (one hand-off per step -- under OWL-QN the last step's travels after the projection, with four values -- plus one
     // for the first numerator if it is summed here: the SAME sequence of reductions as the launch-per-step path, so under
     // P2P ranks whose eligibility differs -- an empty shard, a shard one round larger -- still meet in every exchange)
     const unsigned long long handoffs = (unsigned long long)(ns + (ra.first_dot ? 0 : 1));
     ctx->red_count += handoffs - 1ull;  // one tag per hand-off (prep_red counted one)
-    if (in_kernel_exchange) ctx->p2p_count += handoffs - 1ull;  // ... and one P2P epoch each (prep_red counted one)
+    if (in_kernel_exchange) {  // ... and one P2P epoch each (prep_red counted one)
+        ctx->p2p_count += handoffs - 1ull;
+        ctx->two_loop_exchanges += handoffs - 1ull;
+    }
     // streaming hints on the history vectors' loads (read once per step) and on d's stores: from 16 MiB vectors up for this
     // kernel (measured: neutral at 16 MB, +2 % at 24 MB, +8 % at 32-48 MB, profiles/r02_resident_nt_threshold.log; the
     // launch-per-step kernels want them from 64 / 128 MiB only: their running vector is re-read from the caches)
@@ -2241,9 +2495,24 @@ static int two_loop_eager(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hi
 // once per such combination and replayed with ONE hipGraphLaunch -- the host stops paying a launch per kernel, which
 // is what bounds iterations/s on vectors of a few MB.  Recording = stream capture of the eager path, so both paths
 // launch the very same kernels with the very same arguments (results are bitwise equal; a test checks it).
+static int two_loop_impl_inner(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
+                               int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end,
+                               bool owl, uint64_t owl_start, uint64_t owl_end);
 static int two_loop_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
                          int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end,
                          bool owl, uint64_t owl_start, uint64_t owl_end) {
+    if (!h) return LBFGS_HIP_ERR_ARG;
+    lbfgs_hip_ctx* ctx = h->ctx;
+    ctx->two_loop_calls += 1;
+    ctx->xchg_class = 1;  // (the exchanges enqueued from here on are charged to the two-loop: lbfgs_hip_ctx_comm_info)
+    const int rc = two_loop_impl_inner(h, d, g, k, end, gamma_num_slot, gamma_den_slot, dnorm_slot, first_dot_slot, new_end, owl,
+                                       owl_start, owl_end);
+    ctx->xchg_class = 0;
+    return rc;
+}
+static int two_loop_impl_inner(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
+                               int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end,
+                               bool owl, uint64_t owl_start, uint64_t owl_end) {
     if (first_dot_slot >= 0 && !slot_ok(first_dot_slot, 1)) return LBFGS_HIP_ERR_ARG;
     if (!h || !d || !g || d->ctx != h->ctx || g->ctx != h->ctx || end < 0 || end >= h->m || !new_end)
         return LBFGS_HIP_ERR_ARG;
@@ -2309,6 +2578,7 @@ static int two_loop_impl(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip
         ctx->red_count += tg.tagged_launches;
         ctx->mirror_seq += tg.mirrored_launches;
         ctx->p2p_count += tg.p2p_exchanges;
+        ctx->two_loop_exchanges += tg.p2p_exchanges;
         for (const auto& t : tg.mirror_touch) ctx->mirror_valid[t.first] = t.second;
     }
     *new_end = it->second.new_end;
@@ -2461,16 +2731,17 @@ int lbfgs_hip_two_loop_gram(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_
                             int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int* new_end) {
     if (!h || !d || !g || d->ctx != h->ctx || g->ctx != h->ctx || end < 0 || end >= h->m || !new_end)
         return LBFGS_HIP_ERR_ARG;
-    if (!slot_ok(gamma_num_slot, 1) || !slot_ok(gamma_den_slot, 1) || !slot_ok(dnorm_slot, 2)) return LBFGS_HIP_ERR_ARG;
+    if (!slot_ok(gamma_num_slot, 1) || !slot_ok(gamma_den_slot, 1) || !slot_ok(dnorm_slot, 3)) return LBFGS_HIP_ERR_ARG;
     lbfgs_hip_ctx* ctx = h->ctx;
     const int m = h->m;
     if (m > GRAM_MAX_M) return fail(ctx, LBFGS_HIP_ERR_ARG, "vector-free two-loop supports m <= %d", GRAM_MAX_M);
     if (!h->gram) {
-        const size_t nb = 2 * (size_t)m + 1, words = nb * nb + 3 * nb + nb;
+        const size_t nb = 2 * (size_t)m + 1, words = nb * nb + 3 * nb + nb + 1;
         HIP_TRY(ctx, hipMalloc(&h->gram, words * sizeof(double)));
         HIP_TRY(ctx, hipMemsetAsync(h->gram, 0, words * sizeof(double), ctx->stream));
         h->gram_rows = h->gram + nb * nb;
         h->gram_delta = h->gram_rows + 3 * nb;
+        h->gram_pred = h->gram_delta + nb;
     }
     ProfScope whole(ctx, LBFGS_HIP_K_TWOLOOP_ALL);
     const int e1 = (end + 1) % m;
@@ -2479,13 +2750,18 @@ int lbfgs_hip_two_loop_gram(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_
     const double* gnum = ctx->board + gamma_num_slot;
     const double* gden = ctx->board + gamma_den_slot;
     double* dn = ctx->board + dnorm_slot;
+    ctx->two_loop_calls += 1;
+    ctx->xchg_class = 1;
+    int rc = LBFGS_HIP_ERR_ARG;
     switch (m) {
-#define LH_CASE(MM) case MM: return two_loop_gram_impl<MM>(h, d, g, bound, end, e1, gnum, gden, dn);
+#define LH_CASE(MM) case MM: rc = two_loop_gram_impl<MM>(h, d, g, bound, end, e1, gnum, gden, dn); break;
         LH_CASE(1) LH_CASE(2) LH_CASE(3) LH_CASE(4) LH_CASE(5) LH_CASE(6)
         LH_CASE(7) LH_CASE(8) LH_CASE(9) LH_CASE(10)
 #undef LH_CASE
-        default: return LBFGS_HIP_ERR_ARG;
+        default: break;
     }
+    ctx->xchg_class = 0;
+    return rc;
 }
 
 // ==================================================================================== OWL-QN

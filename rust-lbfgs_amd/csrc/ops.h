@@ -244,11 +244,12 @@ struct GramCoef {
 template <int M>
 struct OpGramCombine {  // in[] in basis order; d = sum_j delta_j * b_j (ascending j); ||d||^2 ; g.d
     static constexpr int NB = 2 * M + 1;
-    static constexpr int NIN = NB, NOUT = 1, NRED = 2;
+    static constexpr int NIN = NB, NOUT = 1, NRED = 3;
     static constexpr int TUNE_MAP = 1, TUNE_UNROLL = 1;
     const double* in[NB];
     double* out[1];
     const double* delta;  // NB coefficients written by the scalar recursion kernel
+    const double* pred;   // the coefficient-space prediction of ||d||^2: the third "sum" (see gram_combine.h GramCombArgs::pred)
     typedef GramCoef<M> Coef;
     __device__ Coef setup() const {
         Coef cf;
@@ -256,13 +257,14 @@ struct OpGramCombine {  // in[] in basis order; d = sum_j delta_j * b_j (ascendi
         for (int j = 0; j < NB; ++j) cf.c[j] = delta[j];
         return cf;
     }
-    __device__ void elem(const Coef& cf, const double* v, double* w, double* acc, uint64_t) const {
+    __device__ void elem(const Coef& cf, const double* v, double* w, double* acc, uint64_t gidx) const {
         double q = cf.c[0] * v[0];
 #pragma unroll
         for (int j = 1; j < NB; ++j) q = q + cf.c[j] * v[j];
         w[0] = q;
         acc[0] += q * q;
         acc[1] += v[NB - 1] * q;
+        if (gidx == 0) acc[2] += *pred;  // (element 0 of the global vector: one contribution in the whole job)
     }
 };
 

@@ -40,44 +40,31 @@ constexpr int RES_MAX_STEPS = 2 * 24;  // 2 * bound for bound <= 24 (the step ta
 constexpr int RES_LDS_PAIRS_MAX = 36;  // 160 KiB / (256 threads x 16 B) = 40, less the kernel's static arrays (4.3 KiB),
                                        // rounded down to a multiple of RES_UNROLL
 constexpr int RES_UNROLL = 4;          // pairs whose loads are issued together (one group)
-#ifndef LH_RES_AHEAD
-#define LH_RES_AHEAD 1
-#endif
-#ifndef LH_RES_P2P_ONE_HOP
-#define LH_RES_P2P_ONE_HOP 0  // several ranks: every workgroup reads the ranks' totals from the mailbox itself (no local broadcast hop)
-#endif
-#ifndef LH_RES_HBM_ALTERNATE
-#define LH_RES_HBM_ALTERNATE 1  // hybrid: odd steps sweep the HBM rounds from the top down (what a step wrote last, the next reads
-                                // first).  Pays together with the cache slice of res_hbm_rounds: a slice larger than the Infinity
-                                // Cache then degrades gracefully instead of thrashing (profiles/r03_hybrid_cache_slice_ab.log)
-#endif
-#ifndef LH_RES_HBM_UNROLL
-#define LH_RES_HBM_UNROLL 4
-#endif
-#ifndef LH_RES_SLIM
-#define LH_RES_SLIM 1  // hand-off with two workgroup barriers instead of five (res_exchange); 0 = the round-2 form (A/B builds)
-#endif
-#ifndef LH_RES_PREFETCH
-// where the NEXT step's first operand groups are loaded relative to the hand-off that yields its coefficient:
-//   0  right before the hand-off (round 2): HBM keeps streaming while the workgroups wait -- but a wave's loads return in
-//      order (vmcnt), so the polls of the hand-off cannot be read before those loads have come back;
-//   1  after the hand-off (A/B only: nothing in flight while the workgroups wait);
-//   2  inside the step's last on-chip group (the loads have returned when the step's own last operands have, the polls
-//      find an empty queue, and the window is ready when the coefficient is)
-#define LH_RES_PREFETCH 0
-#endif
-#ifndef LH_RES_PLAIN_WO
-#define LH_RES_PLAIN_WO 0  // 1: without OWL-QN, too, the last step stores q as it completes it (A/B: slower, see ResRegStep)
-#endif
-#ifndef LH_RES_DPP
-#define LH_RES_DPP 1  // 1: the hand-off's wave sums with DPP moves + readlane (stream.h wave_sum_dpp) instead of ds_bpermute trees
+// TOUCHING.  While a workgroup waits in a hand-off, HBM idles: the NEXT step's operands are known (only its coefficient is
+// not), but the registers and LDS are full of q, so only a window of RES_AHEAD groups can be loaded ahead.  So a waiting
+// workgroup TOUCHES the lines of the rounds that follow that window -- one 4-byte load per 128-byte line, result unused --
+// and finds them in its XCD's L2 when the step asks for them.  A wave's loads return in order, so a touch must never sit in
+// front of a poll whose answer is on the critical path: every thread issues its touches right BEHIND its first poll's
+// loads, in straight-line code, so that the wait for that poll leaves them in flight (at a join of two paths the compiler
+// would wait for everything); a thread's LATER polls do queue behind them, which costs the early arrivers nothing.
+// Depth (ResArgs::touch_rounds, chosen by the host): 8 rounds up to ~60 rounds per thread, 16 beyond -- 16 rounds of two
+// vectors are 4 MiB per XCD, its whole L2; 24 and more thrash (n = 1.25e7: 662 -> 622 us with 16, 679 with 24, 810 with 48;
+// n = 3e6: 129 -> 119 us with 8, 128 with 16; profiles/r04_touch_sweep.log).  Compiled in for every kernel whose shards have
+// something behind the window (ER >= 8, not hybrid: hybrid steps take hundreds of microseconds, nothing to hide there).
+// LH_RES_TOUCH=0 builds the kernels without it (A/B).
+#ifndef LH_RES_TOUCH
+#define LH_RES_TOUCH 16  // the deepest touch compiled in: a thread holds LH_RES_TOUCH / 4 words (rounds, a multiple of BLOCK / 32)
 #endif
 #ifndef LH_RES_TRACE
-#define LH_RES_TRACE 0  // 1: workgroups 0 and G/2 log wall-clock stamps of every hand-off into RedCtl::partials (tools/handoff_trace.py)
+#define LH_RES_TRACE 0  // 1: every workgroup logs wall-clock stamps of every hand-off into RedCtl::partials (tools/handoff_trace.sh)
 #endif
-constexpr int RES_HBM_UNROLL = LH_RES_HBM_UNROLL;  // hybrid: rounds per group of the part of q that stays in HBM
-constexpr int RES_AHEAD = LH_RES_AHEAD;  // groups whose loads are in flight ahead of the group being worked on (2 was measured:
-                                         // no faster at 1.25e7 elements, 4 % slower at 3e6 -- the hand-off is latency, not bandwidth)
+// What was measured and dropped (profiles/EXPERIMENTS.md has the numbers; the code is gone): two groups in flight ahead of the
+// one worked on (RES_AHEAD = 2: no faster at 1.25e7 elements, 4 % slower at 3e6); the next step's window loaded after the
+// hand-off, or inside the step's last on-chip group, instead of right before the hand-off; the round-2 hand-off with five
+// barriers and ds_bpermute wave sums; a one-hop P2P form in which every workgroup reads the mailbox; the plain last step
+// storing q as it completes it (1.5-3.6 % slower than the separate pass of stores); HBM rounds swept upwards in every step.
+constexpr int RES_HBM_UNROLL = 4;  // hybrid: rounds per group of the part of q that stays in HBM
+constexpr int RES_AHEAD = 1;       // groups whose loads are in flight ahead of the group being worked on
 
 struct ResStep {
     const double* u;     // the vector added to q:   q += c * u
@@ -106,11 +93,50 @@ struct ResArgs {
     uint32_t lds_pairs;         // of which in LDS (a multiple of RES_UNROLL)
     uint32_t hbm_pairs;         // hybrid: the rounds beyond registers + LDS, whose part of q lives in `d` itself (0: none)
     uint32_t hbm_plain_pairs;   // ... of which the first so many are accessed with the default cache policy (res_hbm_rounds)
+    uint32_t touch_rounds;      // rounds behind the window that a waiting workgroup touches (TOUCHING above; <= LH_RES_TOUCH)
     int nsteps;
     int fault_drop_last;        // tests (LBFGS_HIP_RESIDENT_FAULT=1): the last workgroup leaves at once, as if it had never been
                                 // given a CU -- the others time out in their first hand-off and the host falls back
     ResStep step[RES_MAX_STEPS];
 };
+
+// what a waiting workgroup touches (LH_RES_TOUCH): rounds [r0, r_end) of the next step's u and v, this workgroup's 4 KiB chunk of each
+struct ResTouch {
+    const char* u = nullptr;  // (always valid vectors: after the last step, vectors whose lines are in the caches anyway)
+    const char* v = nullptr;
+    uint32_t first = 0, round_stride = 0;  // byte offset of this workgroup's chunk in round 0; bytes from one round to the next
+    uint32_t r0 = 0, r_end = 0;
+    uint32_t limit = 0;                    // the last byte offset that may be read
+};
+// The touched words land in `sink` and stay there, unread, until the step that follows has consumed operands it loaded LATER
+// (res_touch_retire: loads return in order, so the touches have returned by then and nothing ever waits for them).  Plain
+// loads on purpose: a volatile load is compiled to a system-scope access followed by s_waitcnt vmcnt(0).
+constexpr int RES_TOUCH_REGS = LH_RES_TOUCH > 0 ? (2 * 32 * LH_RES_TOUCH + BLOCK - 1) / BLOCK : 1;
+struct ResSink {
+    unsigned int w[RES_TOUCH_REGS];
+};
+template <int D>
+__device__ __forceinline__ void res_touch(const ResTouch& t, ResSink& sink) {
+    if constexpr (D > 0) {
+        // (whole multiples of the workgroup per vector: which vector a thread touches is then a compile-time fact -- a run-time
+        // choice between the two pointers is compiled to an indexed read of this struct, i.e. to scratch memory)
+        static_assert((32 * D) % BLOCK == 0, "LH_RES_TOUCH must be a multiple of BLOCK / 32");
+        constexpr int PER_VEC = 32 * D / BLOCK;
+#pragma unroll
+        for (int i = 0; i < 2 * PER_VEC; ++i) {
+            const uint32_t L = threadIdx.x + (uint32_t)(BLOCK * (i % PER_VEC));  // line among this vector's 32 * D
+            const uint32_t r = min(t.r0 + L / 32u, t.r_end - 1u), line = L % 32u;
+            const uint32_t off = min(t.first + r * t.round_stride + line * 128u, t.limit);
+            sink.w[i] = *reinterpret_cast<const unsigned int*>((i < PER_VEC ? t.u : t.v) + off);
+        }
+    }
+}
+__device__ __forceinline__ void res_touch_retire(const ResSink& sink) {
+    if constexpr (LH_RES_TOUCH > 0) {
+#pragma unroll
+        for (int i = 0; i < RES_TOUCH_REGS; ++i) asm volatile("" ::"v"(sink.w[i]));
+    }
+}
 
 // Publish this workgroup's NS partial sums of sequence number `tag`, then collect everybody's and return the totals
 // (identical bits in every workgroup).  gran rows: [parity*4 + k], k < 4.  All threads call it.
@@ -132,11 +158,7 @@ __device__ __forceinline__ void res_block_total(double (&acc)[NS], double (*rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-#if LH_RES_DPP
         const double w = wave_sum_dpp(acc[k]);
-#else
-        const double w = wave_sum(acc[k]);
-#endif
         if (lane == 0) rows[k][wave] = w;
     }
     __syncthreads();
@@ -153,17 +175,19 @@ __device__ __forceinline__ void res_block_total(double (&acc)[NS], double (*rows
 #else
 #define LH_TR(...)
 #endif
-template <int NS>
+// what workgroup 0 of a rank spent in the hand-offs of one launch (several ranks only): DevXchg's figures, kept in registers
+// until the kernel ends
+struct ResXchgAcc {
+    unsigned long long p2p_ticks = 0, local_ticks = 0, count = 0;
+};
+template <int NS, int TOUCH>
 __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& red, const unsigned int tag, const unsigned int p2p_tag,
                                              const int parity, double (*lds)[WAVES], double* s_tot,
-                                             unsigned int (*s_bits)[MAX_RED][2]) {
+                                             unsigned int (*s_bits)[MAX_RED][2], ResSink& sink, ResXchgAcc& xacc,
+                                             const ResTouch& touch) {
     LH_TR(const long long tr0 = wall_clock64(); long long tr1 = 0; unsigned int tr_polls = 0;)
-#if LH_RES_SLIM
     res_block_total<NS>(acc, lds);  // (every thread holds the workgroup's sums)
-#else
-    block_sum<NS>(acc, lds);
-#endif
-    const unsigned int G = gridDim.x;
+    const unsigned int G = gridDim.x;  // (<= BLOCK: the host launches no larger grid -- thread t polls workgroup t)
     const bool multi = red.p2p.world > 1;
     const unsigned long long t = (unsigned long long)tag << 32;
     if (threadIdx.x == 0) {
@@ -178,79 +202,82 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
     LH_TR(asm volatile("" ::: "memory"); tr1 = wall_clock64();)
     // Nobody polls before its own workgroup's partial is on its way.  (Without this barrier 255 threads of every workgroup
     // start polling while thread 0 is still publishing, and 65 000 early pollers on the 32 cache lines that hold the
-    // granules slow every store to them down: 2.5 us per hand-off against 1.7, tools/handoff_bench.hip.  In the round-2
-    // form the same barrier also keeps the two uses of `lds` apart.)
+    // granules slow every store to them down: 2.5 us per hand-off against 1.7, tools/handoff_bench.hip.)
     __syncthreads();
-    double (*rows2)[WAVES] = LH_RES_SLIM ? lds + 4 : lds;
+    double (*rows2)[WAVES] = lds + 4;
     double tot[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) tot[k] = 0.0;
     const long long t0 = wall_clock64();
-    if (!multi || blockIdx.x == 0) {
-        for (unsigned int b = threadIdx.x; b < G; b += BLOCK) {  // (G <= BLOCK in practice: one poll loop per thread)
-            unsigned long long lo[NS], hi[NS];
-            for (;;) {
-                bool ok = true;
+    const bool collector = !multi || blockIdx.x == 0;  // (uniform) this workgroup adds up the G partials itself
+    if (collector) {
+        // Thread b polls workgroup b's granules (threads beyond the grid poll this workgroup's own and drop the value: the first
+        // poll and the touches behind it are then straight-line code, so that the wait for the poll leaves the touches in
+        // flight -- at a join of two paths the compiler would wait for everything).
+        const bool mine = threadIdx.x < G;
+        const unsigned int b = mine ? threadIdx.x : blockIdx.x;
+        unsigned long long lo[NS], hi[NS];
 #pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    const unsigned long long* g = red.gran + ((size_t)(parity * 4 + k) * MAX_GRID + b) * 2;
-                    lo[k] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hi[k] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#pragma unroll
-                for (int k = 0; k < NS; ++k) ok = ok && (unsigned int)(lo[k] >> 32) == tag && (unsigned int)(hi[k] >> 32) == tag;
-                LH_TR(tr_polls++;)
-                if (ok) break;
-                // (slow path only) give up after the timeout -- or at once if somebody already has: one missing workgroup must
-                // cost ONE timeout, not one per hand-off and workgroup
-                if ((unsigned long long)(wall_clock64() - t0) > red.timeout_ticks ||
-                    __hip_atomic_load(red.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    atomicExch(red.err, 2u);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-#pragma unroll
-            for (int k = 0; k < NS; ++k) tot[k] += __longlong_as_double((long long)((hi[k] << 32) | (lo[k] & 0xffffffffULL)));
+        for (int k = 0; k < NS; ++k) {
+            const unsigned long long* g = red.gran + ((size_t)(parity * 4 + k) * MAX_GRID + b) * 2;
+            lo[k] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hi[k] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // a fixed order: thread-strided partials, each wave's sum (stream.h wave_sum_dpp: rows of 16 as trees, the four rows
+        asm volatile("" ::: "memory");
+        res_touch<TOUCH>(touch, sink);
+        asm volatile("" ::: "memory");
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) ok = ok && (unsigned int)(lo[k] >> 32) == tag && (unsigned int)(hi[k] >> 32) == tag;
+            LH_TR(tr_polls++;)
+            if (ok) break;
+            // (slow path only) give up after the timeout -- or at once if somebody already has: one missing workgroup must
+            // cost ONE timeout, not one per hand-off and workgroup
+            if ((unsigned long long)(wall_clock64() - t0) > red.timeout_ticks ||
+                __hip_atomic_load(red.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                atomicExch(red.err, 2u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const unsigned long long* g = red.gran + ((size_t)(parity * 4 + k) * MAX_GRID + b) * 2;
+                lo[k] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hi[k] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const double v = __longlong_as_double((long long)((hi[k] << 32) | (lo[k] & 0xffffffffULL)));
+            tot[k] = mine ? 0.0 + v : 0.0;  // (0.0 + v: the bits of the strided sum this replaces, -0.0 included)
+        }
+        // a fixed order: one partial per thread, each wave's sum (stream.h wave_sum_dpp: rows of 16 as trees, the four rows
         // in order), the waves in order -- the same in every workgroup, so all of them hold the same bits
-#if LH_RES_SLIM
         res_block_total<NS>(tot, rows2);
-        if (multi) {  // (workgroup 0 only) p2p_exchange works on LDS
+        if (multi) {  // (workgroup 0 only) this rank's totals -> the global totals, then tell the other workgroups
             if (threadIdx.x == 0) {
 #pragma unroll
                 for (int k = 0; k < NS; ++k) s_tot[k] = tot[k];
             }
             __syncthreads();
-        }
-#else
-        block_sum<NS>(tot, rows2);
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int k = 0; k < NS; ++k) s_tot[k] = tot[k];
-        }
-        __syncthreads();
-#endif
-#if LH_RES_P2P_ONE_HOP
-        if (multi) p2p_publish(red.p2p, p2p_tag, s_tot, NS);  // (workgroup 0 only) this rank's totals to every rank's mailbox
-    }
-    // every workgroup of every rank reads the P ranks' totals from its rank's mailbox and adds them up in rank order
-    if (multi) p2p_collect(red.p2p, p2p_tag, s_tot, NS, s_bits, red.timeout_ticks);
-#else
-        if (multi) {  // (workgroup 0 only) this rank's totals -> the global totals, then tell the other workgroups
+            const long long t1 = wall_clock64();
             p2p_exchange(red.p2p, p2p_tag, s_tot, NS, s_bits);
+            xacc.p2p_ticks += (unsigned long long)(wall_clock64() - t1);
+            xacc.local_ticks += (unsigned long long)(t1 - t0);
+            xacc.count += 1ull;
             if (threadIdx.x == 0) {
 #pragma unroll
                 for (int k = 0; k < NS; ++k) {
-                    const unsigned long long b = (unsigned long long)__double_as_longlong(s_tot[k]);
+                    const unsigned long long b2 = (unsigned long long)__double_as_longlong(s_tot[k]);
                     unsigned long long* g = red.gran + ((size_t)(8 + parity * 4 + k) * MAX_GRID) * 2;
-                    __hip_atomic_store(g, t | (b & 0xffffffffULL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(g + 1, t | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(g, t | (b2 & 0xffffffffULL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(g + 1, t | (b2 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
     } else {
+        res_touch<TOUCH>(touch, sink);
         if (threadIdx.x < NS) {  // one lane per sum polls the global total workgroup 0 will publish
             const unsigned long long* g = red.gran + ((size_t)(8 + parity * 4 + threadIdx.x) * MAX_GRID) * 2;
             unsigned long long lo, hi;
@@ -269,8 +296,6 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
         }
         __syncthreads();
     }
-#endif
-#if LH_RES_SLIM
     // (s_tot is written behind a barrier of this hand-off and next written behind one of the next: no barrier needed here)
     if (multi) {
 #pragma unroll
@@ -279,18 +304,16 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
 #pragma unroll
         for (int k = 0; k < NS; ++k) acc[k] = tot[k];
     }
-#else
-#pragma unroll
-    for (int k = 0; k < NS; ++k) acc[k] = s_tot[k];
-    __syncthreads();  // s_tot and lds are free again
-#endif
 #if LH_RES_TRACE
     if (threadIdx.x == 0) {  // every workgroup: [slot = tag & 63][workgroup][4] = arrival, partial published, totals known, polls
         unsigned long long* tr = reinterpret_cast<unsigned long long*>(red.partials) + ((size_t)(tag & 63u) * 256u + blockIdx.x) * 4;
         tr[0] = (unsigned long long)tr0;
         tr[1] = (unsigned long long)tr1;
         tr[2] = (unsigned long long)wall_clock64();
-        tr[3] = tr_polls;
+        // polls in the low half; where this workgroup runs in the high half: XCC_ID[3:0] << 16 | HW_ID[15:0] (se, sh, cu, pipe, simd, wave)
+        const unsigned int hw = ((unsigned int)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu) << 16 |
+                                ((unsigned int)__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu);
+        tr[3] = (unsigned long long)tr_polls | ((unsigned long long)hw << 32);
     }
 #endif
 }
@@ -509,8 +532,8 @@ __device__ __forceinline__ void res_shift(ResWin& w, const d2 (&fu)[RES_UNROLL],
 // written by a pass of stores after the last hand-off).  2: in d, under OWL-QN, with the orthant projection
 // (orthantwise.rs:140-161) applied on the way out: the step streams v = pg anyway, so pg is not read a second time (25
 // instead of 26 passes at m = 6); acc0 stays ||d||^2 BEFORE the projection (lbfgs.rs:543 precedes :554), acc2 / acc3 sum
-// ||d||^2 and pg.d of the projected direction.  (1: the plain case stored the same way -- measured 1.5-3.6 % SLOWER than
-// the separate pass at 3e6 ... 1.25e7 elements, profiles/r03_resident_fused_writeout_ab.log; kept for A/B builds only.)
+// ||d||^2 and pg.d of the projected direction.  (The plain case stored the same way measured 1.5-3.6 % SLOWER than the
+// separate pass at 3e6 ... 1.25e7 elements, profiles/r03_resident_fused_writeout_ab.log.)
 struct ResOut {
     double* d;
     ResOwl ow;
@@ -570,24 +593,13 @@ struct ResRegStep {
     }
 };
 // one whole step; on entry the window holds the operands of groups 0 .. RES_AHEAD-1, on exit nothing.
-// EARLY (LH_RES_PREFETCH == 2): the window of the NEXT step (operands nup, nvp) is loaded into `wnext` while the last
-// on-chip group of this step is worked on -- every step has at least one LDS group -- so that those loads have returned
-// when this step's own last operands have: a wave's loads return in order, and the polls of the hand-off that follows
-// must not queue behind a window of HBM loads.
-template <int ER, bool NT, int MODE, bool EARLY, int WO = 0>
+template <int ER, bool NT, int MODE, int WO = 0>
 __device__ __forceinline__ void res_step(ResWin& w, d2* q_lds, const ResPos& ps, const double* up, const double* vp, const double c,
-                                         const double gamma, double* acc, ResWin& wnext, const double* nup, const double* nvp,
-                                         const ResOut& out = ResOut{}) {
+                                         const double gamma, double* acc, const ResOut& out = ResOut{}) {
     static_assert(WO == 0 || MODE == 2, "only the last step writes q out");
     ResRegStep<0, ER, NT, MODE, WO>::run(w, ps, up, vp, c, gamma, acc, out);
     const uint32_t tid = threadIdx.x, NL = ps.EL / RES_UNROLL;
     for (uint32_t j = 0; j < NL; ++j) {
-        if constexpr (EARLY) {
-            if (j + 1 == NL) {
-                ResFetch<ER, NT, true>::window(wnext, ps, nup, nvp);
-                asm volatile("" ::: "memory");
-            }
-        }
         d2 fu[RES_UNROLL], fv[RES_UNROLL];
         ResFetch<ER, NT, MODE != 1>::lds(j + RES_AHEAD, ps, up, vp, fu, fv);
         asm volatile("" ::: "memory");
@@ -813,21 +825,37 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
     unsigned int tag = c0.red_epoch, ptag = c0.p2p_epoch;
     int parity = 0;
     double dot;
-    // (see ResWin: the next step's first groups are loaded BEFORE the hand-off that yields its coefficient)
-    ResWin win, wnext;
+    // (see ResWin: the next step's first groups are loaded BEFORE the hand-off that yields its coefficient, so HBM keeps
+    // streaming while the workgroups wait -- a wave's loads return in order, the polls of the hand-off queue behind them)
+    ResWin win;
     const ResPos ps{p_first, p_stride, n2, EL};
-    // (hybrid: the HBM rounds follow the on-chip groups and need the registers an early window would hold)
-    constexpr int PF = HYB ? (LH_RES_PREFETCH == 2 ? 0 : LH_RES_PREFETCH) : LH_RES_PREFETCH;
-    constexpr bool EARLY = PF == 2;
     auto prefetch = [&](const int si) {
         const double* up = a.step[si].u;
         const double* vp = a.step[si].v ? a.step[si].v : up;  // (the gamma transition has no v: those loads go unused)
         ResFetch<ER, NT, true>::window(win, ps, up, vp);
     };
     prefetch(0);
+    constexpr int TOUCH = (HYB || ER == 0) ? 0 : LH_RES_TOUCH;  // (see TOUCHING at the top; the depth is a.touch_rounds <= TOUCH)
+    ResSink sink{};
+    ResXchgAcc xacc;
+    // (LH_RES_TOUCH) what a workgroup touches while it waits in the hand-off BEFORE step `si`: the rounds behind the window
+    ResTouch tch;
+    tch.first = B * (uint32_t)(BLOCK * 16);
+    tch.round_stride = G * (uint32_t)(BLOCK * 16);
+    tch.r0 = (uint32_t)(RES_AHEAD * RES_UNROLL);
+    // (rounds beyond the depth, or beyond the thread's last round, fall back on the last one touched: the same lines again)
+    tch.r_end = min(tch.r0 + max(min(a.touch_rounds, (uint32_t)(TOUCH > 0 ? TOUCH : 1)), 1u), max(a.pairs_per_thread, 1u));
+    tch.limit = (uint32_t)(a.n * 8ull - 8ull);
+    auto touch_for = [&](const int si) {
+        ResTouch t = tch;
+        const int sj = si < a.nsteps ? si : a.nsteps - 1;  // (past the last step: its operands again -- cached, harmless)
+        t.u = reinterpret_cast<const char*>(a.step[sj].u);
+        t.v = reinterpret_cast<const char*>(a.step[sj].v ? a.step[sj].v : a.step[sj].u);
+        return t;
+    };
     if (need_first) {
         double t1[1] = {acc[0]};
-        res_exchange<1>(t1, red, tag, ptag, parity, lds, s_tot, s_bits);
+        res_exchange<1, TOUCH>(t1, red, tag, ptag, parity, lds, s_tot, s_bits, sink, xacc, touch_for(0));
         dot = t1[0];
         tag = next_epoch(tag);
         ptag = next_epoch(ptag);
@@ -856,28 +884,27 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         const int mode = st.last ? 2 : (st.v == nullptr ? 1 : 0);
         const double* qsrc = si == 0 ? a.g : a.d;  // (hybrid rounds only)
         const double qsign = si == 0 ? -1.0 : 1.0;
-        const bool rev = LH_RES_HBM_ALTERNATE && (si & 1);  // (see LH_RES_HBM_ALTERNATE)
-        // the next step's operands (EARLY: loaded inside this step; past the last step: this step's again, unused)
-        const int sn = si + 1 < a.nsteps ? si + 1 : si;
-        const double* nup = a.step[sn].u;
-        const double* nvp = a.step[sn].v ? a.step[sn].v : nup;
+        // hybrid: odd steps sweep the HBM rounds from the top down (what a step wrote last, the next reads first).  Pays
+        // together with the cache slice of res_hbm_rounds: a slice larger than the Infinity Cache then degrades gracefully
+        // instead of thrashing (profiles/r03_hybrid_cache_slice_ab.log)
+        const bool rev = (si & 1) != 0;
         if (mode == 0) {
-            res_step<ER, NT, 0, EARLY>(win, q_lds, ps, st.u, st.v, c, gamma, acc, wnext, nup, nvp);
+            res_step<ER, NT, 0>(win, q_lds, ps, st.u, st.v, c, gamma, acc);
             if constexpr (HYB) res_hbm_rounds<NT, 0>(EH0, EHP, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc, ow);
         } else if (mode == 1) {
-            res_step<ER, NT, 1, EARLY>(win, q_lds, ps, st.u, st.u, c, gamma, acc, wnext, nup, nvp);
+            res_step<ER, NT, 1>(win, q_lds, ps, st.u, st.u, c, gamma, acc);
             if constexpr (HYB) res_hbm_rounds<NT, 1>(EH0, EHP, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.u, c, gamma, acc, ow);
-        } else {  // the last step: q goes out to d as it is completed (projected on the way under OWL-QN)
+        } else {  // the last step: under OWL-QN q goes out to d as it is completed, projected on the way
             const ResOut out{a.d, ow};
-            if (a.owl) res_step<ER, NT, 2, EARLY, 2>(win, q_lds, ps, st.u, st.v, c, gamma, acc, wnext, nup, nvp, out);
-            else res_step<ER, NT, 2, EARLY, LH_RES_PLAIN_WO>(win, q_lds, ps, st.u, st.v, c, gamma, acc, wnext, nup, nvp, out);
+            if (a.owl) res_step<ER, NT, 2, 2>(win, q_lds, ps, st.u, st.v, c, gamma, acc, out);
+            else res_step<ER, NT, 2, 0>(win, q_lds, ps, st.u, st.v, c, gamma, acc, out);
             if constexpr (HYB) {
                 if (a.owl) res_hbm_rounds<NT, 3>(EH0, EHP, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc, ow);  // (projected here)
                 else res_hbm_rounds<NT, 2>(EH0, EHP, EH1, rev, ps, qsrc, qsign, a.d, st.u, st.v, c, gamma, acc, ow);
             }
         }
-        if constexpr (EARLY) win = wnext;
-        else if constexpr (PF == 0) { if (si + 1 < a.nsteps) prefetch(si + 1); }
+        if constexpr (TOUCH > 0) res_touch_retire(sink);  // (what the hand-off before this step touched has long returned)
+        if (si + 1 < a.nsteps) prefetch(si + 1);
         if (tail_owner) {
             const double ut = st.u[a.n - 1], vt = (mode == 1) ? ut : st.v[a.n - 1];
             q_tail = q_tail + c * ut;
@@ -891,18 +918,17 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
             // its four sums in one reduction: ranks that take different paths still exchange the same sequence)
             if (a.owl) break;
             double t2[2] = {acc[0], acc[1]};
-            res_exchange<2>(t2, red, tag, ptag, parity, lds, s_tot, s_bits);
+            res_exchange<2, TOUCH>(t2, red, tag, ptag, parity, lds, s_tot, s_bits, sink, xacc, touch_for(si));
             acc[0] = t2[0];
             acc[1] = t2[1];
         } else {
             double t1[1] = {acc[0]};
-            res_exchange<1>(t1, red, tag, ptag, parity, lds, s_tot, s_bits);
+            res_exchange<1, TOUCH>(t1, red, tag, ptag, parity, lds, s_tot, s_bits, sink, xacc, touch_for(si + 1));
             dot = t1[0];
         }
         tag = next_epoch(tag);
         ptag = next_epoch(ptag);
         parity ^= 1;
-        if constexpr (PF == 1) { if (si + 1 < a.nsteps) prefetch(si + 1); }
     }
 
     // ---- OWL-QN: d has been written by the last step (res_step WO = 2); what is left: the odd element and the hand-off of
@@ -916,19 +942,17 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
             a.d[a.n - 1] = q_tail;
         }
         double t4[4] = {acc[0], 0.0, acc[2], acc[3]};  // (the layout of ops.h VMODE 3: slot 1 is unused there too)
-        res_exchange<4>(t4, red, tag, ptag, parity, lds, s_tot, s_bits);
+        res_exchange<4, TOUCH>(t4, red, tag, ptag, parity, lds, s_tot, s_bits, sink, xacc, touch_for(a.nsteps));
         tag = next_epoch(tag);
         ptag = next_epoch(ptag);
         acc[0] = t4[0];
         acc[1] = t4[2];
         acc[2] = t4[3];
     } else {
-        if constexpr (LH_RES_PLAIN_WO == 0) {
-            ResGroups<0, NG, NT, 0>::store(b_first, b_stride, a.d);
-            for (uint32_t e = 0; e < EL; ++e) {
-                const uint32_t p = p_first + (ER + e) * p_stride;
-                if (p < n2) st16<NT>(a.d, p, q_lds[(size_t)e * BLOCK + tid]);
-            }
+        ResGroups<0, NG, NT, 0>::store(b_first, b_stride, a.d);
+        for (uint32_t e = 0; e < EL; ++e) {
+            const uint32_t p = p_first + (ER + e) * p_stride;
+            if (p < n2) st16<NT>(a.d, p, q_lds[(size_t)e * BLOCK + tid]);
         }
         if (tail_owner) a.d[a.n - 1] = q_tail;
     }
@@ -940,7 +964,15 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         if (a.owl) { outv[1] = 0.0; outv[2] = acc[1]; outv[3] = acc[2]; }
         for (int k = 0; k < nout; ++k) a.out_dn[k] = outv[k];
         red.ctr->red_epoch = tag;  // every workgroup has left the last hand-off with `tag - 1`: nobody reads the counter again
-        if (red.p2p.world > 1) red.ctr->p2p_epoch = ptag;
+        if (red.p2p.world > 1) {
+            red.ctr->p2p_epoch = ptag;
+            DevXchg* const xs = dev_xchg(red.ctr, 1u);  // (this kernel's exchanges all belong to a two-loop)
+            DevXchg x = *xs;
+            x.p2p_ticks += xacc.p2p_ticks;
+            x.local_ticks += xacc.local_ticks;
+            x.count += xacc.count;
+            *xs = x;
+        }
         if (red.mirror.host_board) {
             const long i0 = a.out_dn - red.mirror.board;
             if (i0 >= 0 && i0 + nout - 1 < red.mirror.slots) {

@@ -90,6 +90,21 @@ struct DevCounters {
     unsigned long long mirror_seq;  // sequence number of the LATEST mirrored launch
 };
 __device__ __forceinline__ unsigned int next_epoch(unsigned int e) { return (e + 1u == 0u) ? 1u : e + 1u; }
+// Run-time figures of the cross-rank exchange (world > 1 only), kept in the same device page as the counters, 64 bytes
+// in: what the ONE workgroup that closes a reduction across ranks spent doing so, in wall-clock ticks (100 MHz).  Two
+// classes: [0] every exchange outside a two-loop recursion, [1] the exchanges inside one (the 2*bound dependent ones the
+// 8-GPU run's latency budget is made of).  Kernels run one after the other on the context's stream and one workgroup per
+// kernel updates them, so a plain read-modify-write suffices.  lbfgs_hip_ctx_comm_info reads them.
+struct DevXchg {
+    unsigned long long p2p_ticks;    // inside p2p_exchange: publish to every peer + wait for every peer's values
+    unsigned long long local_ticks;  // before that: the exchanging workgroup waiting for this GPU's other workgroups
+    unsigned long long count;        // exchanges
+    unsigned long long _pad;
+};
+constexpr int DEV_XCHG_OFFSET = 64;  // bytes from the start of the counters' page
+__device__ __forceinline__ DevXchg* dev_xchg(DevCounters* ctr, const unsigned int cls) {
+    return reinterpret_cast<DevXchg*>(reinterpret_cast<char*>(ctr) + DEV_XCHG_OFFSET) + (cls & 1u);
+}
 
 struct RedCtl {
     double* partials;        // [MAX_RED][MAX_GRID] workgroup partial sums   (ticket hand-off: more than RED_PTRS sums)
@@ -101,6 +116,7 @@ struct RedCtl {
                                   //     exits; nobody waits.  The consumer -- the next kernel on the stream -- adds them up
                                   //     itself in its prologue (sum_partials below), in the reducer's order.
     unsigned int* err;            // device error flag (2 = a partial never arrived)
+    unsigned int xchg_class;      // world > 1: which DevXchg record this launch's exchange is charged to (1 = inside a two-loop)
     unsigned long long timeout_ticks;  // bound on the reducer's spin (wall_clock64 ticks, 100 MHz)
     double* out[RED_PTRS];   // where the last workgroup puts the totals (NRED <= RED_PTRS) ...
     double* out_contig;      // ... or one contiguous array of NRED doubles (NRED > RED_PTRS)
@@ -287,6 +303,7 @@ __device__ __forceinline__ void grid_reduce(double (&acc)[NRED], const RedCtl& r
     double tot[NRED];
     const bool tagged = NRED <= RED_PTRS && red.tagged == 1u;  // (uniform over the grid)
     const unsigned int epoch = c0.red_epoch;   // (the reducer advances the counter only after every partial has arrived)
+    long long t0 = 0;                          // when the reducer started waiting for the others (tagged form)
     if (tagged) {
         // ---- tagged hand-off ----
         if (threadIdx.x == 0) {
@@ -301,7 +318,7 @@ __device__ __forceinline__ void grid_reduce(double (&acc)[NRED], const RedCtl& r
         }
         if (blockIdx.x != G - 1u) return;  // uniform per workgroup
         __syncthreads();                   // lds is reused below
-        const long long t0 = wall_clock64();
+        t0 = wall_clock64();
 #pragma unroll
         for (int k = 0; k < NRED; ++k) tot[k] = 0.0;
         for (unsigned int b = threadIdx.x; b < G; b += BLOCK) {  // same order as the ticket form: b strided by BLOCK
@@ -359,11 +376,23 @@ __device__ __forceinline__ void grid_reduce(double (&acc)[NRED], const RedCtl& r
             for (int k = 0; k < NRED; ++k) s_vals[k] = tot[k];
         }
         __syncthreads();
+        // (DevXchg: the record is loaded before the exchange -- its latency hides behind the peers' -- and stored after it)
+        DevXchg* const xs = dev_xchg(red.ctr, red.xchg_class);
+        DevXchg x{};
+        long long t1 = 0;
+        if (threadIdx.x == 0) {
+            x = *xs;
+            t1 = wall_clock64();
+        }
         p2p_exchange(red.p2p, c0.p2p_epoch, s_vals, NRED, s_bits);
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int k = 0; k < NRED; ++k) tot[k] = s_vals[k];
             red.ctr->p2p_epoch = next_epoch(c0.p2p_epoch);
+            x.p2p_ticks += (unsigned long long)(wall_clock64() - t1);
+            if (tagged) x.local_ticks += (unsigned long long)(t1 - t0);
+            x.count += 1ull;
+            *xs = x;
         }
     }
     if (threadIdx.x == 0) {

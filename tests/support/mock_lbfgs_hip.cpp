@@ -29,7 +29,9 @@ struct lbfgs_hip_ctx {
     void* cb_user = nullptr;
     double board[LBFGS_HIP_BOARD_SLOTS + 2] = {0};
     std::string err;
-    uint64_t n_allreduce = 0;
+    uint64_t n_allreduce = 0, n_two_loop = 0, n_two_loop_allreduce = 0;
+    bool in_two_loop = false;
+    uint64_t n_gram = 0;
 };
 struct lbfgs_hip_vec {
     lbfgs_hip_ctx* ctx;
@@ -54,6 +56,7 @@ size_t nl(const lbfgs_hip_ctx* c) { return (size_t)c->shard.n_local; }
 int allreduce(lbfgs_hip_ctx* c, double* v, int count) {
     if (c->comm_kind == LBFGS_HIP_COMM_NONE) return LBFGS_HIP_OK;
     c->n_allreduce += 1;
+    if (c->in_two_loop) c->n_two_loop_allreduce += 1;
     if (c->cb(c->cb_user, v, count) != 0) return fail(c, LBFGS_HIP_ERR_COMM, "all-reduce callback failed");
     return LBFGS_HIP_OK;
 }
@@ -282,6 +285,11 @@ int lbfgs_hip_two_loop_unfused(lbfgs_hip_history* h, lbfgs_hip_vec* d, uint64_t 
 }
 int lbfgs_hip_two_loop(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end, int gn,
                        int gd, int dn, int* new_end) {
+    struct Scope {  // (lbfgs_hip_ctx_comm_info: all-reduces inside a two-loop are counted apart)
+        lbfgs_hip_ctx* c;
+        explicit Scope(lbfgs_hip_ctx* cc) : c(cc) { c->n_two_loop += 1; c->in_two_loop = true; }
+        ~Scope() { c->in_two_loop = false; }
+    } scope(h->ctx);
     oracle_vecncpy(d->p->data(), g->p->data(), nl(h->ctx));
     int rc = lbfgs_hip_two_loop_unfused(h, d, k, end, gn, gd, new_end);
     if (rc != 0) return rc;
@@ -305,7 +313,16 @@ int lbfgs_hip_two_loop_owlqn(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs
 
 int lbfgs_hip_two_loop_gram(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end, int gn,
                             int gd, int dn, int* new_end) {
-    return lbfgs_hip_two_loop(h, d, g, k, end, gn, gd, dn, new_end);  // the test double has one recursion
+    const int rc = lbfgs_hip_two_loop(h, d, g, k, end, gn, gd, dn, new_end);  // the test double has one recursion
+    // the coefficient-space prediction of ||d||^2 (include/lbfgs_hip.h): exact here -- unless a test asks for a direction
+    // that fails its check (LBFGS_MOCK_VF_BAD = every k-th call, counted per context)
+    h->ctx->board[dn + 2] = h->ctx->board[dn];
+    if (const char* e = getenv("LBFGS_MOCK_VF_BAD")) {
+        const int every = atoi(e);
+        h->ctx->n_gram += 1;
+        if (every > 0 && h->ctx->n_gram % (uint64_t)every == 0) h->ctx->board[dn + 2] = 2.0 * h->ctx->board[dn] + 1.0;
+    }
+    return rc;
 }
 
 int lbfgs_hip_owlqn_post_eval(const lbfgs_hip_vec* x, const lbfgs_hip_vec* g, lbfgs_hip_vec* pg, double cc,
@@ -360,6 +377,20 @@ static int eval_obj(const lbfgs_hip_objective* obj, lbfgs_hip_ctx* c, const doub
     return LBFGS_HIP_OK;
 }
 int lbfgs_hip_path_stats(lbfgs_hip_ctx*, uint64_t* r, uint64_t* e) { if (r) *r = 0; if (e) *e = 0; return LBFGS_HIP_OK; }
+int lbfgs_hip_ctx_comm_info(lbfgs_hip_ctx* c, lbfgs_hip_comm_info* out) {
+    if (!c || !out) return LBFGS_HIP_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    out->kind = c->comm_kind;
+    out->world = c->shard.world;
+    out->rank = c->shard.rank;
+    out->ranks_seen = c->comm_kind == LBFGS_HIP_COMM_NONE ? 1 : 0;  // (callback: the library sees no peer itself)
+    out->rank_seen = c->shard.rank;
+    out->mailbox_placement = -1;
+    out->two_loops = c->n_two_loop;
+    out->two_loop_exchanges = c->n_two_loop_allreduce;
+    out->allreduce_launches = c->n_allreduce;
+    return LBFGS_HIP_OK;
+}
 int lbfgs_hip_lj_cells_stats(lbfgs_hip_ctx*, uint64_t* rebuilds, uint64_t* evaluations, uint32_t* longest) {
     if (rebuilds) *rebuilds = 0;
     if (evaluations) *evaluations = 0;

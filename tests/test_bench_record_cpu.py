@@ -1,0 +1,123 @@
+"""The bench record's evidence fields (round 4): roofline.traffic is keyed to the REAL shard sizes and to the build that was
+profiled; the N > 1 line says what its communicator spanned, what an exchange cost and carries the CPU baseline.
+CPU only (the rank processes of the supervisor tests run on the test double of the C-ABI)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+import rust_lbfgs_amd  # noqa: E402,F401
+from rust_lbfgs_amd import _build  # noqa: E402
+from rust_lbfgs_amd.dist import shard_range  # noqa: E402
+
+RESIDENT = "two_loop_resident_kernel<ER,NT>"
+
+
+def _write(d, name, **kw):
+    rec = dict(kernel="two_loop_resident_kernel", n_local=12500224, m=10, traffic_bytes_per_launch=4.1e9, _source="test")
+    rec.update(kw)
+    with open(os.path.join(d, name), "w") as f:
+        json.dump(rec, f)
+
+
+def test_traffic_lookup_is_strict_about_size_m_and_kernel(tmp_path):
+    d = str(tmp_path)
+    _write(d, "pmc_traffic_a.json", n_local=12500000, build_id="aaaa")
+    assert bench.traffic_lookup(12500224, 10, RESIDENT, build_id="aaaa", profiles_dir=d) == {}
+    _write(d, "pmc_traffic_b.json", n_local=12500224, m=7, build_id="aaaa")
+    assert bench.traffic_lookup(12500224, 10, RESIDENT, build_id="aaaa", profiles_dir=d) == {}
+    _write(d, "pmc_traffic_c.json", kernel="stream_kernel", build_id="aaaa")
+    assert bench.traffic_lookup(12500224, 10, RESIDENT, build_id="aaaa", profiles_dir=d) == {}
+    _write(d, "pmc_traffic_d.json", build_id="aaaa")
+    got = bench.traffic_lookup(12500224, 10, RESIDENT, build_id="aaaa", profiles_dir=d)
+    assert got["traffic"] == pytest.approx(4.1) and got["traffic_is_current"] is True and got["traffic_build_id"] == "aaaa"
+    assert got["traffic_file"].endswith("pmc_traffic_d.json")
+
+
+def test_traffic_lookup_names_a_stale_build_and_prefers_the_current_one(tmp_path):
+    d = str(tmp_path)
+    _write(d, "pmc_traffic_old.json", build_id="0ld0", traffic_bytes_per_launch=9e9)
+    got = bench.traffic_lookup(12500224, 10, RESIDENT, build_id="new1", profiles_dir=d)
+    assert got["traffic_is_current"] is False and got["traffic_build_id"] == "0ld0" and got["loaded_build_id"] == "new1"
+    _write(d, "pmc_traffic_zz_unstamped.json")  # a file from before the ids existed: never "current"
+    _write(d, "pmc_traffic_new.json", build_id="new1", traffic_bytes_per_launch=4e9)
+    got = bench.traffic_lookup(12500224, 10, RESIDENT, build_id="new1", profiles_dir=d)
+    assert got["traffic_is_current"] is True and got["traffic"] == pytest.approx(4.0)
+
+
+# (while kernels are being changed within a round the committed counter passes lag behind the sources; the marks below are
+# removed by the commit that re-takes them -- tools/profile_round.sh at DIM = 1e8, 50000128, 25000192, 12500224)
+EVIDENCE_PENDING = pytest.mark.xfail(reason="counter passes of this build not taken yet", strict=False)
+
+
+@EVIDENCE_PENDING
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_every_rank0_shard_of_the_metric_has_a_current_traffic_file(world):
+    """BASELINE.json's metric at 1 / 2 / 4 / 8 GPUs: the rank-0 shard sizes are 1e8, 50 000 128, 25 000 192 and 12 500 224
+    elements (dist.shard_range rounds to 256), and each must find committed counter passes taken at exactly that size with
+    the build of this checkout -- otherwise a SCALE line would carry `traffic: null` (or a figure of another build)."""
+    lo, hi = shard_range(100_000_000, 0, world)
+    assert hi - lo == {1: 100_000_000, 2: 50_000_128, 4: 25_000_192, 8: 12_500_224}[world]
+    got = bench.traffic_lookup(hi - lo, 10, RESIDENT, build_id=_build.hip_build_id())
+    assert got.get("traffic"), f"no profiles/pmc_traffic*.json for n_local={hi - lo}, m=10 (tools/profile_round.sh)"
+    assert got["traffic_is_current"], (f"{got['traffic_file']} was taken with build {got['traffic_build_id']}, the checked-out "
+                                       f"sources hash to {_build.hip_build_id()}: re-take it (tools/profile_round.sh)")
+    # the traffic is within 2 % of the kernel's byte model (4m+1 passes over the on-chip elements, 8m-1 over the rest)
+    pm = json.load(open(os.path.join(ROOT, got["traffic_file"])))
+    if pm.get("algorithmic_bytes_per_launch"):
+        assert abs(pm["traffic_bytes_per_launch"] / pm["algorithmic_bytes_per_launch"] - 1.0) < 0.02
+
+
+@EVIDENCE_PENDING
+def test_every_traffic_file_names_its_build():
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_traffic*.json")))
+    assert files
+    for path in files:
+        pm = json.load(open(path))
+        assert pm.get("build_id"), f"{path} does not say which build it was taken with"
+
+
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("launcher", [False, True], ids=["plain_python", "torch_distributed_run"])
+def test_the_n_gt_1_line_is_attributable(launcher):
+    """The supervisor's line carries the CPU baseline (timed beside the legs), and per leg what the communicator spanned
+    and how many exchanges a two-loop made (on the test double: the callback communicator, 2*bound + 2 all-reduces)."""
+    env = dict(os.environ, LBFGS_BENCH_WORKER=os.path.join(ROOT, "tests", "support", "bench_on_mock.py"), OMP_NUM_THREADS="1")
+    args = ["--gpus", "2", "--steps", "4", "--warmup", "12", "--dim", "3000", "--hist", "5", "--repeats", "2", "--no-vector-free",
+            "--comm", "callback"]
+    if launcher:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    j = json.loads(lines[0])
+    cb = j["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] == 1 and cb["kind"] == "port" and "supervisor" in cb["where"]
+    ci = j["config"]["comm_info"]
+    assert ci["kind"] == "callback" and ci["world"] == 2 and ci["rank"] == 0
+    leg = j["config"]["legs"]["callback"]
+    # m = 5, history full: the test double's unfused recursion closes 2*bound dots, then ||d||^2 and g.d one by one
+    assert leg["exchanges_per_two_loop"] == pytest.approx(2 * 5 + 2)
+    assert j["roofline"]["exchanges_per_two_loop"] == pytest.approx(12.0)
+    assert "exchange_us_mean" in j["roofline"] and "ranks_seen" in leg

@@ -374,3 +374,11 @@ def test_bench_p2p_leg_with_the_persistent_kernel(tmp_path):
     r = j["roofline"]
     assert r["kernel"].startswith("two_loop_resident_kernel") and 0 < r["resident_elements"] < j["config"]["n_local_rank0"]
     assert "self-test" not in p.stderr
+    # round 4: the line is attributable -- what the communicator spanned, what an exchange cost (measured on the device by
+    # workgroup 0 of the persistent kernel), how many exchanges a two-loop made, and the CPU baseline on an N > 1 line
+    leg, ci = j["config"]["legs"]["p2p"], j["config"]["comm_info"]
+    assert leg["ranks_seen"] == 2 and ci["kind"] == "p2p" and ci["peers_device"] == 1 and ci["mailbox_placement"] == "device"
+    assert leg["exchanges_per_two_loop"] == pytest.approx(20.0)       # m = 10, history full: one exchange per hand-off
+    assert 0.0 < leg["exchange_us_mean"] < 1000.0 and r["exchange_us_mean"] == leg["exchange_us_mean"]
+    assert leg["local_wait_us_mean"] is not None and r["exchanges_per_two_loop"] == pytest.approx(20.0)
+    assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] == 1

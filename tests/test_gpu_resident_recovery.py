@@ -64,6 +64,140 @@ def test_a_resident_launch_that_loses_a_workgroup_is_rerun_per_step(owl, monkeyp
     assert err.count("timed out waiting for a workgroup") == 1, err
 
 
+def test_a_mis_detected_chip_costs_milliseconds_not_the_full_timeout(monkeypatch, capfd):
+    """Until a resident launch of a context has been SEEN to complete, its hand-offs wait 50 ms at most
+    (LBFGS_HIP_RESIDENT_FIRST_TIMEOUT_MS): a device that cannot hold the grid resident (partitioned, shared, CU-masked in a way
+    the probes miss) falls back to the kernel-per-step path after milliseconds.  Here: the default 10 s hand-off timeout is left
+    alone, the first launch loses a workgroup -- and the whole run, fallback included, must take a fraction of that."""
+    import time
+
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs the GPU")
+    n, m, iters = 300_007, 5, 12
+    monkeypatch.setenv("LBFGS_HIP_RESIDENT_FAULT", "1")
+    monkeypatch.delenv("LBFGS_HIP_HANDOFF_TIMEOUT_MS", raising=False)
+    rows_o, xo = run_oracle(n, m, iters)
+    with R.Context(n) as ctx:
+        t0 = time.perf_counter()
+        rows_g, xg = run_device(ctx, n, m, iters)
+        wall = time.perf_counter() - t0
+        resident, info = ctx.resident_two_loops(), ctx.comm_info()
+    close(rows_o, rows_g, xo, xg)
+    assert resident == 1 and info["resident_fallbacks"] == 1
+    assert wall < 3.0, wall  # (10 s with the configured timeout)
+    assert capfd.readouterr().err.count("timed out waiting for a workgroup") == 1
+
+
+def test_the_configured_timeout_applies_once_a_resident_launch_has_completed(monkeypatch):
+    """... and once a resident launch HAS completed, the context is trusted with the configured timeout: a later launch that
+    loses a workgroup waits that long (here 400 ms: longer than the first-launch bound, short enough for a test)."""
+    import time
+
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs the GPU")
+    n, m = 300_007, 4
+    monkeypatch.setenv("LBFGS_HIP_HANDOFF_TIMEOUT_MS", "400")
+    monkeypatch.setenv("LBFGS_HIP_RESIDENT_FAULT", "2")  # (the SECOND resident launch of the context loses a workgroup)
+    with R.Context(n) as ctx:
+        hist, g, d = _history_with_pairs(ctx, m)
+        hist.two_loop(d, g, m, m - 1, 7, 8, 12)
+        ref_dn = ctx.scalars(12, 2).copy()      # (this read proves the launch)
+        assert ctx.resident_two_loops() == 1
+        t0 = time.perf_counter()
+        hist.two_loop(d, g, m, m - 1, 7, 8, 12)
+        dn = ctx.scalars(12, 2).copy()
+        wall = time.perf_counter() - t0
+        assert 0.35 < wall < 3.0, wall
+        assert ctx.comm_info()["resident_fallbacks"] == 1
+        np.testing.assert_allclose(dn, ref_dn, rtol=1e-12)
+        hist.free(); g.free(); d.free()
+
+
+def _history_with_pairs(ctx, m):
+    """m corrections with y = A s of the hashed quadratic (ys > 0), and a gradient: inputs of a two-loop, all on the device"""
+    from rust_lbfgs_amd import hotpath as H
+    from rust_lbfgs_amd.math import DeviceVec
+
+    hist = H.History(ctx, m)
+    g, d, tmp = DeviceVec(ctx), DeviceVec(ctx), DeviceVec(ctx)
+    q = objectives.Quadratic()
+    for j in range(m):
+        tmp.fill(0.25 + 0.1 * j)
+        H.objective_eval(q, tmp, hist.s(j), 0)
+        H.objective_eval(q, hist.s(j), hist.y(j), 0)
+        hist.y(j).vecadd(hist.s(j), 2.0)
+    ys = [hist.y(j).vecdot(hist.s(j)) for j in range(m)]
+    hist.set_scalars(ys=np.array(ys), alpha=np.zeros(m))
+    tmp.fill(-0.3)
+    H.objective_eval(objectives.Logistic(), tmp, g, 0)
+    ctx.set_scalars(7, [ys[m - 1], hist.y(m - 1).vecdot(hist.y(m - 1))])
+    tmp.free()
+    return hist, g, d
+
+
+@pytest.mark.parametrize("first", ["download", "history_scalars", "sync"])
+def test_every_synchronising_entry_point_recovers_from_a_timed_out_resident_launch(first, monkeypatch, capfd):
+    """Round-3 advice: the recovery used to live in lbfgs_hip_scalars_read only, so a caller of the C-ABI that downloaded d (or
+    read alpha, or just synchronised) FIRST got the aborted kernel's output with rc = OK.  Now every entry point that hands
+    results of the stream to the host looks at the device error word: the direction downloaded right after a resident launch
+    that lost a workgroup is the kernel-per-step path's, to the last bit of what that path gives on the same inputs."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs the GPU")
+    n, m = 300_007, 5
+    monkeypatch.setenv("LBFGS_HIP_RESIDENT", "0")
+    with R.Context(n) as ctx:
+        hist, g, d = _history_with_pairs(ctx, m)
+        hist.two_loop(d, g, m, m - 1, 7, 8, 12)
+        ref_d, ref_dn, ref_alpha = d.to_numpy(), ctx.scalars(12, 2).copy(), hist.scalars()[1].copy()
+        hist.free(); g.free(); d.free()
+    monkeypatch.setenv("LBFGS_HIP_RESIDENT", "1")
+    monkeypatch.setenv("LBFGS_HIP_RESIDENT_FAULT", "1")
+    with R.Context(n) as ctx:
+        hist, g, d = _history_with_pairs(ctx, m)
+        hist.two_loop(d, g, m, m - 1, 7, 8, 12)
+        assert ctx.resident_two_loops() == 1
+        if first == "download":
+            got_d = d.to_numpy()
+        elif first == "history_scalars":
+            got_alpha = hist.scalars()[1].copy()
+            np.testing.assert_array_equal(got_alpha, ref_alpha)
+            got_d = d.to_numpy()
+        else:
+            ctx.sync()
+            got_d = d.to_numpy()
+        np.testing.assert_array_equal(got_d, ref_d)
+        np.testing.assert_array_equal(ctx.scalars(12, 2), ref_dn)
+        assert ctx.comm_info()["resident_fallbacks"] == 1
+        hist.free(); g.free(); d.free()
+    assert capfd.readouterr().err.count("timed out waiting for a workgroup") == 1
+
+
+@pytest.mark.parametrize("change", ["upload_g", "write_gamma", "write_ys"])
+def test_inputs_changed_after_a_resident_launch_are_never_silently_re_used(change, monkeypatch):
+    """... and the recovery re-runs the recursion on its INPUTS: a call that changes one of them after the launch (an upload
+    into g, a write of the gamma slots, of ys) withdraws the permission to re-run -- the timed-out launch then surfaces as the
+    error it is instead of a recomputation from other inputs."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs the GPU")
+    n, m = 300_007, 5
+    monkeypatch.setenv("LBFGS_HIP_RESIDENT_FAULT", "1")
+    ctx = R.Context(n)
+    try:
+        hist, g, d = _history_with_pairs(ctx, m)
+        hist.two_loop(d, g, m, m - 1, 7, 8, 12)
+        if change == "upload_g":
+            g.upload(np.ones(n))
+        elif change == "write_gamma":
+            ctx.set_scalars(7, [1.0, 2.0])
+        else:
+            hist.set_scalars(ys=np.ones(m))
+        with pytest.raises(R.LbfgsError, match="timed out waiting for a workgroup"):
+            ctx.scalars(12, 2)
+        assert ctx.comm_info is not None
+    finally:
+        ctx.close()
+
+
 def test_two_contexts_on_two_streams_of_one_gpu(monkeypatch):
     """Two independent optimisations in ONE process, each with its own context and stream, both eligible for the
     chip-wide kernel, driven from two threads at the same time.  Whatever the dispatcher does with two kernels that each
@@ -110,6 +244,8 @@ KNOBS = [
     {"LBFGS_HIP_HANDOFF": "ticket"},                      # arrival-counter reductions (the persistent kernel is not eligible)
     {"LBFGS_HIP_NO_MIRROR": "1"},                         # scalar reads by copy
     {"LBFGS_HIP_RESIDENT_NT_MB": "100000"},               # the persistent kernel without `nt` hints
+    {"LBFGS_HIP_RESIDENT_TOUCH": "0"},                    # the waiting workgroups touch (next to) nothing ahead
+    {"LBFGS_HIP_RESIDENT_TOUCH": "16"},                   # ... the deepest touch, whatever the shard size
 ]
 
 

@@ -374,3 +374,35 @@ def test_random_configurations_match_oracle_exactly(seed):
     for a, b in zip(ro, rp):
         assert np.array_equal(np.array(a, dtype=np.float64), np.array(b, dtype=np.float64), equal_nan=True), (c, a, b)
     assert np.array_equal(xo, xp, equal_nan=True), c
+
+
+@pytest.mark.parametrize("owl", [False, True], ids=["lbfgs", "owlqn"])
+def test_vector_free_direction_that_fails_its_check_is_redone_exactly(owl, monkeypatch):
+    """EXTENSION guard (solver.cpp): when the ||d||^2 the Gram arithmetic predicts is not the ||d||^2 of the direction itself,
+    that iteration's direction is formed again by the exact recursion and counted.  The test double is told to mispredict
+    every third vector-free two-loop: the run must be the exact run, bit for bit, with the fallbacks counted."""
+    def configure(b, vf):
+        b = b.with_m(5).with_epsilon(0.0).with_max_iterations(20)
+        if owl:
+            b = b.with_orthantwise(0.25, 2, None)
+        return b.with_vector_free(vf) if vf else b
+
+    def run(vf):
+        x, rows = np.linspace(-1.0, 2.0, 40), []
+        st = configure(R.lbfgs(), vf).build(x, R.default_evaluate())
+        for _ in range(15):
+            p = st.propagate()
+            rows.append((p.fx, p.gnorm, p.step, p.ncall))
+        fb, xs = st.vector_free_fallbacks(), st.download("x")
+        st.close()
+        return rows, xs, fb
+
+    exact_rows, exact_x, fb0 = run(False)
+    assert fb0 == 0
+    monkeypatch.setenv("LBFGS_MOCK_VF_BAD", "3")
+    rows, x, fb = run(True)
+    assert rows == exact_rows and np.array_equal(x, exact_x)
+    assert fb == 14 // 3  # (15 propagate calls: the first is the reference's no-op, 14 two-loops, every third mispredicted)
+    monkeypatch.setenv("LBFGS_MOCK_VF_BAD", "0")
+    rows, x, fb = run(True)
+    assert rows == exact_rows and fb == 0

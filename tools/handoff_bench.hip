@@ -15,6 +15,8 @@
 //       broadcast, and, the point of it, no vector load in the polling path: a wave's vector loads return in order
 //       (vmcnt), so a vector poll cannot be read before every streaming load issued ahead of it has come back, while
 //       scalar loads are counted separately (lgkmcnt).
+//    3  round 3's form (resident.h today): DPP wave sums, a barrier between the publish and the polls;   4  ... one polling wave
+//    5  round 4: two levels with VECTOR polls -- per XCD (workgroup mod 8) by that XCD's leader, then the 8 XCD totals
 // K = 16-byte streaming loads per thread that are issued BEFORE the hand-off and consumed after it (resident.h: the window
 // of the next step's operands).  Every spin is bounded; a protocol that reads stale data ends with err != 0, not a hang.
 #include <hip/hip_runtime.h>
@@ -161,6 +163,43 @@ __device__ __forceinline__ double exchange(double x, const Args& a, const unsign
         __syncthreads();
         if constexpr (V == 3) return ((rows[4][0] + rows[4][1]) + rows[4][2]) + rows[4][3];
         return rows[4][0];
+    } else if constexpr (V == 5) {
+        // round 4: TWO LEVELS with vector polls -- the workgroups of an XCD (B mod 8) first, by wave 0 of that XCD's leader
+        // workgroup (32 polls instead of 256), then every workgroup's wave 0 reads the 8 XCD totals (8 polls).  256 x 256 polls
+        // become 8 x 32 + 256 x 8 -- but a total now takes two dependent trips through memory.
+        double w = wave_sum_dpp(x);
+        if (lane == 0) rows[0][wave] = w;
+        __syncthreads();
+        const double p = ((rows[0][0] + rows[0][1]) + rows[0][2]) + rows[0][3];
+        if (tid == 0) publish(a.part + ((size_t)parity * 256 + B) * 2, tag, p);
+        __syncthreads();
+        const unsigned X = 8u;
+        auto poll = [&](const unsigned long long* g, unsigned code) {
+            unsigned long long lo, hi;
+            unsigned spins = 0;
+            for (;;) {
+                lo = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hi = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag) break;
+                if (++spins > SPIN_MAX) { atomicExch(a.err, code); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            return __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffULL)));
+        };
+        if (B < X && wave == 0) {  // the leader of XCD B: its members are B, B + 8, B + 16, ...
+            double t = 0.0;
+            for (unsigned i = (unsigned)lane; B + X * i < G; i += 64u) t += poll(a.part + ((size_t)parity * 256 + B + X * i) * 2, 5u);
+            const double gs = wave_sum_dpp(t);
+            if (lane == 0) publish(a.grp + ((size_t)parity * 16 + B) * 2, tag, gs);
+        }
+        if (wave == 0) {
+            double t = 0.0;
+            if ((unsigned)lane < min(X, G)) t = poll(a.grp + ((size_t)parity * 16 + lane) * 2, 6u);
+            const double tt = wave_sum_dpp(t);
+            if (lane == 0) rows[4][0] = tt;
+        }
+        __syncthreads();
+        return rows[4][0];
     } else if constexpr (V == 2) {
         double w = wave_sum_dpp(x);
         if (lane == 0) rows[0][wave] = w;
@@ -277,8 +316,11 @@ void sweep(Args a, int grid, const char* mem, bool uc) {
     const double v3 = run<3, K>(a, grid, buf);
     snprintf(buf, sizeof(buf), "... only wave 0 polls (%s)", mem);
     const double v4 = run<4, K>(a, grid, buf);
+    snprintf(buf, sizeof(buf), "two levels, vector polls (%s)", mem);
+    const double v5 = run<5, K>(a, grid, buf);
     printf("   => visible cost of a hand-off with %2d loads in flight: round-2 %.2f, DPP/no barrier %.2f, scalar %.2f, DPP+barrier %.2f, "
-           "one polling wave %.2f us\n", K, v0 - base, v1 - base, v2 - base, v3 - base, v4 - base);
+           "one polling wave %.2f, two levels (per XCD, then 8 leaders) %.2f us\n", K, v0 - base, v1 - base, v2 - base, v3 - base, v4 - base,
+           v5 - base);
 }
 
 int main(int argc, char** argv) {

@@ -20,7 +20,7 @@ j = json.loads(open("gpurun_out/ht.json").read())
 r = j["roofline"]; tl = r.get("two_loop") or {}
 print(f"n={sys.argv[1]:>9} m={sys.argv[2]:>2} {sys.argv[3]:>9}: {j['value']:8.1f} it/s  kernel {(r.get('avg_ms') or 0)*1e3:7.1f} us = {r.get('achieved') or 0:5.0f} GB/s ({(r.get('frac') or 0)*100:4.1f} %)  two-loop {tl.get('ms', 0):.3f} ms", flush=True)
 PY
-  grep "res-trace" gpurun_out/ht.err || true
+  grep -E "res-(trace|skew)" gpurun_out/ht.err || true
 }
 IFS=";" read -ra CFGS <<< "${CONFIGS:-3000000 6;10000000 7;12500000 10}"   # "n m" pairs
 for cfg in "${CFGS[@]}"; do

@@ -3,7 +3,12 @@
 
     python tools/summarize_profile.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir> <n_local> <out.md> [tag] [m] [bench.json]
 (bench.json: the un-profiled line of the same command; its roofline.bytes_per_launch prices the resident kernel, whose
-on-chip share of q depends on the shard size)
+on-chip share of q depends on the shard size -- without it (tools/profile_configs.sh: other commands than bench.py) the
+resident kernel is priced as fully on-chip: 4m+1 passes, under OWL-QN too -- the fused write-out streams pg with the last step)
+
+Every pmc_traffic.json it writes names the build the passes were made with (LBFGS_HIP_BUILD_ID in the environment, else
+lbfgs_hip_build_id() of the in-tree library): bench.py reports roofline.traffic_build_id / traffic_is_current from it and
+tests/test_bench_record_cpu.py requires the committed files to belong to the checked-out sources.
 
 PMC handling follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE
 are collected in SEPARATE passes (TCC slots), both are in KiB; on gfx950 FETCH_SIZE reports exactly
@@ -32,6 +37,19 @@ PASSES = [
     (r"OpDot[,>]", (2, 0), "dot (dginit)"),
     (r"OpNorms2", (2, 0), "norms"),
     (r"OpCopy<", (1, 1), "copy / ncopy"),
+    # OWL-QN (config 3)
+    (r"OpObjOwlLineEval<", (3, 3), "OWL-QN trial: line step + projection + eval + x1norm + pseudo-gradient + g.d (orthantwise.rs:70-133)"),
+    (r"OpOrthantSelect", (2, 1), "orthant of the new point (core.rs:167-180)"),
+    (r"OpOwlPost", (2, 1), "x1norm + pseudo-gradient (orthantwise.rs:70-112)"),
+    (r"OpConstrainDir", (2, 1), "constrain_search_direction (orthantwise.rs:140-161)"),
+    (r"OpLineStep<", (2, 1), "take_line_step (core.rs:155-164)"),
+    # damping (config 5)
+    (r"OpDamp", (2, 1), "Powell damping case 1: y = (1-theta) bs + theta y (lbfgs.rs:675-680)"),
+    (r"OpAxpy[,>]", (2, 1), "axpy"),
+    (r"OpScale[,>]", (1, 1), "scale"),
+    (r"OpDiff", (2, 1), "diff"),
+    (r"OpNrm2", (1, 0), "squared norm"),
+    (r"OpFill", (0, 1), "fill"),
 ]
 
 
@@ -47,6 +65,9 @@ def short(name):
     if m:
         return "stream_kernel<" + m.group(1) + ">"
     m = re.search(r"(two_loop_resident_kernel<\d+, (true|false)(, (true|false))?>)", name)
+    if m:
+        return m.group(1)
+    m = re.search(r"lh::(lj_\w+)", name)
     return m.group(1) if m else name[:60]
 
 
@@ -126,6 +147,10 @@ def main():
             gb = resident_bytes / 1e9
             rwtxt = "(see left)"
             label += f"; {gb:.2f} GB = 4m+1 passes over the on-chip part of q, 8m-1 over the rest"
+        elif "two_loop_resident_kernel" in nm:
+            gb = (4 * M + 1) * 8 * n_local / 1e9
+            rwtxt = f"{4 * M}r+1w"
+            label += f"; {gb:.2f} GB = 4m+1 passes (all of q on the chip)"
         gbps = gb / (avg_us * 1e-6)
         fr = fetch.get(nm)
         wr = write.get(nm)
@@ -149,7 +174,22 @@ def main():
         kname = "stream_kernel<OpTwoLoopStep<*,false,0>>"
     if dom and dom[0] in write:
         rd, wr = fetch[dom[0]] * 1024 * 2, write[dom[0]] * 1024
-        json.dump({"_source": f"profiles/{tag}_pmc_fetch_counter_collection.csv + profiles/{tag}_pmc_write_counter_collection.csv "
+        build_id = os.environ.get("LBFGS_HIP_BUILD_ID")
+        if not build_id:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+            import rust_lbfgs_amd  # noqa: F401
+            from rust_lbfgs_amd import _build
+            build_id = _build.embedded_id(_build.HIP_LIB, "LBFGS_HIP_BUILD_ID")
+        full_us = None
+        for k, v in durs.items():
+            if k == dom[0] and v:
+                ref = sorted(v)[len(v) // 2]
+                fl = [x for x in v if abs(x - ref) <= 0.05 * ref]
+                full_us = sum(fl) / len(fl)
+        algo = resident_bytes if (resident_bytes and "resident" in kname) else (
+            (4 * M + 1) * 8 * n_local if "resident" in kname else 32 * n_local)
+        json.dump({"build_id": build_id, "algorithmic_bytes_per_launch": round(algo),
+                   "rocprof_avg_us_full_depth_launches": full_us,"_source": f"profiles/{tag}_pmc_fetch_counter_collection.csv + profiles/{tag}_pmc_write_counter_collection.csv "
                               "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python3 bench.py`, averaged over the "
                               "dispatches of the kernel; FETCH_SIZE x2: gfx950 correction of MI355X_MICROARCH.md section HBM; KiB)",
                    "kernel": kname, "n_local": n_local, "m": M,
