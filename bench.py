@@ -46,7 +46,16 @@ The JSON line carries, besides the contract fields:
                 stream over the timed region, against the 8 TB/s HBM peak;
   cpu_baseline  the CPU oracle (reference operation order, 1 thread) on the metric's own
                 configuration (n = 1e8, m = 10: 3 iterations after m+2 warm-up, ~22 GB of host memory) when
-                the host has the memory, with the sampled-and-scaled figure beside it; rank 0, N = 1 only.
+                the host has the memory, with the sampled-and-scaled figure beside it.  N = 1: a child of the
+                measuring process; N > 1: a child of rank 0's SUPERVISOR (which touches no GPU), timed beside the legs.
+and, so that an N > 1 line can be cross-checked and a scaling shortfall attributed (lbfgs_hip_ctx_comm_info):
+  config.comm_info / config.ranks_seen   what the communicator really spans: RCCL's own ncclCommCount (context creation
+                fails unless it equals the shard's world), or the P2P mailboxes rank 0 mapped and their placement;
+  roofline.exchange_us_mean, roofline.exchanges_per_two_loop, config.legs[leg].*   one cross-rank exchange inside a
+                two-loop as the device timed it (P2P: the exchanging workgroup's wall clock; RCCL: HIP events around
+                the all-reduce launches) and how many a two-loop made, over the timed regions only;
+  roofline.traffic_build_id / traffic_is_current   which build the committed counter passes behind `traffic` were made
+                with, and whether it is the build measuring now.
 """
 import argparse
 import json

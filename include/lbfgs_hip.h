@@ -275,11 +275,16 @@ int lbfgs_hip_two_loop_owlqn(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs
  * kernel runs lbfgs.rs:582-601 on 2m+1 coefficients, one pass forms d.  4m+3 passes and 2 all-reduces
  * instead of 8m+1 and 2m+1.  Mathematically identical; rounding differs (tests bound it by 1e-10 against
  * the exact recursion).  Requires that it is called after EVERY history update (the Gram matrix is
- * maintained incrementally) and m <= 10.  Same arguments and outputs as lbfgs_hip_two_loop, plus a run-time check of the
- * coefficient-space arithmetic: board[dnorm_slot+2] = ||d||^2 as the Gram entries PREDICT it (delta^T G delta; NaN if a
- * coefficient is not finite) next to board[dnorm_slot] = ||d||^2 summed over the direction itself.  When the two differ by
- * more than rounding (the solver: 1e-8 relative) the Gram entries have lost the digits the recursion needs -- a run that
- * blows up, or one converged to rounding level -- and the caller forms this direction again with lbfgs_hip_two_loop_from. */
+ * maintained incrementally) and m <= 10.  Same arguments and outputs as lbfgs_hip_two_loop, plus two figures by which the
+ * caller judges the coefficient-space arithmetic at run time (dnorm_slot must have 4 slots):
+ *   board[dnorm_slot+2] = ||d||^2 as the Gram entries PREDICT it (delta^T G delta; NaN if a coefficient is not finite), next
+ *                         to board[dnorm_slot] = ||d||^2 summed over the direction itself;
+ *   board[dnorm_slot+3] = the CANCELLATION of the recursion's running vector in the basis, max over its two turning points of
+ *                         sum_t ||b_t|| |delta_t| / ||sum_t delta_t b_t||: how many times more rounding error a dot product
+ *                         taken through Gram entries carries than the exact recursion's (NaN: no digits left).
+ * When they say that the Gram entries have lost the digits the recursion needs -- a run that blows up, one converged to
+ * rounding level, more history vectors than dimensions -- the caller forms this direction again with
+ * lbfgs_hip_two_loop_from (the solver: prediction off by > 1e-8, or cancellation > 1e4). */
 int lbfgs_hip_two_loop_gram(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
                             int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int* new_end);
 /* the same recursion as the reference's UNFUSED sequence of primitives (10*bound+2 passes);

@@ -1,6 +1,7 @@
 """Build the native libraries in-tree (they travel to the GPU box with the snapshot).
 
-  liblbfgs_hip.so     HIP kernels + the C-ABI of include/lbfgs_hip.h   (hipcc, gfx950)
+  liblbfgs_hip.so     HIP kernels + the C-ABI of include/lbfgs_hip.h   (hipcc, gfx950; three translation units:
+                      csrc/context.hip, csrc/lbfgs_hip.hip, csrc/lj.hip, sharing csrc/ctx.h)
   liblbfgs_solver.so  host orchestration of include/lbfgs_solver.h    (g++, links the former)
 
 hipcc cross-compiles for gfx950 without a GPU.  -ffp-contract=off on both sides: the
@@ -24,7 +25,10 @@ HIP_LIB = os.path.join(HERE, "liblbfgs_hip.so")
 SOLVER_LIB = os.path.join(HERE, "liblbfgs_solver.so")
 RESOURCES = os.path.join(HERE, "liblbfgs_hip.resources.txt")  # per-kernel register / scratch usage of the last build
 
-HIP_SRCS = [os.path.join(CSRC, f) for f in ("lbfgs_hip.hip", "ops.h", "stream.h", "gram.h", "lj.h", "resident.h", "gram_combine.h")] + [
+# the library's translation units (compiled one by one, in parallel, then linked) ...
+HIP_UNITS = [os.path.join(CSRC, f) for f in ("context.hip", "lbfgs_hip.hip", "lj.hip")]
+# ... and everything the build id covers: the units, the headers they share, the public header
+HIP_SRCS = HIP_UNITS + [os.path.join(CSRC, f) for f in ("ctx.h", "ops.h", "stream.h", "gram.h", "lj.h", "resident.h", "gram_combine.h")] + [
     os.path.join(ROOT, "include", "lbfgs_hip.h")
 ]
 SOLVER_SRCS = [os.path.join(CSRC, "host", "solver.cpp"), os.path.join(ROOT, "include", "lbfgs_solver.h"),
@@ -55,7 +59,7 @@ def embedded_id(lib, marker):
     return m.group(1).decode() if m else None
 
 
-HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",
              # (resident.h parks data in the accumulation registers by hand: the compiler must not spill into them)
              "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-Wall"]
 SOLVER_FLAGS = ["-O2", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall"]
@@ -111,25 +115,45 @@ def _audit_agprs(asm_text):
 LAST_BUILD = {}  # name -> "compiled" | "reused" (what build_all did this time; __graft_entry__.build() prints it)
 
 
+def _compile_hip(out_lib, flags, build_id):
+    """Compile every unit of HIP_UNITS (in parallel: one hipcc -c each, in a directory of its own so that -save-temps keeps
+    the device assembly apart) and link them into `out_lib`.  -> (the compiler's per-kernel resource report, the AGPR audit).
+    -Rpass-analysis=kernel-resource-usage: registers / scratch / occupancy of every kernel (tests/test_abi_exports.py requires
+    ScratchSize == 0 everywhere: a kernel that touches scratch memory pays ~12 us of extra dispatch cost per launch on
+    MI355X, measured).  -save-temps keeps the device assembly long enough to audit the resident kernels' AGPR usage."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    with tempfile.TemporaryDirectory(prefix="lbfgs_hip_build_") as tmp:
+        def one(unit):
+            d = os.path.join(tmp, os.path.basename(unit) + ".d")
+            os.makedirs(d)
+            obj = os.path.join(d, "unit.o")
+            r = _run([hipcc(), *flags, "-c", "-save-temps", "-Rpass-analysis=kernel-resource-usage",
+                      '-DLBFGS_HIP_BUILD_ID="%s"' % build_id, unit, "-o", obj], cwd=d)
+            asm = glob.glob(os.path.join(d, "*amdgcn*gfx950.s"))
+            if len(asm) != 1:
+                raise RuntimeError("build: expected one device assembly file for %s, found %r" % (unit, asm))
+            with open(asm[0]) as f:
+                return obj, r.stderr, f.read()
+
+        with ThreadPoolExecutor(max_workers=len(HIP_UNITS)) as ex:
+            results = list(ex.map(one, HIP_UNITS))
+        _run([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *[o for o, _, _ in results], "-o", out_lib, "-ldl", "-lrt"])
+        report = "".join(err for _, err, _ in results)
+        audit = {}
+        for _, _, asm in results:
+            audit.update(_audit_agprs(asm))
+    return report, audit
+
+
 def build_hip(force=False):
     want = hip_build_id()
     if force or _stale(HIP_LIB, "LBFGS_HIP_BUILD_ID", want) or not os.path.exists(RESOURCES):
-        # -Rpass-analysis=kernel-resource-usage: registers / scratch / occupancy of every kernel, kept next to the library
-        # (tests/test_abi_exports.py requires ScratchSize == 0 everywhere: a kernel that touches scratch memory pays
-        # ~12 us of extra dispatch cost per launch on MI355X, measured).  -save-temps keeps the device assembly long
-        # enough to audit the resident kernels' AGPR usage (same test).
-        with tempfile.TemporaryDirectory(prefix="lbfgs_hip_build_") as tmp:
-            r = _run([hipcc(), *HIP_FLAGS, "-save-temps", "-Rpass-analysis=kernel-resource-usage",
-                      '-DLBFGS_HIP_BUILD_ID="%s"' % want, HIP_SRCS[0], "-o", HIP_LIB, "-ldl", "-lrt"], cwd=tmp)
-            asm = glob.glob(os.path.join(tmp, "*amdgcn*gfx950.s"))
-            if len(asm) != 1:
-                raise RuntimeError("build: expected one device assembly file, found %r" % (asm,))
-            with open(asm[0]) as f:
-                audit = _audit_agprs(f.read())
+        report, audit = _compile_hip(HIP_LIB, HIP_FLAGS, want)
         if not audit:
             raise RuntimeError("build: no resident kernel found in the device assembly")
         with open(RESOURCES, "w") as f:
-            f.write(r.stderr)
+            f.write(report)
             f.write("\n# AGPR operands emitted by the compiler (outside inline asm) in the resident kernels\n")
             for k in sorted(audit):
                 f.write("agpr-audit: %s %d\n" % (k, audit[k]))
@@ -166,17 +190,12 @@ def build_variant(name, extra_flags):
     hip_lib, solver_lib = os.path.join(out, "liblbfgs_hip.so"), os.path.join(out, "liblbfgs_solver.so")
     flags = HIP_FLAGS + list(extra_flags)
     bid = source_hash(HIP_SRCS, flags)
-    with tempfile.TemporaryDirectory(prefix="lbfgs_hip_variant_") as tmp:
-        r = _run([hipcc(), *flags, "-save-temps", "-Rpass-analysis=kernel-resource-usage", '-DLBFGS_HIP_BUILD_ID="%s"' % bid,
-                  HIP_SRCS[0], "-o", hip_lib, "-ldl", "-lrt"], cwd=tmp)
-        asm = glob.glob(os.path.join(tmp, "*amdgcn*gfx950.s"))
-        with open(asm[0]) as f:
-            audit = _audit_agprs(f.read())
+    report, audit = _compile_hip(hip_lib, flags, bid)
     with open(os.path.join(out, "liblbfgs_hip.resources.txt"), "w") as f:
-        f.write(r.stderr)
+        f.write(report)
         for k in sorted(audit):
             f.write("agpr-audit: %s %d\n" % (k, audit[k]))
-    scratch = [ln for ln in r.stderr.splitlines() if "ScratchSize" in ln and not ln.rstrip().endswith(": 0 [-Rpass-analysis=kernel-resource-usage]")]
+    scratch = [ln for ln in report.splitlines() if "ScratchSize" in ln and not ln.rstrip().endswith(": 0 [-Rpass-analysis=kernel-resource-usage]")]
     bad = {k: v for k, v in audit.items() if v}
     if (scratch or bad) and not os.environ.get("LBFGS_VARIANT_ALLOW_BAD"):  # (experiments that will not RUN the bad kernels)
         raise RuntimeError("variant %s: scratch %r, compiler-placed AGPR operands %r" % (name, scratch[:3], bad))

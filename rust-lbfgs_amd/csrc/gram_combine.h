@@ -23,8 +23,8 @@ struct GramCombArgs {
     const double* in[GC_MAX_COLS];  // basis order; the last one is g
     double* d;
     const double* delta;            // nb coefficients (device: written by the scalar recursion kernel)
-    const double* pred;             // ||d||^2 as the coefficient-space arithmetic predicts it (gram_coef_kernel) ...
-    int lead;                       // ... which the thread that owns element 0 of the GLOBAL vector carries into a third "sum"
+    const double* pred;             // [2]: ||d||^2 as the coefficient-space arithmetic predicts it, its cancellation figure ...
+    int lead;                       // ... which the thread that owns element 0 of the GLOBAL vector carries into two more "sums"
                                     // (every other contribution is 0: the total is the prediction, bit for bit), so that it
                                     // reaches the board -- and the host mirror -- next to the ||d||^2 summed here
     uint64_t n;
@@ -97,7 +97,7 @@ void gram_combine_resident_kernel(const GramCombArgs a, const RedCtl red) {
     const uint32_t n2 = (uint32_t)(a.n >> 1);
     const uint32_t G = gridDim.x, B = blockIdx.x, tid = threadIdx.x;
     const uint32_t p_stride = G * BLOCK;
-    double acc[3] = {0.0, 0.0, 0.0};
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (uint32_t e_lo = 0; e_lo < a.total_rounds; e_lo += a.tile_rounds) {
         const uint32_t e_hi = min(e_lo + a.tile_rounds, a.total_rounds), rounds = e_hi - e_lo;
         // every round but the vector's last one is full: the register rounds carry no bounds checks, the rest go to LDS
@@ -163,8 +163,8 @@ void gram_combine_resident_kernel(const GramCombArgs a, const RedCtl red) {
         acc[1] += gl * q;
         a.d[a.n - 1] = q;
     }
-    if (a.lead && B == 0 && tid == 0) acc[2] = *a.pred;
-    grid_reduce<3>(acc, red, c0);
+    if (a.lead && B == 0 && tid == 0) { acc[2] = a.pred[0]; acc[3] = a.pred[1]; }
+    grid_reduce<4>(acc, red, c0);
 }
 
 

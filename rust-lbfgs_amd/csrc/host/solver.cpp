@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -874,17 +875,28 @@ int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
     bool exact = !st->vars.vector_free;
     if (st->vars.vector_free) {
         // EXTENSION: the recursion in coefficient space.  Its arithmetic works on Gram entries -- sums over whole vectors --
-        // and loses the digits the recursion needs when a run blows up or has converged to rounding level; nothing in the
-        // direction itself shows that.  The guard: the coefficient kernel predicts ||d||^2 = delta^T G delta from the same
-        // Gram entries, the combine pass sums the real ||d||^2; when the two differ by more than 1e-8 (or a coefficient is not
-        // finite) the coefficient-space arithmetic is not to be trusted and THIS iteration's direction is formed again by the
-        // exact recursion (lbfgs.rs:569-604).  The read below waits for the combine kernel the next read would wait for anyway.
+        // and loses the digits the recursion needs when its running vector is a small difference of large basis vectors: a
+        // run that blows up (y ~ g: q = -g + alpha*y cancels), one that has converged to rounding level, a history with
+        // more vectors than the problem has dimensions.  Nothing in the direction itself shows that, so the coefficient
+        // kernel reports two figures with it (include/lbfgs_hip.h): the ||d||^2 its Gram arithmetic PREDICTS, next to the
+        // ||d||^2 the combine pass sums over the direction itself, and the CANCELLATION of the running vector in the basis
+        // -- the factor by which a dot product taken through Gram entries carries more rounding error than the exact
+        // recursion's.  When the prediction is off by more than 1e-8, or the cancellation exceeds VF_MAX_CANCELLATION (the
+        // exact recursion's 1e-16 * 1e4 = 1e-12 still leaves the 1e-10 this path is held to), THIS iteration's direction is
+        // formed again by the exact recursion (lbfgs.rs:569-604) and counted.  The read below waits for the combine kernel
+        // the next read would wait for anyway.
+        constexpr double VF_MAX_CANCELLATION = 1e4;
         TRYB(st, lbfgs_hip_two_loop_gram(st->hist, st->d_next, st->grad_for_direction(), st->k - 1, st->end, S_UPD + 1,
                                          S_UPD + 2, S_DNORM2, &new_end));
-        double chk[3] = {0.0, 0.0, 0.0};
-        TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_DNORM2, 3, chk));
-        const double dn2 = chk[0], pred = chk[2];
-        if (!(std::fabs(pred - dn2) <= 1e-8 * std::fabs(dn2))) {  // (NaN on either side: not trusted)
+        double chk[4] = {0.0, 0.0, 0.0, 0.0};
+        TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_DNORM2, 4, chk));
+        const double dn2 = chk[0], pred = chk[2], cancel = chk[3];
+        const bool trusted = std::fabs(pred - dn2) <= 1e-8 * std::fabs(dn2) && cancel <= VF_MAX_CANCELLATION;  // (NaN: not trusted)
+        static const bool vf_trace = getenv("LBFGS_VF_TRACE") != nullptr;  // (diagnostics: one line per iteration)
+        if (vf_trace)
+            fprintf(stderr, "[lbfgs] vector-free k=%llu: ||d||^2 %.17g predicted %.17g (rel %.2e), cancellation %.3g -> %s\n",
+                    (unsigned long long)st->k, dn2, pred, std::fabs(pred - dn2) / std::fabs(dn2), cancel, trusted ? "kept" : "EXACT");
+        if (!trusted) {
             st->vector_free_fallbacks += 1;
             exact = true;
         }

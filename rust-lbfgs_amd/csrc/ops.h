@@ -244,7 +244,7 @@ struct GramCoef {
 template <int M>
 struct OpGramCombine {  // in[] in basis order; d = sum_j delta_j * b_j (ascending j); ||d||^2 ; g.d
     static constexpr int NB = 2 * M + 1;
-    static constexpr int NIN = NB, NOUT = 1, NRED = 3;
+    static constexpr int NIN = NB, NOUT = 1, NRED = 4;
     static constexpr int TUNE_MAP = 1, TUNE_UNROLL = 1;
     const double* in[NB];
     double* out[1];
@@ -264,7 +264,7 @@ struct OpGramCombine {  // in[] in basis order; d = sum_j delta_j * b_j (ascendi
         w[0] = q;
         acc[0] += q * q;
         acc[1] += v[NB - 1] * q;
-        if (gidx == 0) acc[2] += *pred;  // (element 0 of the global vector: one contribution in the whole job)
+        if (gidx == 0) { acc[2] += pred[0]; acc[3] += pred[1]; }  // (element 0 of the global vector: one contribution in the whole job)
     }
 };
 

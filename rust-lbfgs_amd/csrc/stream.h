@@ -83,7 +83,7 @@ struct MirrorCtl {
 // Launch-to-launch sequence numbers live in DEVICE memory, not in kernel arguments: every workgroup reads them when it
 // starts and the reducer (the last workgroup) advances them before the kernel ends -- stream order makes the next kernel
 // see the new values.  A kernel's arguments are then the same every time it is launched with the same operands, which
-// is what lets a whole two-loop recursion be replayed as a hipGraph.  The host keeps a shadow of each counter.
+// keeps launches free of host-computed sequence numbers (round 2 replayed whole recursions as hipGraphs on the strength of it).  The host keeps a shadow of each counter.
 struct DevCounters {
     unsigned int red_epoch;         // tag of the NEXT tagged hand-off: never 0, distinct from every tag still in `gran`
     unsigned int p2p_epoch;         // epoch of the NEXT P2P exchange: identical on all ranks, never 0

@@ -122,11 +122,27 @@ def scales(row, f0, g0):
     return (max(abs(row[3]), 1e-6 * f0), max(row[4], 1e-300), max(row[5], 1e-6 * g0), max(abs(row[6]), 1e-300))
 
 
+COVERAGE = {"cases": 0, "vacuous": 0, "truncated": 0, "rows": 0, "compared": 0, "loosest_tol": 0.0}
+
+
 def compare_with_oracle(c, ro, eo, rp, ep, floors, all_stable, slack=1.0):
     """The product's rows `rp` against the oracle's `ro` over the stable prefix: same discrete decisions, values within
-    max(1e-10, 20 x floor) x slack."""
+    max(1e-10, 20 x floor) x slack (1e-10 flat wherever the oracle's own scatter is below 5e-12).  What was actually compared
+    is returned and added up in COVERAGE: a case whose perturbed oracle runs part ways at once compares NOTHING (`vacuous`),
+    one that parts ways later is `truncated`; callers that sweep many seeds assert a cap on both (a sweep that quietly
+    stopped comparing would pass for ever)."""
     f0 = max(abs(ro[0][3]), 1e-3) if ro else 1.0
     g0 = max(ro[0][5], 1e-6) if ro else 1.0
+    cov = {"rows": len(ro), "compared": len(floors), "vacuous": bool(ro) and not floors, "truncated": 0 < len(floors) < len(ro),
+           "loosest_tol": max([max(1e-10, 20.0 * f) * slack for f in floors], default=0.0)}
+    COVERAGE["cases"] += 1
+    COVERAGE["vacuous"] += int(cov["vacuous"])
+    COVERAGE["truncated"] += int(cov["truncated"])
+    COVERAGE["rows"] += cov["rows"]
+    COVERAGE["compared"] += cov["compared"]
+    COVERAGE["loosest_tol"] = max(COVERAGE["loosest_tol"], cov["loosest_tol"])
+    if not floors and ro:  # nothing comparable: at least the first row's discrete decisions and the error code class must agree
+        assert (len(rp) > 0) == (len(ro) > 0), (c, "one side produced no iteration", eo, ep)
     for i, floor in enumerate(floors):
         a = ro[i]
         assert i < len(rp), (c, "the product stopped early", ep)
@@ -140,6 +156,7 @@ def compare_with_oracle(c, ro, eo, rp, ep, floors, all_stable, slack=1.0):
     if all_stable:
         assert ep == eo, (c, eo, ep)
         assert len(rp) == len(ro)
+    return cov
 
 
 def run_product(R, objectives, c):

@@ -317,6 +317,7 @@ int lbfgs_hip_two_loop_gram(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_
     // the coefficient-space prediction of ||d||^2 (include/lbfgs_hip.h): exact here -- unless a test asks for a direction
     // that fails its check (LBFGS_MOCK_VF_BAD = every k-th call, counted per context)
     h->ctx->board[dn + 2] = h->ctx->board[dn];
+    h->ctx->board[dn + 3] = 1.0;  // (no cancellation to report: the test double runs the exact recursion)
     if (const char* e = getenv("LBFGS_MOCK_VF_BAD")) {
         const int every = atoi(e);
         h->ctx->n_gram += 1;

@@ -195,7 +195,7 @@ def compare_sharded_fuzz(seed, tmp_path, vector_free):
     floors, _, all_stable = F.order_sensitivity(c, ro, eo)
     outs = run_world(dict(name=f"fuzz{seed}", n=c["n"], m=c["m"], iters=c["iters"], objective="fuzz", fuzz=c), 2, tmp_path)
     assert outs[0]["rows"] == outs[1]["rows"] and outs[0]["err"] == outs[1]["err"]
-    F.compare_with_oracle(c, ro, eo, outs[0]["rows"], outs[0]["err"], floors, all_stable, slack=50.0 if vector_free else 1.0)
+    F.compare_with_oracle(c, ro, eo, outs[0]["rows"], outs[0]["err"], floors, all_stable, slack=5.0 if vector_free else 1.0)
 
 
 def test_three_ranks_uneven_shards(tmp_path):

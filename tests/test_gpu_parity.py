@@ -514,10 +514,16 @@ def test_trajectory_matches_oracle_trace(case, two_loop_path):
 # ---------------------------------------------------------------------------------------------
 # EXTENSION: vector-free (Gram) two-loop -- same direction as the exact recursion and as the oracle
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernels", ["on_chip_tiles", "streaming"])
 @pytest.mark.parametrize("n,m", [(4097, 7), (70001, 10), (513, 3), (100, 6), (262145, 9)])
-def test_two_loop_gram_vs_oracle_over_a_run(n, m):
+def test_two_loop_gram_vs_oracle_over_a_run(n, m, kernels, monkeypatch):
     """Feed the ORACLE's history, slot by slot as a run produces it (the Gram matrix is incremental), and
-    compare every direction with the oracle's at 1e-10."""
+    compare every direction with the oracle's at 1e-10 -- with the rows / combine kernels that keep the reused tiles on the
+    chip (gram_combine.h) and with the streaming ones ineligible shapes take (LBFGS_HIP_GRAM_COMBINE_RESIDENT=0).  The
+    run-time check figures (include/lbfgs_hip.h) ride along: the predicted ||d||^2 equals the summed one to rounding, the
+    cancellation figure is finite and modest on this well-conditioned run."""
+    if kernels == "streaming":
+        monkeypatch.setenv("LBFGS_HIP_GRAM_COMBINE_RESIDENT", "0")
     x = np.zeros(n)
     st = O.lbfgs().with_m(m).with_epsilon(0.0).build(x, O.quadratic())
     with R.Context(n) as ctx:
@@ -538,9 +544,10 @@ def test_two_loop_gram_vs_oracle_over_a_run(n, m):
             assert ne == st.end
             dref = st.vec("d")
             worst = max(worst, rel(d.to_numpy(), dref))
-            dn2, dg = ctx.scalars(12, 2)
+            dn2, dg, pred, cancel = ctx.scalars(12, 4)
             assert abs(dn2 - O.vecdot(dref, dref)) <= 1e-9 * O.vecdot(dref, dref)
             assert abs(dg - O.vecdot(st.vec("gx"), dref)) <= 1e-9 * abs(O.vecdot(st.vec("gx"), dref))
+            assert abs(pred - dn2) <= 1e-9 * dn2 and 0.999 <= cancel < 1e4, (pred, dn2, cancel)
         st.close()
         hist.free(); gv.free(); d.free()
     print("gram worst", n, m, worst)
@@ -843,7 +850,25 @@ def test_random_configurations_match_oracle(seed, two_loop_path):
     for vf in (False, True):
         c["vector_free"] = vf
         rp, xp, ep = F.run_product(R, objectives, c)
-        F.compare_with_oracle(c, ro, eo, rp, ep, floors, all_stable, slack=50.0 if vf else 1.0)
+        # (the vector-free extension is another rounding of the same recursion; since round 4 its run-time guard redoes the
+        # iterations whose coefficient-space arithmetic has lost digits, so it is held to 5x the exact path's bar, not 50x)
+        F.compare_with_oracle(c, ro, eo, rp, ep, floors, all_stable, slack=5.0 if vf else 1.0)
+
+
+def test_random_sweep_compared_what_it_claims():
+    """Round-3 advice: the sweep compares only the prefix over which the oracle's own perturbed re-runs agree.  Here: of the
+    cases the tests above ran in this process, none compared nothing, at most 5 % were cut short, and at least 95 % of all
+    oracle iterations were compared; the loosest tolerance any row was given stays below 5e-8 (20 x CHAOS x the vector-free
+    slack)."""
+    from tests import fuzz_common as F
+
+    cov = F.COVERAGE
+    if cov["cases"] < 20:
+        pytest.skip("the sweep did not run in this process")
+    assert cov["vacuous"] == 0, cov
+    assert cov["truncated"] <= 0.05 * cov["cases"], cov
+    assert cov["compared"] >= 0.95 * cov["rows"], cov
+    assert cov["loosest_tol"] <= 1e-7, cov
 
 
 @pytest.mark.parametrize("n", [7, 1001, 70001])
@@ -1012,14 +1037,13 @@ def test_handoff_forms_are_bitwise_identical(monkeypatch):
 
 
 @pytest.mark.parametrize("owl", [False, True])
-@pytest.mark.parametrize("knob", ["LBFGS_HIP_GRAPH", "LBFGS_HIP_DEFER_SUMS"])
+@pytest.mark.parametrize("knob", ["LBFGS_HIP_DEFER_SUMS"])
 def test_two_loop_launch_forms_are_bitwise_equal(knob, owl, monkeypatch):
-    """Two pairs of launch forms of the same recursion must agree BITWISE over whole runs (x, f, ||g||, step per
-    iteration), including the first iterations (bound < m), the ring wrap and the alternating gx/gp buffers:
-      LBFGS_HIP_GRAPH       the two-loop recorded once per (ring position, bound, operands) and replayed as a hipGraph
-                            vs eager launches (same kernels, same arguments);
+    """Two launch forms of the same recursion must agree BITWISE over whole runs (x, f, ||g||, step per iteration),
+    including the first iterations (bound < m), the ring wrap and the alternating gx/gp buffers:
       LBFGS_HIP_DEFER_SUMS  inner dot products left as workgroup partials for the consuming kernel to add up in its
-                            prologue vs reduced by the producing kernel's last workgroup (same summation order)."""
+                            prologue vs reduced by the producing kernel's last workgroup (same summation order).
+    (Round 2's hipGraph replay of the kernel-per-step chain was compared the same way; it was removed in round 4.)"""
     if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
         pytest.skip("the test double has neither")
     monkeypatch.setenv("LBFGS_HIP_RESIDENT", "0")  # (both forms belong to the launch-per-step path)

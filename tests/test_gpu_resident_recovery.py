@@ -240,12 +240,13 @@ KNOBS = [
     {"LBFGS_HIP_RESIDENT_HYBRID": "0"},                   # shards beyond the chip: kernel per step
     {"LBFGS_HIP_RESIDENT": "0"},                          # never the persistent kernel
     {"LBFGS_HIP_RESIDENT": "0", "LBFGS_HIP_DEFER_SUMS": "0"},
-    {"LBFGS_HIP_RESIDENT": "0", "LBFGS_HIP_GRAPH": "1"},
     {"LBFGS_HIP_HANDOFF": "ticket"},                      # arrival-counter reductions (the persistent kernel is not eligible)
     {"LBFGS_HIP_NO_MIRROR": "1"},                         # scalar reads by copy
     {"LBFGS_HIP_RESIDENT_NT_MB": "100000"},               # the persistent kernel without `nt` hints
     {"LBFGS_HIP_RESIDENT_TOUCH": "0"},                    # the waiting workgroups touch (next to) nothing ahead
     {"LBFGS_HIP_RESIDENT_TOUCH": "16"},                   # ... the deepest touch, whatever the shard size
+    {"LBFGS_HIP_GRID": "64"},                             # a launch grid for the streaming kernels (takes the persistent kernel out)
+    {"LBFGS_HIP_NT_THRESHOLD_MB": "1", "LBFGS_HIP_NT_STORE_THRESHOLD_MB": "1", "LBFGS_HIP_RESIDENT": "0"},  # `nt` everywhere
 ]
 
 
@@ -271,7 +272,7 @@ def test_every_knob_setting_follows_the_oracle(knobs, shape, monkeypatch):
         rows_g, xg = run_device(ctx, n, m, iters)
         resident, on_chip = ctx.resident_two_loops(), ctx.resident_elements()
     close(rows_o, rows_g, xo, xg)
-    eligible = knobs.get("LBFGS_HIP_RESIDENT") != "0" and knobs.get("LBFGS_HIP_HANDOFF") != "ticket"
+    eligible = knobs.get("LBFGS_HIP_RESIDENT") != "0" and knobs.get("LBFGS_HIP_HANDOFF") != "ticket" and "LBFGS_HIP_GRID" not in knobs
     if shape == "hybrid_streaming" and knobs.get("LBFGS_HIP_RESIDENT_HYBRID") == "0":
         eligible = False
     assert (resident > 0) == eligible, (resident, knobs)
