@@ -399,7 +399,7 @@ def loaded_build_id():
         return None
 
 
-def traffic_lookup(n_local, m, kernel, build_id=None, profiles_dir=None):
+def traffic_lookup(n_local, m, kernel, build_id=None, profiles_dir=None, resident_elements=None):
     """roofline.traffic: HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS
     command (tools/profile_round.sh; rocprofv3 counters cannot be collected from inside this process).  A file counts only
     if it was taken at this shard size, this m and for this kernel (strict: a near-by size is a different measurement);
@@ -414,6 +414,10 @@ def traffic_lookup(n_local, m, kernel, build_id=None, profiles_dir=None):
             pm = json.load(open(path))
             if (pm["n_local"] == n_local and pm.get("m", 10) == m
                     and pm.get("kernel", "stream_kernel").split("<")[0] == kernel.split("<")[0]):
+                # (the persistent kernel on another grid keeps another share of q on the chip and moves other bytes: rehearsals
+                # of several ranks on one GPU must not be given the whole-GPU figure)
+                if resident_elements is not None and pm.get("resident_elements") not in (None, resident_elements):
+                    continue
                 cur = pm.get("build_id") is not None and pm.get("build_id") == build_id
                 if best is None or (cur and not best[0]):
                     best = (cur, pm, path)
@@ -601,7 +605,7 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
                 # HBM bytes per launch: rocprofv3 PMC counters cannot be collected from inside this process; the
                 # figure is taken from the committed counter passes of THIS command (tools/profile_round.sh) when
                 # they were made at this shard size and for this kernel, and the record names them -- otherwise null
-                roof.update(traffic_lookup(n_local, a.m, roof["kernel"]))
+                roof.update(traffic_lookup(n_local, a.m, roof["kernel"], resident_elements=roof.get("resident_elements")))
             if nt:
                 t_tl = ms_all / nt
                 # 8*b passes of 8 bytes is the fused minimum that respects the dot->axpy dependency;

@@ -28,3 +28,19 @@ for k in 2 3 5; do
   cpy $d/pmc_write_counter_collection.csv profiles/r04_config${k}_pmc_write_counter_collection.csv
   cpy $d/pmc_traffic.json profiles/pmc_traffic_config$k.json
 done
+# (evidence taken before summarize_profile.py wrote `resident_elements`: take it from the same run's bench line)
+python3 - <<'PY'
+import glob, json, os
+pairs = {"profiles/pmc_traffic.json": "profiles/r04_bench_n1e8_m10.json"}
+for p in (8, 4, 2):
+    pairs[f"profiles/pmc_traffic_shard_P{p}.json"] = f"profiles/r04_shard_P{p}_bench.json"
+for tf, bf in pairs.items():
+    if not (os.path.exists(tf) and os.path.exists(bf)):
+        continue
+    t = json.load(open(tf))
+    if t.get("resident_elements") is None:
+        roof = json.loads(open(bf).read().strip().splitlines()[-1])["roofline"]
+        t["resident_elements"] = roof.get("resident_elements")
+        json.dump(t, open(tf, "w"), indent=1)
+        print("  resident_elements ->", tf)
+PY

@@ -107,13 +107,14 @@ def main():
     tag = sys.argv[6] if len(sys.argv) > 6 else "rXX"
     global M
     M = int(sys.argv[7]) if len(sys.argv) > 7 else 10
-    resident_bytes = None
+    resident_bytes = resident_elements = None
     if len(sys.argv) > 8:
         try:
             import json as _json
             roof = _json.loads(open(sys.argv[8]).read().strip().splitlines()[-1])["roofline"]
             if "two_loop_resident_kernel" in roof.get("kernel", ""):
                 resident_bytes = roof["bytes_per_launch"]
+                resident_elements = roof.get("resident_elements")
         except Exception:  # noqa: BLE001
             pass
     n_local = int(n_local)
@@ -188,7 +189,7 @@ def main():
                 full_us = sum(fl) / len(fl)
         algo = resident_bytes if (resident_bytes and "resident" in kname) else (
             (4 * M + 1) * 8 * n_local if "resident" in kname else 32 * n_local)
-        json.dump({"build_id": build_id, "algorithmic_bytes_per_launch": round(algo),
+        json.dump({"build_id": build_id, "resident_elements": resident_elements, "algorithmic_bytes_per_launch": round(algo),
                    "rocprof_avg_us_full_depth_launches": full_us,"_source": f"profiles/{tag}_pmc_fetch_counter_collection.csv + profiles/{tag}_pmc_write_counter_collection.csv "
                               "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python3 bench.py`, averaged over the "
                               "dispatches of the kernel; FETCH_SIZE x2: gfx950 correction of MI355X_MICROARCH.md section HBM; KiB)",
