@@ -265,6 +265,14 @@ def test_bench_contract_line(world, launch, kind, tmp_path):
             assert legs["p2p"]["status"] == "ok" and legs["p2p-host"]["status"] == "ok", legs
             assert probes["rccl"]["status"] != "ok" and "rccl" not in legs, (probes, legs)
             assert probes["p2p"]["mailboxes"] == "device" and probes["p2p-host"]["mailboxes"] == "host", probes
+            # (round 4) every leg says what it spanned and what an exchange cost -- here with a kernel per two-loop step: the
+            # reducing kernel's last workgroup closes each reduction across the two ranks and times it
+            for name, placement in (("p2p", "device"), ("p2p-host", "host")):
+                leg = legs[name]
+                assert leg["ranks_seen"] == 2 and leg["mailbox_placement"] == placement, leg
+                assert leg["exchanges_per_two_loop"] >= 10 and leg["exchange_us_mean"] > 0.0, leg  # (2 * bound, bound <= m = 10)
+        # ... and an N > 1 line carries the CPU baseline (timed by the supervisor, which touches no GPU)
+        assert j["cpu_baseline"]["value"] > 0 and "supervisor" in j["cpu_baseline"]["where"]
 
 
 def test_bench_survives_a_hung_leg(tmp_path):
