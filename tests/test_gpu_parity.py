@@ -839,9 +839,10 @@ def test_lj38_damped_device_objective():
 @pytest.mark.parametrize("seed", range(60))
 def test_random_configurations_match_oracle(seed, two_loop_path):
     """The seeded random sweep of tests/fuzz_common.py on the HIP path: same error code, same discrete decisions
-    (neval, ncall) and values within the run's calibrated tolerance (20x the oracle's own sensitivity to last-bit
+    (neval, ncall) and values within the run's calibrated tolerance (4x the oracle's own sensitivity to last-bit
     changes -- the largest of six perturbed re-runs: four other summation orders, two last-bit neighbours of x0;
-    tests/fuzz_common.py order_sensitivity --, floor 1e-10) for as long as the oracle itself is insensitive to them."""
+    tests/fuzz_common.py order_sensitivity; the factor is twice the worst ratio seen in 4000 seeds --, floor 1e-10) for as
+    long as the oracle itself is insensitive to them."""
     from tests import fuzz_common as F
 
     c = F.make_case(seed)
@@ -858,7 +859,7 @@ def test_random_configurations_match_oracle(seed, two_loop_path):
 def test_random_sweep_compared_what_it_claims():
     """Round-3 advice: the sweep compares only the prefix over which the oracle's own perturbed re-runs agree.  Here: of the
     cases the tests above ran in this process, none compared nothing, at most 5 % were cut short, and at least 95 % of all
-    oracle iterations were compared; the loosest tolerance any row was given stays below 5e-8 (20 x CHAOS x the vector-free
+    oracle iterations were compared; the loosest tolerance any row was given stays below 2.1e-8 (4 x CHAOS x the vector-free
     slack)."""
     from tests import fuzz_common as F
 
@@ -868,7 +869,7 @@ def test_random_sweep_compared_what_it_claims():
     assert cov["vacuous"] == 0, cov
     assert cov["truncated"] <= 0.05 * cov["cases"], cov
     assert cov["compared"] >= 0.95 * cov["rows"], cov
-    assert cov["loosest_tol"] <= 1e-7, cov
+    assert cov["loosest_tol"] <= 2.1e-8, cov   # (FACTOR x CHAOS x the vector-free slack = 4 x 1e-9 x 5)
 
 
 @pytest.mark.parametrize("n", [7, 1001, 70001])

@@ -29,5 +29,13 @@ for seed, path in todo:
         print("FAIL seed", seed, traceback.format_exc().splitlines()[-1][:600], flush=True)
     if seed % 100 == 0:
         print("... seed", seed, "failures so far", len(bad), flush=True)
+    if seed % 500 == 499:
+        from tests import fuzz_common as _F
+
+        print("... bar used so far:", {k: _F.COVERAGE[k] for k in ("cases", "truncated", "rows", "compared", "worst_over_flat_bar",
+                                                                     "worst_over_floor", "rows_on_calibrated_bar")}, flush=True)
+from tests import fuzz_common as F  # noqa: E402
+
 print("seeds", lo, "..", hi - 1, "failures:", len(bad), bad[:40])
+print("coverage and how much of the bar was used (exact path):", F.COVERAGE)
 sys.exit(1 if bad else 0)
