@@ -990,9 +990,12 @@ int lbfgs_hip_vec_swap(lbfgs_hip_vec* a, lbfgs_hip_vec* b) {
 }
 
 // ==================================================================================== board
-static int device_error(lbfgs_hip_ctx* ctx, unsigned int flag) {
+static int device_error(lbfgs_hip_ctx* ctx, unsigned int flag, bool after_rerun = false) {
     if (flag == 2u)
-        return fail(ctx, LBFGS_HIP_ERR_HIP, "a reduction timed out waiting for a workgroup's partial sums");
+        return fail(ctx, LBFGS_HIP_ERR_HIP, "a reduction timed out waiting for a workgroup's partial sums (the latest reducing launch was %s; "
+                    "resident two-loops so far %llu, of which re-run per step %llu; resident path %s)",
+                    after_rerun ? "the per-step re-run of a resident two-loop" : "not a resident two-loop (or its inputs have changed since)",
+                    ctx->resident_launches, ctx->resident_fallbacks, ctx->resident_ok == 1 ? (ctx->resident_proven ? "in use" : "unproven") : "off");
     return fail(ctx, LBFGS_HIP_ERR_COMM, "P2P all-reduce timed out waiting for a peer");
 }
 
@@ -1086,7 +1089,7 @@ int settle(lbfgs_hip_ctx* ctx) {
             if (rc != LBFGS_HIP_OK) return rc;
             continue;
         }
-        return device_error(ctx, flag);
+        return device_error(ctx, flag, attempt == 1);
     }
     return LBFGS_HIP_OK;
 }
@@ -1097,15 +1100,17 @@ int lbfgs_hip_scalars_read(lbfgs_hip_ctx* ctx, int first, int count, double* hos
     if (!ctx || !host || !slot_ok(first, count)) return LBFGS_HIP_ERR_ARG;
     if (count == 0) return lbfgs_hip_sync(ctx);
     unsigned int flag = 0;
+    bool rerun = false;
     int rc = scalars_read_once(ctx, first, count, host, &flag);
     if (rc != LBFGS_HIP_OK) return rc;
     if (flag == 2u && ctx->last_res.valid && ctx->comm_kind == LBFGS_HIP_COMM_NONE) {
         if ((rc = recover_resident(ctx)) != LBFGS_HIP_OK) return rc;
         flag = 0;
+        rerun = true;
         rc = scalars_read_once(ctx, first, count, host, &flag);
         if (rc != LBFGS_HIP_OK) return rc;
     }
-    if (flag) return device_error(ctx, flag);
+    if (flag) return device_error(ctx, flag, rerun);
     if (ctx->last_res.valid) ctx->resident_proven = true;  // (the read waited for the latest launch: a resident two-loop that completed)
     return LBFGS_HIP_OK;
 }

@@ -900,6 +900,14 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     // lbfgs_hip_ctx::first_timeout_ticks); one rank only: with peers a hand-off also waits for THEIR start-up
     if (!ctx->resident_proven && ctx->comm_kind == LBFGS_HIP_COMM_NONE)
         red.timeout_ticks = std::min(red.timeout_ticks, ctx->first_timeout_ticks);
+    // Afterwards a resident hand-off still waits only HALF as long as a launch-per-step reduction does.  Two contexts sharing a
+    // GPU can block each other: this kernel holds most CUs and needs the rest EMPTY, while the other stream's reducing kernel
+    // has its waiting last workgroup on one of those and cannot place its remaining workgroups on the XCDs this kernel fills
+    // (workgroups are bound to XCDs round robin).  Only a timeout ends that, and it must be THIS kernel's: its inputs are
+    // intact and it is re-run per step (context.hip recover_resident), whereas a timed-out launch-per-step reduction is an
+    // error.  Both sides start waiting within a step's time of each other; half the timeout is the margin.
+    else
+        red.timeout_ticks = std::max(1ull, red.timeout_ticks / 2ull);
     // (one hand-off per step -- under OWL-QN the last step's travels after the projection, with four values -- plus one
     // for the first numerator if it is summed here: the SAME sequence of reductions as the launch-per-step path, so under
     // P2P ranks whose eligibility differs -- an empty shard, a shard one round larger -- still meet in every exchange)

@@ -20,7 +20,7 @@
 // kernels.  After a step every workgroup publishes its partial sum(s) as tagged 8-byte
 // granules (tag = the step's sequence number; agent-scope atomics on both sides, no fence: stream.h) into a double
 // buffer indexed by the step's parity, and then EVERY workgroup collects all G partials -- thread t polls workgroup t's
-// granules -- and adds them up in one fixed order (each wave's 64 values by stream.h wave_sum_dpp, then the waves in
+// granules (touching kernels: t's and t + 128's, see TOUCHING) -- and adds them up in one fixed order (each wave's 64 values by stream.h wave_sum_dpp, then the waves in
 // order).  All workgroups therefore hold the same bits for the total and form the same coefficient; no broadcast step
 // is needed.  (That order is this kernel's own: not the launch-per-step reducer's ds_bpermute tree.)  A workgroup can
 // be at most one step ahead of any other (it needs everybody's partial of step s to leave step s), so two buffers
@@ -44,16 +44,18 @@ constexpr int RES_UNROLL = 4;          // pairs whose loads are issued together 
 // not), but the registers and LDS are full of q, so only a window of RES_AHEAD groups can be loaded ahead.  So a waiting
 // workgroup TOUCHES the lines of the rounds that follow that window -- one 4-byte load per 128-byte line, result unused --
 // and finds them in its XCD's L2 when the step asks for them.  A wave's loads return in order, so a touch must never sit in
-// front of a poll whose answer is on the critical path: every thread issues its touches right BEHIND its first poll's
-// loads, in straight-line code, so that the wait for that poll leaves them in flight (at a join of two paths the compiler
-// would wait for everything); a thread's LATER polls do queue behind them, which costs the early arrivers nothing.
+// front of a poll whose answer is on the critical path: the workgroup's waves SPLIT THE ROLES.  The lower two poll (thread t
+// the granules of workgroups t and t + 128) and never touch; the upper two touch and never poll, and go straight to the
+// barrier in front of the workgroup's sum with their touches in flight.  (The form in which every thread polled one
+// workgroup and issued touches behind its first poll made every later poll wait for HBM: 0.6 us more until the last
+// workgroup had left a hand-off; n = 1.25e7: 618.8 -> 607.4 us, 1.2e6: 69.3 -> 66.2 us, profiles/r04_split_ab.log.)
 // Depth (ResArgs::touch_rounds, chosen by the host): 8 rounds up to ~60 rounds per thread, 16 beyond -- 16 rounds of two
 // vectors are 4 MiB per XCD, its whole L2; 24 and more thrash (n = 1.25e7: 662 -> 622 us with 16, 679 with 24, 810 with 48;
 // n = 3e6: 129 -> 119 us with 8, 128 with 16; profiles/r04_touch_sweep.log).  Compiled in for every kernel whose shards have
 // something behind the window (ER >= 8, not hybrid: hybrid steps take hundreds of microseconds, nothing to hide there).
 // LH_RES_TOUCH=0 builds the kernels without it (A/B).
 #ifndef LH_RES_TOUCH
-#define LH_RES_TOUCH 16  // the deepest touch compiled in: a thread holds LH_RES_TOUCH / 4 words (rounds, a multiple of BLOCK / 32)
+#define LH_RES_TOUCH 16  // the deepest touch compiled in (rounds, a multiple of 4): a touching thread holds LH_RES_TOUCH / 2 words
 #endif
 #ifndef LH_RES_TRACE
 #define LH_RES_TRACE 0  // 1: every workgroup logs wall-clock stamps of every hand-off into RedCtl::partials (tools/handoff_trace.sh)
@@ -111,20 +113,22 @@ struct ResTouch {
 // The touched words land in `sink` and stay there, unread, until the step that follows has consumed operands it loaded LATER
 // (res_touch_retire: loads return in order, so the touches have returned by then and nothing ever waits for them).  Plain
 // loads on purpose: a volatile load is compiled to a system-scope access followed by s_waitcnt vmcnt(0).
-constexpr int RES_TOUCH_REGS = LH_RES_TOUCH > 0 ? (2 * 32 * LH_RES_TOUCH + BLOCK - 1) / BLOCK : 1;
+constexpr int RES_TOUCHERS = BLOCK / 2;  // threads of a workgroup that touch: its upper two waves (the lower two poll; res_exchange)
+constexpr int RES_TOUCH_REGS = LH_RES_TOUCH > 0 ? (2 * 32 * LH_RES_TOUCH + RES_TOUCHERS - 1) / RES_TOUCHERS : 1;
 struct ResSink {
     unsigned int w[RES_TOUCH_REGS];
 };
+// `tt`: this thread's index among the touching threads (0 .. RES_TOUCHERS-1)
 template <int D>
-__device__ __forceinline__ void res_touch(const ResTouch& t, ResSink& sink) {
+__device__ __forceinline__ void res_touch(const ResTouch& t, ResSink& sink, const uint32_t tt) {
     if constexpr (D > 0) {
-        // (whole multiples of the workgroup per vector: which vector a thread touches is then a compile-time fact -- a run-time
-        // choice between the two pointers is compiled to an indexed read of this struct, i.e. to scratch memory)
-        static_assert((32 * D) % BLOCK == 0, "LH_RES_TOUCH must be a multiple of BLOCK / 32");
-        constexpr int PER_VEC = 32 * D / BLOCK;
+        // (whole multiples of the touching threads per vector: which vector a thread touches is then a compile-time fact -- a
+        // run-time choice between the two pointers is compiled to an indexed read of this struct, i.e. to scratch memory)
+        static_assert((32 * D) % RES_TOUCHERS == 0, "LH_RES_TOUCH must be a multiple of the touching threads / 32");
+        constexpr int PER_VEC = 32 * D / RES_TOUCHERS;
 #pragma unroll
         for (int i = 0; i < 2 * PER_VEC; ++i) {
-            const uint32_t L = threadIdx.x + (uint32_t)(BLOCK * (i % PER_VEC));  // line among this vector's 32 * D
+            const uint32_t L = tt + (uint32_t)(RES_TOUCHERS * (i % PER_VEC));  // line among this vector's 32 * D
             const uint32_t r = min(t.r0 + L / 32u, t.r_end - 1u), line = L % 32u;
             const uint32_t off = min(t.first + r * t.round_stride + line * 128u, t.limit);
             sink.w[i] = *reinterpret_cast<const unsigned int*>((i < PER_VEC ? t.u : t.v) + off);
@@ -210,49 +214,83 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
     for (int k = 0; k < NS; ++k) tot[k] = 0.0;
     const long long t0 = wall_clock64();
     const bool collector = !multi || blockIdx.x == 0;  // (uniform) this workgroup adds up the G partials itself
-    if (collector) {
-        // Thread b polls workgroup b's granules (threads beyond the grid poll this workgroup's own and drop the value: the first
-        // poll and the touches behind it are then straight-line code, so that the wait for the poll leaves the touches in
-        // flight -- at a join of two paths the compiler would wait for everything).
-        const bool mine = threadIdx.x < G;
-        const unsigned int b = mine ? threadIdx.x : blockIdx.x;
-        unsigned long long lo[NS], hi[NS];
+    if (collector && TOUCH > 0) {
+        // SPLIT ROLES: the lower half of the waves polls -- thread t the granules of workgroups t and t + BLOCK/2 --, the upper
+        // half touches and does not poll.  A wave's loads return in order: a thread that touched would read its LATER polls only
+        // after the touches have come back from HBM (the all-waves form: +0.6 us until the last workgroup has left a
+        // hand-off); a polling wave with nothing else in its queue reads every poll as soon as the memory answers.
+        if (threadIdx.x < (unsigned int)(BLOCK / 2)) {
+            const unsigned int b1 = threadIdx.x, b2 = threadIdx.x + (unsigned int)(BLOCK / 2);
+            const bool mine1 = b1 < G, mine2 = b2 < G;
+            const unsigned int bb[2] = {mine1 ? b1 : blockIdx.x, mine2 ? b2 : blockIdx.x};
+            unsigned long long lo[2][NS], hi[2][NS];
+            for (;;) {
+                bool ok = true;
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const unsigned long long* g = red.gran + ((size_t)(parity * 4 + k) * MAX_GRID + b) * 2;
-            lo[k] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            hi[k] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("" ::: "memory");
-        res_touch<TOUCH>(touch, sink);
-        asm volatile("" ::: "memory");
-        for (;;) {
-            bool ok = true;
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int k = 0; k < NS; ++k) ok = ok && (unsigned int)(lo[k] >> 32) == tag && (unsigned int)(hi[k] >> 32) == tag;
-            LH_TR(tr_polls++;)
-            if (ok) break;
-            // (slow path only) give up after the timeout -- or at once if somebody already has: one missing workgroup must
-            // cost ONE timeout, not one per hand-off and workgroup
-            if ((unsigned long long)(wall_clock64() - t0) > red.timeout_ticks ||
-                __hip_atomic_load(red.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                atomicExch(red.err, 2u);
-                break;
+                    for (int k = 0; k < NS; ++k) {
+                        const unsigned long long* g = red.gran + ((size_t)(parity * 4 + k) * MAX_GRID + bb[j]) * 2;
+                        lo[j][k] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        hi[j][k] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int k = 0; k < NS; ++k)
+                        ok = ok && (unsigned int)(lo[j][k] >> 32) == tag && (unsigned int)(hi[j][k] >> 32) == tag;
+                LH_TR(tr_polls++;)
+                if (ok) break;
+                if ((unsigned long long)(wall_clock64() - t0) > red.timeout_ticks ||
+                    __hip_atomic_load(red.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    atomicExch(red.err, 2u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
             }
-            __builtin_amdgcn_s_sleep(2);
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                const unsigned long long* g = red.gran + ((size_t)(parity * 4 + k) * MAX_GRID + b) * 2;
-                lo[k] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                hi[k] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double v1 = __longlong_as_double((long long)((hi[0][k] << 32) | (lo[0][k] & 0xffffffffULL)));
+                const double v2 = __longlong_as_double((long long)((hi[1][k] << 32) | (lo[1][k] & 0xffffffffULL)));
+                tot[k] = mine1 ? 0.0 + v1 : 0.0;
+                if (mine2) tot[k] += v2;
             }
+        } else {
+            res_touch<TOUCH>(touch, sink, threadIdx.x - (unsigned int)(BLOCK / 2));
         }
+    } else if (collector) {
+        // (kernels that do not touch: the hybrid ones and those whose shard fits the registers) thread b polls workgroup b's granules
+        const bool mine = threadIdx.x < G;
+        unsigned long long lo[NS], hi[NS];
+        if (mine) {
+            for (;;) {
+                bool ok = true;
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const double v = __longlong_as_double((long long)((hi[k] << 32) | (lo[k] & 0xffffffffULL)));
-            tot[k] = mine ? 0.0 + v : 0.0;  // (0.0 + v: the bits of the strided sum this replaces, -0.0 included)
+                for (int k = 0; k < NS; ++k) {
+                    const unsigned long long* g = red.gran + ((size_t)(parity * 4 + k) * MAX_GRID + threadIdx.x) * 2;
+                    lo[k] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hi[k] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int k = 0; k < NS; ++k) ok = ok && (unsigned int)(lo[k] >> 32) == tag && (unsigned int)(hi[k] >> 32) == tag;
+                LH_TR(tr_polls++;)
+                if (ok) break;
+                // (slow path only) give up after the timeout -- or at once if somebody already has: one missing workgroup must
+                // cost ONE timeout, not one per hand-off and workgroup
+                if ((unsigned long long)(wall_clock64() - t0) > red.timeout_ticks ||
+                    __hip_atomic_load(red.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    atomicExch(red.err, 2u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k)  // (0.0 + v: the bits of the strided sum this replaces, -0.0 included)
+                tot[k] = 0.0 + __longlong_as_double((long long)((hi[k] << 32) | (lo[k] & 0xffffffffULL)));
         }
-        // a fixed order: one partial per thread, each wave's sum (stream.h wave_sum_dpp: rows of 16 as trees, the four rows
+    }
+    if (collector) {
+        // a fixed order: the partials of a thread, each wave's sum (stream.h wave_sum_dpp: rows of 16 as trees, the four rows
         // in order), the waves in order -- the same in every workgroup, so all of them hold the same bits
         res_block_total<NS>(tot, rows2);
         if (multi) {  // (workgroup 0 only) this rank's totals -> the global totals, then tell the other workgroups
@@ -277,7 +315,9 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
             }
         }
     } else {
-        res_touch<TOUCH>(touch, sink);
+        // (several ranks, not workgroup 0: the lanes that poll the global total below sit in the first wave, which does not touch
+        // in the split form)
+        if (threadIdx.x >= (unsigned int)(BLOCK / 2)) res_touch<TOUCH>(touch, sink, threadIdx.x - (unsigned int)(BLOCK / 2));
         if (threadIdx.x < NS) {  // one lane per sum polls the global total workgroup 0 will publish
             const unsigned long long* g = red.gran + ((size_t)(8 + parity * 4 + threadIdx.x) * MAX_GRID) * 2;
             unsigned long long lo, hi;

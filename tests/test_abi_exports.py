@@ -227,4 +227,4 @@ def test_resident_kernels_own_their_accumulation_registers(libs):
         blk = txt[txt.index("Function Name: " + sym):]
         vgprs = int(re.search(r" VGPRs: (\d+)", blk).group(1))
         hybrid = "two_loop_resident" in sym and "ELb1EEEv" in sym          # two_loop_resident_kernel<ER, NT, HYB = true>
-        assert vgprs <= (248 if hybrid else 200), (sym, vgprs)   # (the audit above is the guarantee; this keeps a distance: 256 is the cliff)
+        assert vgprs <= (248 if hybrid else 216), (sym, vgprs)   # (the audit above is the guarantee; this keeps a distance: 256 is the cliff)

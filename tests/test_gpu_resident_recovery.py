@@ -89,8 +89,10 @@ def test_a_mis_detected_chip_costs_milliseconds_not_the_full_timeout(monkeypatch
 
 
 def test_the_configured_timeout_applies_once_a_resident_launch_has_completed(monkeypatch):
-    """... and once a resident launch HAS completed, the context is trusted with the configured timeout: a later launch that
-    loses a workgroup waits that long (here 400 ms: longer than the first-launch bound, short enough for a test)."""
+    """... and once a resident launch HAS completed, the context is trusted with the configured timeout -- half of it: a resident
+    hand-off gives up before a launch-per-step reduction of another context on the same GPU would (see
+    test_two_contexts_on_two_streams_of_one_gpu).  A later launch that loses a workgroup waits that long (here 200 ms of the
+    configured 400: longer than the first-launch bound, short enough for a test)."""
     import time
 
     if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
@@ -107,7 +109,7 @@ def test_the_configured_timeout_applies_once_a_resident_launch_has_completed(mon
         hist.two_loop(d, g, m, m - 1, 7, 8, 12)
         dn = ctx.scalars(12, 2).copy()
         wall = time.perf_counter() - t0
-        assert 0.35 < wall < 3.0, wall
+        assert 0.18 < wall < 3.0, wall
         assert ctx.comm_info()["resident_fallbacks"] == 1
         np.testing.assert_allclose(dn, ref_dn, rtol=1e-12)
         hist.free(); g.free(); d.free()
@@ -202,7 +204,10 @@ def test_two_contexts_on_two_streams_of_one_gpu(monkeypatch):
     """Two independent optimisations in ONE process, each with its own context and stream, both eligible for the
     chip-wide kernel, driven from two threads at the same time.  Whatever the dispatcher does with two kernels that each
     want every CU -- one after the other, or a share each (then both time out once and fall back) -- both runs must
-    finish with the oracle's trajectory."""
+    finish with the oracle's trajectory.  That includes the case in which one context's resident kernel and the OTHER
+    context's launch-per-step reduction block each other (the resident kernel needs the CUs empty on which the other kernel's
+    last workgroup waits for workgroups that are bound to XCDs the resident kernel fills): the resident kernel's hand-offs
+    wait half the configured timeout, so it is always the one that gives up -- and it is the one that can be re-run."""
     if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
         pytest.skip("needs the GPU")
     n, m, iters = 2_000_003, 6, 25
