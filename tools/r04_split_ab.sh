@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4: split-role touching (half the waves poll, half touch) against the all-waves form, then the trace of the split form
+# (history: the `nosplit` variant was -DLH_RES_TOUCH_SPLIT=0, a switch that existed while both forms were being compared (before commit f52c870); it and the all-waves form are gone; kept as the record of how profiles/r04_split_ab.log was made)
 mkdir -p gpurun_out
 for cfg in "1200001 6" "3000000 6" "6000000 6" "10000000 7" "12500224 10"; do
   set -- $cfg
