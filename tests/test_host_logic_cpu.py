@@ -409,12 +409,13 @@ def test_vector_free_direction_that_fails_its_check_is_redone_exactly(owl, monke
 
 
 def test_touch_addresses_stay_inside_the_vectors():
-    """resident.h TOUCHING: while a workgroup waits in a hand-off every thread reads one word of some lines of the NEXT step's
-    operands.  A read outside a vector is a GPU fault that can take a whole host down, so the address arithmetic of
+    """resident.h TOUCHING: while a workgroup waits in a hand-off the threads of its upper two waves read one word of some lines
+    of the NEXT step's operands (the lower two waves poll).  A read outside a vector is a GPU fault that can take a whole host down, so the address arithmetic of
     `res_touch` / `two_loop_resident_kernel` is restated here (uint32, as on the device) and swept over shard sizes around
     every boundary the host-side launcher knows (rounds per thread 1 ... 96, ragged last rounds, odd n, small grids): every
     offset is a multiple of 4 inside [0, 8n), and the rounds touched are rounds the shard has."""
     BLOCK, RES_UNROLL, RES_AHEAD, TOUCH = 256, 4, 1, 16
+    TOUCHERS = BLOCK // 2                                 # resident.h RES_TOUCHERS
     u32 = lambda v: v & 0xFFFFFFFF  # noqa: E731
     rng = np.random.default_rng(4)
     sizes = [2, 3, 255, 256, 1000, 65_536, 131_073, 600_001, 1_200_001, 2_097_152, 3_000_017, 8_000_000, 12_500_224,
@@ -432,13 +433,17 @@ def test_touch_addresses_stay_inside_the_vectors():
                 limit = u32(n * 8 - 8)
                 for B in sorted({0, G // 2, G - 1}):
                     first, stride = u32(B * BLOCK * 16), u32(G * BLOCK * 16)
-                    tid = np.arange(BLOCK, dtype=np.uint64)
-                    per_vec = 32 * TOUCH // BLOCK
+                    tt = np.arange(TOUCHERS, dtype=np.uint64)  # a thread's index among the touching threads
+                    per_vec = 32 * TOUCH // TOUCHERS
+                    seen = set()
                     for i in range(2 * per_vec):
-                        L = tid + BLOCK * (i % per_vec)
+                        L = tt + TOUCHERS * (i % per_vec)
+                        if i < per_vec:
+                            seen.update(int(v) for v in L)
                         r = np.minimum(r0 + L // 32, np.uint64((r_end - 1) & 0xFFFFFFFF))  # (u32 wrap of r_end - 1 never happens: r_end >= 1)
                         assert r_end >= 1 and np.all(r < max(E, 1))
                         off = (first + r * stride + (L % 32) * 128) & 0xFFFFFFFF
                         assert np.all(first + r * stride + (L % 32) * 128 < 2**32)   # no 32-bit overflow before the clamp
                         off = np.minimum(off, limit)
                         assert np.all(off % 4 == 0) and np.all(off + 4 <= 8 * n), (n, G, depth, B, i)
+                    assert seen == set(range(32 * TOUCH))   # every line of the TOUCH rounds of a vector has exactly one toucher
