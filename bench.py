@@ -32,7 +32,9 @@ mailboxes: the placement a machine falls back to when device memory cannot be ma
 when p2p gave nothing), "callback" (host-staged all-reduce through gloo) only if nothing produced a result.  Every job's
 outcome is echoed to stderr as it lands; SIGTERM / SIGINT kill the running job and print the best line so far.  The run
 prints ONE JSON line with the best leg as `value`, every probe and leg in `config.probes` / `config.legs`, and exits 0 if
-any leg succeeded.
+any leg succeeded.  The line SAYS which leg that is: `metric` ends in "scalars closed by: <leg in words>", `config.allreduce`
+/ `config.allreduce_says` name it, and `config.rccl` carries the RCCL leg's iterations/sec, two-loop ms and ncclAllReduce
+microseconds at the top level of `config` whichever leg won (the north star's wording is "scalar RCCL all-reduce").
 
 Timing.  W warm-up steps (plus whatever fills the history: bound = m before anything is timed), then
 EXACTLY K steps between barrier + synchronize on both sides, max over ranks.  That K-step region is
@@ -41,9 +43,13 @@ every repeat times the same K iterations; `value` / `ms_per_step` are the MEDIAN
 are listed in `config.repeats_iters_per_sec`.
 
 The JSON line carries, besides the contract fields:
-  roofline      the dominant kernel (two-loop step  q += c*u ; out = v.q,  3 reads + 1 write of
-                an n-vector = 32 bytes/element algorithmic) timed with HIP events on the launch
-                stream over the timed region, against the 8 TB/s HBM peak;
+  roofline      the dominant kernel, timed with HIP events on the launch stream over the timed region, against the 8 TB/s
+                HBM peak.  By default that is the WHOLE two-loop recursion as one persistent kernel
+                (two_loop_resident_kernel, csrc/resident.h): the running vector q stays in registers + LDS, so the on-chip
+                elements cost (4m+1) n-vector passes (g once, every s and y twice, d written once) and -- hybrid form, shards
+                beyond ~1.25e7 elements -- the rest of q, kept in HBM, the kernel-per-step (8m-1); `bytes_per_launch` is that
+                sum.  Only with LBFGS_HIP_RESIDENT=0 is it the two-loop step kernel (q += c*u ; out = v.q: 3 reads + 1 write =
+                32 bytes per element).  `note` bounds from above what the Infinity Cache can absorb of those bytes;
   cpu_baseline  the CPU oracle (reference operation order, 1 thread) on the metric's own
                 configuration (n = 1e8, m = 10: 3 iterations after m+2 warm-up, ~22 GB of host memory) when
                 the host has the memory, with the sampled-and-scaled figure beside it.  N = 1: a child of the
@@ -69,6 +75,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+METRIC = "L-BFGS iters/sec (two-loop HBM GB/s in roofline) at n=1e8, m=10"
 
 
 def parse(argv=None):
@@ -402,8 +409,10 @@ def loaded_build_id():
 def traffic_lookup(n_local, m, kernel, build_id=None, profiles_dir=None, resident_elements=None):
     """roofline.traffic: HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS
     command (tools/profile_round.sh; rocprofv3 counters cannot be collected from inside this process).  A file counts only
-    if it was taken at this shard size, this m and for this kernel (strict: a near-by size is a different measurement);
-    the record names the build the passes were made with and whether that is the build measuring now."""
+    if it was taken from `bench.py` itself (its `command` stamp: tools/profile_configs.sh profiles tools/run_configs.py --
+    other objectives, OWL-QN, damping -- at sizes this program can also be asked to run), at this shard size, this m and
+    for this kernel (strict: a near-by size is a different measurement); the record names the build the passes were made
+    with and whether that is the build measuring now."""
     import glob
 
     if build_id is None:
@@ -412,7 +421,7 @@ def traffic_lookup(n_local, m, kernel, build_id=None, profiles_dir=None, residen
     for path in sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "pmc_traffic*.json"))):
         try:
             pm = json.load(open(path))
-            if (pm["n_local"] == n_local and pm.get("m", 10) == m
+            if (pm.get("command") == "bench.py" and pm["n_local"] == n_local and pm.get("m", 10) == m
                     and pm.get("kernel", "stream_kernel").split("<")[0] == kernel.split("<")[0]):
                 # (the persistent kernel on another grid keeps another share of q on the chip and moves other bytes: rehearsals
                 # of several ranks on one GPU must not be given the whole-GPU figure)
@@ -595,7 +604,8 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
                                  "on the chip, (8m-1) over the rest (hybrid: shards larger than ~1.25e7 elements).  In the hybrid "
                                  "form a 256 MiB slice of the rest keeps the default cache policy and is served by the Infinity "
                                  "Cache between steps: those bytes are requested by the kernel (and counted here and by "
-                                 "`traffic`, which counts what leaves the L2s) but do not all reach HBM")
+                                 "`traffic`, which counts what leaves the L2s) but do not all reach HBM",
+                            infinity_cache_bound=ic_bound(ctx, a.m, n_local, n_res, nbytes, avg_ms))
             elif ns:
                 avg_ms = ms_step / ns
                 ach = 32.0 * n_local / (avg_ms * 1e-3) / 1e9  # 3 reads + 1 write of f64 per element
@@ -657,6 +667,26 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
     return res
 
 
+def ic_bound(ctx, m, n_local, n_res, nbytes, avg_ms):
+    """Upper bound on the bytes of one hybrid launch that the Infinity Cache can serve instead of HBM, so that the record bounds
+    the HBM-channel rate from below by itself: only the slice of the HBM part of q that keeps the default cache policy
+    (LBFGS_HIP_RESIDENT_PLAIN_MB, 256 MiB by default; everything else carries `nt`) can be found there, and each of the 2m
+    steps after the first reads it once: <= 2m x slice bytes."""
+    if n_res >= n_local:
+        return None  # all of q on the chip: nothing of it is streamed
+    try:
+        slice_mb = float(os.environ.get("LBFGS_HIP_RESIDENT_PLAIN_MB", "256"))
+    except ValueError:
+        slice_mb = 256.0
+    slice_bytes = min(slice_mb * 2 ** 20, 8.0 * (n_local - n_res))
+    absorbed = 2 * m * slice_bytes
+    hbm_min = (nbytes - absorbed) / (avg_ms * 1e-3) / 1e9
+    return {"slice_bytes": slice_bytes, "absorbed_bytes_at_most": absorbed, "hbm_GBps_at_least": hbm_min,
+            "hbm_frac_at_least": hbm_min / HBM_PEAK_GBPS,
+            "says": "at most 2m x the cache slice of q (re-read once per step) can come from the Infinity Cache: the HBM channels "
+                    "carry at least (bytes_per_launch - that) / avg_ms"}
+
+
 def calibrate(ctx, reps=20):
     """What this box's HBM delivers to the plainest kernels of the library: copy (1r 1w) and triad y += c*x (2r 1w), on
     vectors of the bench's shard size.  SURVEY 8(d) asks for the achievable-copy figure beside the 8 TB/s spec peak.
@@ -703,8 +733,9 @@ def compose(a, world, results, ext, legs=None):
     if best.get("comm"):
         cfg["comm_info"] = best["comm"]
         cfg["ranks_seen"] = best["comm"]["ranks_seen"]
+    cfg["allreduce_says"] = LEG_SAYS.get(best["label"], best["label"])
     return {
-        "metric": "L-BFGS iters/sec (two-loop HBM GB/s in roofline) at n=1e8, m=10",
+        "metric": METRIC if world == 1 else f"{METRIC}; {world} GPUs, scalars closed by: {LEG_SAYS.get(best['label'], best['label'])}",
         "value": best["value"],
         "unit": "iters/sec",
         "n_gpus": world,
@@ -813,6 +844,35 @@ def free_port():
 
 
 LEG_COMM = {"p2p": "p2p", "p2p-per-step": "p2p", "p2p-host": "p2p-host", "rccl": "rccl", "callback": "callback"}
+# what closes the scalar reductions of a leg, in words: an N > 1 line says it in `metric` and `config.allreduce`, so that nobody
+# reads a number of the in-kernel exchange as a number of RCCL (BASELINE.json's north star names "a scalar RCCL all-reduce")
+LEG_SAYS = {
+    "p2p": "p2p in-kernel exchange (tagged stores into device mailboxes mapped over xGMI, inside the reducing kernels; the two-loop "
+           "is one persistent kernel) -- NOT RCCL",
+    "p2p-per-step": "p2p in-kernel exchange (device mailboxes over xGMI), one kernel per two-loop step -- NOT RCCL",
+    "p2p-host": "p2p in-kernel exchange through host-coherent mailboxes (reached over PCIe) -- NOT RCCL",
+    "rccl": "rccl ncclAllReduce(ncclDouble, ncclSum) on the compute stream, one per reduction; the two-loop is one kernel per step",
+    "callback": "host-staged all-reduce through torch.distributed/gloo (last resort) -- NOT RCCL",
+    "none": "single GPU: no communicator",
+}
+
+
+def rccl_beside(report, lines):
+    """config.rccl: the RCCL leg at the top level of `config` whatever leg `value` comes from -- its iterations/sec, its
+    two-loop and what one ncclAllReduce cost (HIP events around the launches), or why there is no such figure."""
+    rep = report.get("rccl")
+    out = {"iters_per_sec": None, "two_loop_ms": None, "allreduce_us_mean": None, "allreduces_per_two_loop": None,
+           "ranks_seen": None, "status": "not run" if rep is None else rep.get("status"),
+           "says": LEG_SAYS["rccl"]}
+    for lg, j in lines:
+        if lg != "rccl":
+            continue
+        roof = j.get("roofline") or {}
+        ci = j["config"].get("comm_info") or {}
+        out.update(iters_per_sec=round(j["value"], 3), two_loop_ms=(roof.get("two_loop") or {}).get("ms"),
+                   allreduce_us_mean=ci.get("exchange_us_mean"), allreduces_per_two_loop=ci.get("exchanges_per_two_loop"),
+                   ranks_seen=ci.get("ranks_seen"))
+    return out
 
 
 def passthrough(a, leg, probe=False, vector_free=True):
@@ -916,6 +976,10 @@ def supervisor_main(a):
         cfg = best["config"]
         cfg["probes"], cfg["legs"] = probes, report
         cfg["allreduce"] = leg
+        cfg["allreduce_says"] = LEG_SAYS.get(leg, leg)
+        cfg["value_from_leg"] = leg
+        cfg["rccl"] = rccl_beside(report, lines)
+        best["metric"] = f"{METRIC}; {world} GPUs, scalars closed by: {LEG_SAYS.get(leg, leg)}"
         cfg["allreduce_measured_iters_per_sec"] = {lg: round(j["value"], 3) for lg, j in lines}
         ext = {}
         for lg, j in lines:
@@ -930,10 +994,13 @@ def supervisor_main(a):
 
     def attach_cpu_baseline(best, wait_s):
         """the baseline child's result into the line (it has had the whole run to finish; `wait_s` more at most)"""
-        child, state["cpu_child"] = state["cpu_child"], None
+        child = state["cpu_child"]
         if child is None or best is None:
             return
+        # (the Popen stays in `state` while communicate() waits -- up to left() + 60 s: a signal that arrives meanwhile must
+        # still find the child, ~22 GB of host memory and minutes of CPU time, and kill it)
         cb = collect_cpu_baseline(child, a, timeout=max(0.5, wait_s))
+        state["cpu_child"] = None
         cb["where"] = ("rank 0's supervisor process (no GPU), started before the first probe and timed while the legs ran; the "
                        "reference is single-threaded, so this is the N = 1 figure whatever --gpus says")
         best["cpu_baseline"] = cb
@@ -954,7 +1021,10 @@ def supervisor_main(a):
                   file=sys.stderr)
             if best is not None:
                 best["config"]["interrupted_by_signal"] = int(signum)
-                attach_cpu_baseline(best, 0.5)  # (only if it has finished: no time to wait now)
+                try:
+                    attach_cpu_baseline(best, 0.5)  # (only if it has finished: no time to wait now)
+                except Exception:  # noqa: BLE001  (e.g. the signal arrived inside the main flow's own communicate())
+                    pass
                 os.write(real_stdout, (json.dumps(best) + "\n").encode())
                 rc = 0
         if state["cpu_child"] is not None:

@@ -20,7 +20,8 @@ RESIDENT = "two_loop_resident_kernel<ER,NT>"
 
 
 def _write(d, name, **kw):
-    rec = dict(kernel="two_loop_resident_kernel", n_local=12500224, m=10, traffic_bytes_per_launch=4.1e9, _source="test")
+    rec = dict(kernel="two_loop_resident_kernel", n_local=12500224, m=10, traffic_bytes_per_launch=4.1e9, _source="test",
+               command="bench.py")
     rec.update(kw)
     with open(os.path.join(d, name), "w") as f:
         json.dump(rec, f)
@@ -38,6 +39,20 @@ def test_traffic_lookup_is_strict_about_size_m_and_kernel(tmp_path):
     got = bench.traffic_lookup(12500224, 10, RESIDENT, build_id="aaaa", profiles_dir=d)
     assert got["traffic"] == pytest.approx(4.1) and got["traffic_is_current"] is True and got["traffic_build_id"] == "aaaa"
     assert got["traffic_file"].endswith("pmc_traffic_d.json")
+
+
+def test_traffic_lookup_takes_only_passes_of_bench_py_itself(tmp_path):
+    """tools/profile_configs.sh profiles tools/run_configs.py (OWL-QN logistic at n = 1e7, m = 6; damped Lennard-Jones at
+    n = 3e6, m = 6) -- sizes `bench.py --dim ... --hist 6` can be asked to run with ANOTHER objective: those bytes are not this
+    command's (round-4 advice)."""
+    d = str(tmp_path)
+    _write(d, "pmc_traffic_config5.json", n_local=3000000, m=6, build_id="aaaa", command="tools/run_configs.py --only config5",
+           resident_elements=None)
+    assert bench.traffic_lookup(3000000, 6, RESIDENT, build_id="aaaa", profiles_dir=d) == {}
+    _write(d, "pmc_traffic_unstamped.json", n_local=3000000, m=6, build_id="aaaa", command=None)
+    assert bench.traffic_lookup(3000000, 6, RESIDENT, build_id="aaaa", profiles_dir=d) == {}
+    for path in __import__("glob").glob(os.path.join(ROOT, "profiles", "pmc_traffic_config*.json")):
+        assert json.load(open(path)).get("command", "").startswith("tools/run_configs.py"), path
 
 
 def test_traffic_lookup_names_a_stale_build_and_prefers_the_current_one(tmp_path):

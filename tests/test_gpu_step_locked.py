@@ -59,6 +59,29 @@ CASES = {
                              .with_epsilon(0.0), O.logistic, objectives.Logistic, "zeros", 25),
 }
 DAMPED_CASES = ("rosenbrock_damped_m10", "rosenbrock_armijo_damped", "quadratic_gradient_only")
+# cases on which the vector-free extension must pass its own run-time check on EVERY iteration (the sizes it is quoted at);
+# on the others an iteration the guard rejects is one the solver would redo exactly, and only counted here
+GRAM_MUST_BE_TRUSTED = ("config2_quadratic_n1e7_m7", "config3_owlqn_logistic_n1e7_m6", "quadratic_m10_big",
+                        "quadratic_m3_streaming", "owlqn_logistic_n2e7_m6_hybrid")
+VF_PRED_RTOL, VF_MAX_CANCELLATION = 1e-8, 1e4   # the solver's acceptance test (solver.cpp, lbfgs_propagate)
+
+
+def vector_free_row(ctx, hist, dv, src, st, end_before, m, slot=24):
+    """EXTENSION in front of the oracle: lbfgs_hip_two_loop_gram on the history the caller has just made
+    identical to the oracle's (the Gram matrix is incremental: one call per history update).  -> the guard's figures, the
+    alphas it left, and whether the solver would have kept this direction (solver.cpp: prediction within 1e-8, cancellation
+    <= 1e4).  The direction is left in dv for the caller to compare."""
+    hist.set_scalars(alpha=np.zeros(m))
+    assert hist.two_loop_gram(dv, src, st.k - 1, end_before, 7, 8, slot) == st.end
+    dn2, gd, pred, cancel = ctx.scalars(slot, 4)
+    perr = abs(pred - dn2) / abs(dn2) if dn2 == dn2 and dn2 != 0.0 else float("inf")
+    trusted = bool(perr <= VF_PRED_RTOL and cancel <= VF_MAX_CANCELLATION)
+    bound = int(min(m, st.k - 1))
+    slots = [(st.end - 1 - i) % m for i in range(bound)]
+    a_dev = hist.scalars()[1]
+    a_ref = np.array([st.alpha(j) for j in range(m)])
+    return dict(dn2=dn2, gd=gd, prediction_error=perr, cancellation=float(cancel), trusted=trusted,
+                alpha=rel(a_dev[slots], a_ref[slots]))
 
 
 def damp_like_the_host(ctx, hist, slot, gpv, step, out_slot):
@@ -82,7 +105,9 @@ def test_step_locked(case):
     with R.Context(n) as ctx:
         hist = H.History(ctx, m)
         xv, gv, pgv, dv, xpv, gpv = (DeviceVec(ctx) for _ in range(6))
-        worst = dict(f=0.0, g=0.0, d=0.0, s=0.0, y=0.0, ys=0.0, ls_step=0.0, ls_f=0.0, ls_x=0.0, d_fused=0.0, fused_sums=0.0)
+        worst = dict(f=0.0, g=0.0, d=0.0, s=0.0, y=0.0, ys=0.0, ls_step=0.0, ls_f=0.0, ls_x=0.0, d_fused=0.0, fused_sums=0.0,
+                     d_vector_free=0.0, vector_free_sums=0.0, vector_free_alpha=0.0)
+        vf = dict(kept=0, rejected=0, cancellation_max=0.0, prediction_error_max=0.0)
         fused_paths = set()
         done = fired = 0
         damping = bool(b.param.damping)
@@ -171,6 +196,26 @@ def test_step_locked(case):
                 dn2_unfused = ctx.scalars(12)[0]  # ||d||^2 before the projection (lbfgs.rs:543 precedes :554)
                 H.constrain_direction(dv, pgv, s0, e0, 13)
             worst["d"] = max(worst["d"], rel(dv.to_numpy(), st.vec("d")))
+            # (3a) EXTENSION: the vector-free (Gram) recursion on the same history, held to the same bar whenever its own
+            #      run-time check accepts the direction (a rejected one is redone exactly by the solver: that is (3))
+            if m <= 10:
+                row = vector_free_row(ctx, hist, dv, src, st, end_before, m)
+                if row["trusted"]:
+                    vf["kept"] += 1
+                    vf["cancellation_max"] = max(vf["cancellation_max"], row["cancellation"])
+                    vf["prediction_error_max"] = max(vf["prediction_error_max"], row["prediction_error"])
+                    d_ref, g_ref = st.vec("d"), st.vec("pg" if owl else "gx")
+                    if owl:   # ||d||^2 of lbfgs.rs:543 precedes the projection of :554
+                        worst["vector_free_sums"] = max(worst["vector_free_sums"], abs(row["dn2"] - dn2_unfused) / dn2_unfused)
+                        H.constrain_direction(dv, pgv, s0, e0, 28)
+                    else:
+                        want_dn2, want_gd = O.vecdot(d_ref, d_ref), O.vecdot(g_ref, d_ref)
+                        worst["vector_free_sums"] = max(worst["vector_free_sums"], abs(row["dn2"] - want_dn2) / want_dn2,
+                                                        abs(row["gd"] - want_gd) / abs(want_gd))
+                    worst["d_vector_free"] = max(worst["d_vector_free"], rel(dv.to_numpy(), d_ref))
+                    worst["vector_free_alpha"] = max(worst["vector_free_alpha"], row["alpha"])
+                else:
+                    vf["rejected"] += 1
             # (3b) OWL-QN: the FUSED entry the solver uses in production -- lbfgs_hip_two_loop_owlqn: the recursion with
             #      constrain_search_direction (orthantwise.rs:140-161) folded into its last step; in the resident kernel's
             #      write-out / its hybrid rounds' last step -- against the oracle's projected direction and its sums
@@ -204,7 +249,9 @@ def test_step_locked(case):
         assert fused_paths == {"resident"}, fused_paths   # (hybrid for the 2e7 cases: the shard exceeds the chip)
     if case in DAMPED_CASES:
         assert fired >= 1, "damping case 1 (lbfgs.rs:675-680) never fired: the case does not test it"
-    print(case, {k: f"{v:.2e}" for k, v in worst.items()}, "damping case 1 fired:", fired)
+    print(case, {k: f"{v:.2e}" for k, v in worst.items()}, "damping case 1 fired:", fired, "vector-free:", vf)
+    if case in GRAM_MUST_BE_TRUSTED:
+        assert vf["rejected"] == 0 and vf["kept"] == done, (case, vf)
     for k, v in worst.items():
         assert v <= RTOL, (case, k, v)
 
@@ -226,17 +273,17 @@ def _mem_available():
     return None
 
 
-def test_step_locked_at_the_metric_size():
-    """BASELINE.json's headline configuration (quadratic, n = 1e8, m = 10, More-Thuente, crate defaults) against the
-    ORACLE, not against itself: the oracle runs m+3 iterations on the CPU (history full: bound = m), then the GPU is
-    handed the oracle's inputs of the last iteration and must reproduce f, ||g||, the (s, y, ys) pair and the search
-    direction d of lbfgs.rs:569-604 over all m corrections.
+def _metric_size_case(n, m):
+    """The oracle runs m+3 iterations on the CPU (history full: bound = m).  Along the way the GPU keeps the Gram matrix of
+    the vector-free extension current on the ORACLE's history (one call per history update: it is incremental,
+    include/lbfgs_hip.h) and every one of its directions is compared with the oracle's; after the last iteration the GPU is
+    handed the oracle's inputs of that iteration and must reproduce f, ||g||, the (s, y, ys) pair and the search direction d
+    of lbfgs.rs:569-604 over all m corrections -- by the exact recursion AND by the vector-free one.
 
-    At this size the reference's own sequential sums (math.rs:41) carry a summation-order error that can exceed the
+    At these sizes the reference's own sequential sums (math.rs:41) carry a summation-order error that can exceed the
     north star's 1e-10, so each quantity is also formed by the oracle's primitives in PAIRWISE mode from
     the same inputs: that measures the oracle's self-distance.  Asserted bound: max(1e-10, oracle self-distance) --
     the deviations against both modes are printed and written to gpurun_out/ for DESIGN.md."""
-    n, m = N_METRIC, M_METRIC
     need = (2 * m + 9 + 6) * 8 * n
     avail = _mem_available()
     if avail is not None and avail < need * 1.15:
@@ -244,36 +291,64 @@ def test_step_locked_at_the_metric_size():
     L = O.lib()
     x = np.zeros(n)
     st = O.lbfgs().with_m(m).with_epsilon(0.0).build(x, O.quadratic())
+    rd = lambda a, b: abs(a - b) / abs(b)
+    vf_rows = []
     try:
-        for it in range(m + 3):
-            end_before = st.end
-            if it == m + 2:  # inputs of the last iteration
-                xp_h, gp_h = st.vec("x").copy(), st.vec("gx").copy()
-            p = st.propagate()
-        assert st.k - 1 >= m  # bound = m
-        x_h, g_h = st.vec("x"), st.vec("gx")
-        dev, seq, pair = {}, {}, {}
-        # ---- oracle, sequential (the reference's arithmetic) and pairwise (diagnostic), on identical inputs
-        seq["f"], seq["gnorm"], seq["xnorm"] = p["fx"], p["gnorm"], p["xnorm"]
-        seq["ys"] = st.ys(end_before)
-        s_list = [st.hist(j, "s") for j in range(m)]
-        y_list = [st.hist(j, "y") for j in range(m)]
-        ys_all = np.array([st.ys(j) for j in range(m)])
-        d_seq = st.vec("d")
-        L.oracle_set_dot_mode(1)
-        try:
-            pair["f"], _ = O.eval_builtin(O.quadratic(), np.ascontiguousarray(x_h))
-            pair["gnorm"], pair["xnorm"] = O.vec2norm(g_h), O.vec2norm(x_h)
-            pair["ys"] = O.vecdot(y_list[end_before], s_list[end_before])
-            d_pair = -g_h
-            O.two_loop(s_list, y_list, ys_all.copy(), np.zeros(m), d_pair, st.gamma, m, st.k - 1, end_before)
-        finally:
-            L.oracle_set_dot_mode(0)
-        d_self = rel(d_pair, d_seq)
-        # ---- device
         with R.Context(n) as ctx:
             hist = H.History(ctx, m)
             xv, gv, dv, xpv, gpv = (DeviceVec(ctx) for _ in range(5))
+            for it in range(m + 3):
+                end_before = st.end
+                if it == m + 2:  # inputs of the last iteration
+                    xp_h, gp_h = st.vec("x").copy(), st.vec("gx").copy()
+                p = st.propagate()
+                if p["niter"] == 1:
+                    continue
+                # ---- vector-free extension, maintained over the oracle's run: the pair the oracle has just written goes
+                #      into the same slot on the device, then ONE call refreshes the three changed rows and forms d
+                hist.s(end_before).upload(st.hist(end_before, "s"))
+                hist.y(end_before).upload(st.hist(end_before, "y"))
+                hist.set_scalars(ys=np.array([st.ys(j) for j in range(m)]))
+                ctx.set_scalars(7, [st.gamma, 1.0])
+                gv.upload(st.vec("gx"))
+                row = vector_free_row(ctx, hist, dv, gv, st, end_before, m)
+                d_ref, g_ref = st.vec("d"), st.vec("gx")
+                want_dn2, want_gd = O.vecdot(d_ref, d_ref), O.vecdot(g_ref, d_ref)
+                row.update(iteration=int(p["niter"]), bound=int(min(m, st.k - 1)), d=rel(dv.to_numpy(), d_ref),
+                           dn2=rd(row["dn2"], want_dn2), gd=rd(row["gd"], want_gd))
+                vf_rows.append(row)
+            assert st.k - 1 >= m  # bound = m
+            x_h, g_h = st.vec("x"), st.vec("gx")
+            dev, seq, pair = {}, {}, {}
+            # ---- oracle, sequential (the reference's arithmetic) and pairwise (diagnostic), on identical inputs
+            seq["f"], seq["gnorm"], seq["xnorm"] = p["fx"], p["gnorm"], p["xnorm"]
+            seq["ys"] = st.ys(end_before)
+            s_list = [st.hist(j, "s") for j in range(m)]
+            y_list = [st.hist(j, "y") for j in range(m)]
+            ys_all = np.array([st.ys(j) for j in range(m)])
+            d_seq = st.vec("d")
+            seq["dn2"], seq["gd"] = O.vecdot(d_seq, d_seq), O.vecdot(g_h, d_seq)
+            L.oracle_set_dot_mode(1)
+            try:
+                pair["f"], _ = O.eval_builtin(O.quadratic(), np.ascontiguousarray(x_h))
+                pair["gnorm"], pair["xnorm"] = O.vec2norm(g_h), O.vec2norm(x_h)
+                pair["ys"] = O.vecdot(y_list[end_before], s_list[end_before])
+                d_pair = -g_h
+                alpha_pair = np.zeros(m)
+                O.two_loop(s_list, y_list, ys_all.copy(), alpha_pair, d_pair, st.gamma, m, st.k - 1, end_before)
+                pair["dn2"], pair["gd"] = O.vecdot(d_pair, d_pair), O.vecdot(g_h, d_pair)
+            finally:
+                L.oracle_set_dot_mode(0)
+            d_self = rel(d_pair, d_seq)
+            alpha_seq = np.array([st.alpha(j) for j in range(m)])
+            alpha_self = rel(alpha_pair, alpha_seq)
+            # ---- the vector-free direction of the LAST iteration is still in dv (the loop's last call)
+            d_vf = dv.to_numpy()
+            vf_last = dict(vf_rows[-1])
+            vf_last.update(d_vs_pair=rel(d_vf, d_pair), dn2_vs_pair=rd(ctx.scalars(24)[0], pair["dn2"]),
+                           gd_vs_pair=rd(ctx.scalars(25)[0], pair["gd"]), alpha_vs_pair=rel(hist.scalars()[1], alpha_pair))
+            del d_vf
+            # ---- device, exact path
             xv.upload(x_h)
             H.objective_eval(objectives.Quadratic(), xv, gv, 0)
             dev["f"] = ctx.scalars(0)[0]
@@ -284,12 +359,13 @@ def test_step_locked_at_the_metric_size():
             g_bitwise = bool(np.array_equal(g_dev, g_h))  # element-wise: a*x - b with the reference's roundings
             del g_dev
             xpv.upload(xp_h); gpv.upload(gp_h); gv.upload(g_h)
-            hist.update(end_before, xv, xpv, gv, gpv, p["step"], False, 6)
+            h1 = H.History(ctx, 1)   # (its own one-slot history: the m-slot one keeps the oracle's vectors)
+            h1.update(0, xv, xpv, gv, gpv, p["step"], False, 6)
             dev["ys"] = ctx.scalars(7)[0]
-            s_bitwise = bool(np.array_equal(hist.s(end_before).to_numpy(), s_list[end_before]))
-            y_bitwise = bool(np.array_equal(hist.y(end_before).to_numpy(), y_list[end_before]))
-            for j in range(m):
-                hist.s(j).upload(s_list[j]); hist.y(j).upload(y_list[j])
+            s_bitwise = bool(np.array_equal(h1.s(0).to_numpy(), s_list[end_before]))
+            y_bitwise = bool(np.array_equal(h1.y(0).to_numpy(), y_list[end_before]))
+            h1.free()
+            # every slot of `hist` holds what the oracle last wrote there (uploaded as the run went)
             hist.set_scalars(ys=ys_all, alpha=np.zeros(m))
             ctx.set_scalars(7, [st.gamma, 1.0])
             new_end = hist.two_loop(dv, gv, st.k - 1, end_before, 7, 8, 12)
@@ -297,19 +373,40 @@ def test_step_locked_at_the_metric_size():
             d_dev = dv.to_numpy()
             d_vs_seq, d_vs_pair = rel(d_dev, d_seq), rel(d_dev, d_pair)
             del d_dev
+            dev["dn2"], dev["gd"] = ctx.scalars(12, 2)
+            alpha_dev = hist.scalars()[1]
             hist.free()
             for v in (xv, gv, dv, xpv, gpv):
                 v.free()
     finally:
         st.close()
-    rd = lambda a, b: abs(a - b) / abs(b)
     report = {"n": n, "m": m, "iteration": int(p["niter"]), "g_bitwise": g_bitwise, "s_bitwise": s_bitwise,
               "y_bitwise": y_bitwise}
-    for k in ("f", "gnorm", "xnorm", "ys"):
+    for k in ("f", "gnorm", "xnorm", "ys", "dn2", "gd"):
         report[k] = {"device_vs_sequential_oracle": rd(dev[k], seq[k]), "device_vs_pairwise_oracle": rd(dev[k], pair[k]),
                      "oracle_self_distance": rd(pair[k], seq[k])}
     report["d"] = {"device_vs_sequential_oracle": d_vs_seq, "device_vs_pairwise_oracle": d_vs_pair,
                    "oracle_self_distance": d_self}
+    report["alpha"] = {"device_vs_sequential_oracle": rel(alpha_dev, alpha_seq), "device_vs_pairwise_oracle": rel(alpha_dev, alpha_pair),
+                       "oracle_self_distance": alpha_self}
+    # the vector-free extension: every iteration of the oracle's run against the sequential oracle, the last one also
+    # against the pairwise oracle; with the guard's own figures beside the deviations
+    report["vector_free"] = {
+        "rows": vf_rows,
+        "last_iteration": {
+            "d": {"device_vs_sequential_oracle": vf_last["d"], "device_vs_pairwise_oracle": vf_last["d_vs_pair"],
+                  "oracle_self_distance": d_self},
+            "dn2": {"device_vs_sequential_oracle": vf_last["dn2"], "device_vs_pairwise_oracle": vf_last["dn2_vs_pair"],
+                    "oracle_self_distance": report["dn2"]["oracle_self_distance"]},
+            "gd": {"device_vs_sequential_oracle": vf_last["gd"], "device_vs_pairwise_oracle": vf_last["gd_vs_pair"],
+                   "oracle_self_distance": report["gd"]["oracle_self_distance"]},
+            "alpha": {"device_vs_sequential_oracle": vf_last["alpha"], "device_vs_pairwise_oracle": vf_last["alpha_vs_pair"],
+                      "oracle_self_distance": alpha_self},
+            "prediction_error": vf_last["prediction_error"], "cancellation": vf_last["cancellation"]},
+        "guard": {"rejected": sum(not r["trusted"] for r in vf_rows),
+                  "cancellation_max": max(r["cancellation"] for r in vf_rows),
+                  "prediction_error_max": max(r["prediction_error"] for r in vf_rows)},
+    }
     print(json.dumps(report, indent=1))
     outdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
@@ -318,8 +415,30 @@ def test_step_locked_at_the_metric_size():
     except OSError:
         pass
     assert g_bitwise and s_bitwise and y_bitwise
-    for k in ("f", "gnorm", "xnorm", "ys", "d"):
+    for k in ("f", "gnorm", "xnorm", "ys", "dn2", "gd", "d", "alpha"):
         r = report[k]
         bound = max(RTOL, r["oracle_self_distance"])
         assert r["device_vs_sequential_oracle"] <= bound, (k, r)
         assert r["device_vs_pairwise_oracle"] <= bound, (k, r)
+    # vector-free: healthy at this size (the guard keeps every direction), and inside the same bound
+    assert report["vector_free"]["guard"]["rejected"] == 0, report["vector_free"]["guard"]
+    for k in ("d", "dn2", "gd", "alpha"):
+        r = report["vector_free"]["last_iteration"][k]
+        bound = max(RTOL, r["oracle_self_distance"])
+        assert r["device_vs_sequential_oracle"] <= bound, ("vector_free", k, r)
+        assert r["device_vs_pairwise_oracle"] <= bound, ("vector_free", k, r)
+    for r in vf_rows:   # earlier iterations: against the sequential oracle, flat bar unless the last one's self-distance is larger
+        for k in ("d", "dn2", "gd", "alpha"):
+            assert r[k] <= max(RTOL, report[k]["oracle_self_distance"]), ("vector_free", r["iteration"], k, r)
+
+
+def test_step_locked_at_the_metric_size():
+    """BASELINE.json's headline configuration (quadratic, n = 1e8, m = 10, More-Thuente, crate defaults) against the
+    ORACLE, not against itself; exact recursion and vector-free extension."""
+    _metric_size_case(N_METRIC, M_METRIC)
+
+
+def test_step_locked_at_the_8gpu_shard_size():
+    """The same at n = 12 500 224 = rank 0's shard of the 8-GPU run (the size at which the vector-free extension is carried as
+    the latency escape hatch in profiles/r04_scaling_model.md): all of q on the chip, the on-chip Gram kernels."""
+    _metric_size_case(int(os.environ.get("LBFGS_TEST_SHARD_N", 12_500_224)), M_METRIC)

@@ -23,7 +23,7 @@ for k in ${2:-2 3 5}; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 tools/run_configs.py --only config$k > "$out/stats.log" 2>&1
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- python3 tools/run_configs.py --only config$k > "$out/pmc_fetch.log" 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- python3 tools/run_configs.py --only config$k > "$out/pmc_write.log" 2>&1
-  python3 tools/summarize_profile.py "$out/stats" "$out/pmc_fetch" "$out/pmc_write" $n "$out/summary.md" "${tag}_config$k" $m > /dev/null
+  LBFGS_PROFILE_COMMAND="tools/run_configs.py --only config$k" python3 tools/summarize_profile.py "$out/stats" "$out/pmc_fetch" "$out/pmc_write" $n "$out/summary.md" "${tag}_config$k" $m > /dev/null
   cp "$out"/stats/*/*_kernel_stats.csv "$out/kernel_stats.csv"
   cat "$out"/pmc_fetch/*/*_counter_collection.csv > "$out/pmc_fetch_counter_collection.csv"
   cat "$out"/pmc_write/*/*_counter_collection.csv > "$out/pmc_write_counter_collection.csv"

@@ -26,7 +26,7 @@ python3 bench.py $size > "$out/bench.json" 2> "$out/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py $size --steps ${STEPS:-400} --repeats 1 --warmup 12 --no-cpu-baseline --no-vector-free > "$out/stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- python3 bench.py $size --steps 4 --warmup 12 --no-cpu-baseline --no-prof --no-vector-free > "$out/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- python3 bench.py $size --steps 4 --warmup 12 --no-cpu-baseline --no-prof --no-vector-free > "$out/pmc_write.log" 2>&1
-python3 tools/summarize_profile.py "$out/stats" "$out/pmc_fetch" "$out/pmc_write" $dim "$out/summary.md" "$tag" $hist "$out/bench.json" > /dev/null
+LBFGS_PROFILE_COMMAND=bench.py python3 tools/summarize_profile.py "$out/stats" "$out/pmc_fetch" "$out/pmc_write" $dim "$out/summary.md" "$tag" $hist "$out/bench.json" > /dev/null
 cp "$out"/stats/*/*_kernel_stats.csv "$out/kernel_stats.csv"
 # the RAW counter rows behind roofline.traffic (one row per dispatch; a few hundred KB) are kept and committed
 cat "$out"/pmc_fetch/*/*_counter_collection.csv > "$out/pmc_fetch_counter_collection.csv"

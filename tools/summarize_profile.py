@@ -189,7 +189,11 @@ def main():
                 full_us = sum(fl) / len(fl)
         algo = resident_bytes if (resident_bytes and "resident" in kname) else (
             (4 * M + 1) * 8 * n_local if "resident" in kname else 32 * n_local)
-        json.dump({"build_id": build_id, "resident_elements": resident_elements, "algorithmic_bytes_per_launch": round(algo),
+        # which command the passes profiled: bench.py's roofline.traffic only accepts its own (tools/profile_round.sh sets it;
+        # tools/profile_configs.sh profiles tools/run_configs.py -- other objectives, OWL-QN, damping -- at sizes bench.py can
+        # also be asked to run)
+        command = os.environ.get("LBFGS_PROFILE_COMMAND") or ("bench.py" if len(sys.argv) > 8 else "unknown")
+        json.dump({"build_id": build_id, "command": command, "resident_elements": resident_elements, "algorithmic_bytes_per_launch": round(algo),
                    "rocprof_avg_us_full_depth_launches": full_us,"_source": f"profiles/{tag}_pmc_fetch_counter_collection.csv + profiles/{tag}_pmc_write_counter_collection.csv "
                               "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python3 bench.py`, averaged over the "
                               "dispatches of the kernel; FETCH_SIZE x2: gfx950 correction of MI355X_MICROARCH.md section HBM; KiB)",
