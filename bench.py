@@ -327,6 +327,7 @@ def make_context(env, kind):
         # one rank per GPU (the driver's launch) unless --device forces several ranks onto one card (tests).
         # The "p2p" leg means mailboxes in DEVICE memory, strictly (no silent retry: host placement is its own leg).
         ctx = sharded_context(a.n, device=env.dev, kind={"p2p": "p2p-device"}.get(kind, kind),
+                              process_group=getattr(env, "group", None),  # (None: torch.distributed; tools/eight_ranks_one_gpu.py brings its own)
                               exclusive_device=(a.device < 0) if a.exclusive_device < 0 else bool(a.exclusive_device))
         # known-answer reductions through the real code path before trusting it
         tri = env.world * (env.world + 1) / 2.0

@@ -39,13 +39,14 @@
 extern "C" {
 #endif
 
-/* 3: lbfgs_hip_ctx_comm_info / lbfgs_hip_comm_info (round 4); lbfgs_hip_sync, lbfgs_hip_vec_download and
+/* 4: lbfgs_evaluator (lbfgs_solver.h) grew device_probe / device_accept: deferred trial points for device closures (round 5).
+ * 3: lbfgs_hip_ctx_comm_info / lbfgs_hip_comm_info (round 4); lbfgs_hip_sync, lbfgs_hip_vec_download and
  *    lbfgs_hip_history_scalars_read report device errors (and recover from a timed-out resident two-loop) like
  *    lbfgs_hip_scalars_read.
  * 2: lbfgs_hip_objective.skin, lbfgs_hip_comm.exclusive_device, LBFGS_HIP_K_TWOLOOP_RESIDENT (all round 2, unversioned then),
  *    mailbox placements, lbfgs_hip_build_id.  A caller compares lbfgs_hip_abi_version() with the constant it was built
  *    against before anything else (rust-lbfgs_amd/_ffi.py, integration/rust-shim, tests/support/c_caller.c do). */
-#define LBFGS_HIP_ABI_VERSION 3
+#define LBFGS_HIP_ABI_VERSION 4
 #define LBFGS_HIP_BOARD_SLOTS 256
 
 /* status codes */

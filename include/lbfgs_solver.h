@@ -77,6 +77,23 @@ enum { LBFGS_EVAL_HOST = 0, LBFGS_EVAL_DEVICE = 1, LBFGS_EVAL_BUILTIN = 2 };
 typedef double (*lbfgs_host_eval_cb)(void* user, const double* x, double* g, uint64_t n_local, int* failed);
 typedef double (*lbfgs_device_eval_cb)(void* user, const void* x_dev, void* g_dev, uint64_t n_local, void* stream,
                                        int* failed);
+/* DEFERRED TRIAL POINTS for device closures (ABI version 4; optional).  A line search reads two scalars from each trial --
+ * f and g.d (line.rs:283-288, :740-753) -- and only the LAST trial's x and g are ever used again (by IterationData::update,
+ * lbfgs.rs:525).  A DEVICE evaluator that also supplies `device_probe` lets the solver run a search of T trials as T probes
+ * + ONE materialisation of the accepted point, instead of T x (take_line_step + evaluate + dg_unchecked: core.rs:155-164,
+ * 119-121, 114-116) -- the protocol the built-in element-wise objectives already follow (lbfgs_hip_objective_line_probe):
+ *   probe   returns f(xp + step*d) and stores grad f(xp + step*d) . d in *dg_out; writes NO vector of the optimiser.
+ *           With world > 1: this rank's partial sums of both (the solver all-reduces them).
+ *   accept  x_out = xp + step*d (a multiply, then an add: core.rs:157-158), g_out = grad f(x_out); the return value is
+ *           ignored (the search already holds f of that point: the last probe's).  Optional: without it the solver forms
+ *           the accepted point with lbfgs_hip_line_step + `device`.
+ * Both receive the context's stream after it has been synchronised, like `device`.  The trajectory equals the undeferred
+ * one bit for bit whenever the closure's probe and evaluate agree on f and g.d bit for bit.  Used inside lbfgs_propagate only,
+ * never under OWL-QN (the orthant projection needs x), never by the stand-alone lbfgs_line_search (its caller reads x). */
+typedef double (*lbfgs_device_probe_cb)(void* user, const void* xp_dev, const void* d_dev, double step, uint64_t n_local,
+                                        void* stream, double* dg_out, int* failed);
+typedef double (*lbfgs_device_accept_cb)(void* user, const void* xp_dev, const void* d_dev, double step, void* x_out_dev,
+                                         void* g_out_dev, uint64_t n_local, void* stream, int* failed);
 typedef struct lbfgs_evaluator {
     int32_t kind;
     int32_t fuse_line_eval;  /* BUILTIN: 0 = line step, evaluate, g.d as separate passes; 1 = one pass per trial;
@@ -87,6 +104,8 @@ typedef struct lbfgs_evaluator {
     lbfgs_device_eval_cb device;
     void* user;
     lbfgs_hip_objective builtin;
+    lbfgs_device_probe_cb device_probe;    /* DEVICE, optional (NULL = every trial is a full evaluate): see above */
+    lbfgs_device_accept_cb device_accept;  /* DEVICE, optional, only read when device_probe is set */
 } lbfgs_evaluator;
 
 /* Progress (core.rs:223-250); x and gx stay on the device: fetch them with lbfgs_state_download */

@@ -10,7 +10,7 @@ use std::os::raw::{c_char, c_int, c_void};
 
 /// `LBFGS_HIP_ABI_VERSION` of the `include/lbfgs_hip.h` these declarations mirror; `Context::new` refuses a library
 /// that reports another one (struct layouts are shared by value).
-pub const LBFGS_HIP_ABI_VERSION: i32 = 3;
+pub const LBFGS_HIP_ABI_VERSION: i32 = 4;
 pub const LBFGS_HIP_OK: c_int = 0;
 pub const LBFGS_ERR_EVALUATE: c_int = -1;
 pub const LBFGS_PANIC_OWLQN_RANGE: c_int = -20;
@@ -113,6 +113,18 @@ pub type lbfgs_device_eval_cb = Option<
                          failed: *mut c_int) -> f64,
 >;
 
+/// Deferred trial points for device closures (include/lbfgs_solver.h, ABI version 4): a line search reads f and g.d from each
+/// trial (src/line.rs:283-288); `probe` returns f(xp + step*d) and stores grad.d in `dg_out` without writing a vector,
+/// `accept` forms x = xp + step*d and g = grad f(x) once, for the accepted step.
+pub type lbfgs_device_probe_cb = Option<
+    unsafe extern "C" fn(user: *mut c_void, xp_dev: *const c_void, d_dev: *const c_void, step: f64, n_local: u64,
+                         stream: *mut c_void, dg_out: *mut f64, failed: *mut c_int) -> f64,
+>;
+pub type lbfgs_device_accept_cb = Option<
+    unsafe extern "C" fn(user: *mut c_void, xp_dev: *const c_void, d_dev: *const c_void, step: f64, x_out_dev: *mut c_void,
+                         g_out_dev: *mut c_void, n_local: u64, stream: *mut c_void, failed: *mut c_int) -> f64,
+>;
+
 #[repr(C)]
 pub struct lbfgs_evaluator {
     pub kind: i32,
@@ -121,6 +133,8 @@ pub struct lbfgs_evaluator {
     pub device: lbfgs_device_eval_cb,
     pub user: *mut c_void,
     pub builtin: lbfgs_hip_objective,
+    pub device_probe: lbfgs_device_probe_cb,
+    pub device_accept: lbfgs_device_accept_cb,
 }
 
 #[repr(C)]

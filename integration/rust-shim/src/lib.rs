@@ -13,7 +13,9 @@
 //! `minimize` keeps `E: FnMut(&[f64], &mut [f64]) -> Result<f64>` (src/lbfgs.rs:401): x is downloaded and gx
 //! uploaded around every evaluation.  That is the compatibility path (PCIe-bound); `minimize_builtin` runs one of
 //! the device-resident objectives with no host traffic, and a device-pointer closure can be passed through
-//! `ffi::lbfgs_evaluator { kind: LBFGS_EVAL_DEVICE, .. }` by callers that own HIP kernels.
+//! `ffi::lbfgs_evaluator { kind: LBFGS_EVAL_DEVICE, .. }` by callers that own HIP kernels -- optionally with
+//! `device_probe` / `device_accept`, so that a line search of T trials costs T probes (f and g.d, nothing written) and one
+//! materialisation of the accepted point instead of T full evaluations (include/lbfgs_solver.h).
 pub mod ffi;
 
 use anyhow::{anyhow, bail, Result};
@@ -210,6 +212,8 @@ impl Lbfgs {
             device: None,
             user: ptr::null_mut(),
             builtin: obj,
+            device_probe: None,
+            device_accept: None,
         };
         self.run(x, &ev, prgr_fn)
     }
@@ -334,6 +338,8 @@ where
         device: None,
         user: bridge as *mut HostBridge<F> as *mut c_void,
         builtin: no_objective(),
+        device_probe: None,
+        device_accept: None,
     }
 }
 

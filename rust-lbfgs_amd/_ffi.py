@@ -24,7 +24,7 @@ LS_MORETHUENTE, LS_BT_ARMIJO, LS_BT_STRONGWOLFE, LS_BT_WOLFE = 0, 1, 2, 3
 EVAL_HOST, EVAL_DEVICE, EVAL_BUILTIN = 0, 1, 2
 COMM_NONE, COMM_RCCL, COMM_CALLBACK, COMM_P2P = 0, 1, 2, 3
 MAILBOX_AUTO, MAILBOX_DEVICE, MAILBOX_HOST = -1, 0, 1
-ABI_VERSION = 3  # LBFGS_HIP_ABI_VERSION of the include/lbfgs_hip.h these declarations were written against
+ABI_VERSION = 4  # LBFGS_HIP_ABI_VERSION of the include/lbfgs_hip.h these declarations were written against
 OBJ_QUADRATIC, OBJ_LOGISTIC, OBJ_ROSENBROCK, OBJ_LJ_ALLPAIRS, OBJ_LJ_NEIGHBORS, OBJ_LJ_CELLS = 1, 2, 3, 4, 5, 6
 (K_TWOLOOP_STEP, K_TWOLOOP_EDGE, K_UPDATE, K_LINE, K_EVAL, K_OWLQN, K_BLAS1, K_COMM, K_TWOLOOP_ALL,
  K_TWOLOOP_RESIDENT) = range(10)
@@ -82,9 +82,17 @@ DEVICE_EVAL_CB = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c
                              C.POINTER(C.c_int))
 
 
+# deferred trial points for device closures (lbfgs_solver.h, ABI version 4)
+DEVICE_PROBE_CB = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_uint64, C.c_void_p,
+                              C.POINTER(C.c_double), C.POINTER(C.c_int))
+DEVICE_ACCEPT_CB = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_uint64,
+                               C.c_void_p, C.POINTER(C.c_int))
+
+
 class Evaluator(C.Structure):
     _fields_ = [("kind", C.c_int32), ("fuse_line_eval", C.c_int32), ("host", HOST_EVAL_CB),
-                ("device", DEVICE_EVAL_CB), ("user", C.c_void_p), ("builtin", Objective)]
+                ("device", DEVICE_EVAL_CB), ("user", C.c_void_p), ("builtin", Objective),
+                ("device_probe", DEVICE_PROBE_CB), ("device_accept", DEVICE_ACCEPT_CB)]
 
 
 class CProgress(C.Structure):
@@ -321,17 +329,23 @@ def load():
     if got != ABI_VERSION:  # struct layouts are shared by value: never talk to a library with another one
         raise ImportError(f"{hip} has ABI version {got}, this package was written against {ABI_VERSION}: rebuild "
                           "(python -c 'import rust_lbfgs_amd as r; r.build()')")
-    lib = declare(raw)
     if os.path.realpath(libdir) == os.path.realpath(HERE) and os.environ.get("LBFGS_HIP_ALLOW_STALE") != "1":
         # In-tree libraries must belong to the checked-out sources (builds are content-addressed: _build.py).  A library of
         # the same ABI built from other sources -- older kernels -- is refused, not trusted; prebuilt libraries somewhere
         # else (LBFGS_HIP_LIB_DIR: deployments, A/B builds) carry whatever id they were built with and are taken as they are.
+        # Checked BEFORE any symbol is declared, from the ids embedded in the FILES: a stale library of the same ABI version
+        # may lack a symbol added since, and "rebuild" is the answer then too, not an AttributeError from declare().
         from . import _build
 
-        have = (lib.lbfgs_hip_build_id().decode(), lib.lbfgs_solver_build_id().decode())
-        want = (_build.hip_build_id(), _build.solver_build_id())
+        have = (_build.embedded_id(hip, "LBFGS_HIP_BUILD_ID"), _build.embedded_id(solver, "LBFGS_SOLVER_BUILD_ID"))
+        try:
+            want = (_build.hip_build_id(), _build.solver_build_id())
+        except OSError as e:  # (a deployment that ships the libraries without csrc/)
+            raise ImportError(f"the sources the in-tree libraries are checked against are not available ({e}); set "
+                              "LBFGS_HIP_ALLOW_STALE=1 to load them as they are, or LBFGS_HIP_LIB_DIR to name prebuilt ones") from e
         if have != want:
             raise ImportError(f"{hip} / {solver} carry build ids {have}, the checked-out sources hash to {want}: rebuild "
                               "(python -c 'import rust_lbfgs_amd as r; r.build()'), or set LBFGS_HIP_ALLOW_STALE=1 to load them anyway")
+    lib = declare(raw)
     _LIB = lib
     return _LIB

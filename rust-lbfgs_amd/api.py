@@ -167,10 +167,19 @@ class Context:
 
 # ------------------------------------------------------------------------------------ evaluators
 class DeviceEvaluate:
-    """`evaluate` on device pointers: fn(x_ptr:int, g_ptr:int, n_local:int, stream:int) -> float."""
+    """`evaluate` on device pointers: fn(x_ptr:int, g_ptr:int, n_local:int, stream:int) -> float.
 
-    def __init__(self, fn):
+    Optional DEFERRED TRIAL POINTS (lbfgs_solver.h, lbfgs_evaluator.device_probe / device_accept): a line search reads only
+    f and g.d from each trial (line.rs:283-288); with
+        probe(xp_ptr, d_ptr, step, n_local, stream) -> (f(xp + step*d), grad f(xp + step*d) . d)       nothing written
+        accept(xp_ptr, d_ptr, step, x_out_ptr, g_out_ptr, n_local, stream) -> None                     x = xp + step*d, g = grad f(x)
+    a search of T trials costs T probes + one accept instead of T x (line step + evaluate + dot).  `accept` may be omitted
+    (the solver then forms the accepted point with its line-step kernel + `fn`)."""
+
+    def __init__(self, fn, probe=None, accept=None):
         self.fn = fn
+        self.probe = probe
+        self.accept = accept
 
 
 class _DevArray:
@@ -187,11 +196,26 @@ class TorchEvaluate(DeviceEvaluate):
             ...
     x and g are float64 CUDA(HIP) tensors that VIEW the optimiser's buffers of this rank's shard."""
 
-    def __init__(self, fn, device=0):
+    def __init__(self, fn, device=0, probe=None, accept=None):
+        """probe(xp, d, step) -> (f, g.d) and accept(xp, d, step, x_out, g_out) on tensors that view the optimiser's buffers:
+        the deferred-trial protocol of DeviceEvaluate."""
         import torch
 
         self._torch = torch
         self._dev = torch.device("cuda", device)
+        view = lambda ptr, n: (torch.as_tensor(_DevArray(ptr, n), device=self._dev) if n else  # noqa: E731
+                               torch.empty(0, dtype=torch.float64, device=self._dev))
+        num = lambda v: float(v.detach()) if hasattr(v, "detach") else float(v)  # noqa: E731
+
+        def raw_probe(xpptr, dptr, step, n, stream):
+            f, dg = probe(view(xpptr, n), view(dptr, n), step)
+            f, dg = num(f), num(dg)
+            torch.cuda.synchronize(self._dev)
+            return f, dg
+
+        def raw_accept(xpptr, dptr, step, xptr, gptr, n, stream):
+            accept(view(xpptr, n), view(dptr, n), step, view(xptr, n), view(gptr, n))
+            torch.cuda.synchronize(self._dev)
 
         def raw(xptr, gptr, n, stream):
             if n == 0:
@@ -204,7 +228,8 @@ class TorchEvaluate(DeviceEvaluate):
             torch.cuda.synchronize(self._dev)
             return f
 
-        super().__init__(raw)
+        super().__init__(raw, probe=raw_probe if probe is not None else None,
+                         accept=raw_accept if (probe is not None and accept is not None) else None)
 
 
 @dataclass
@@ -253,7 +278,34 @@ def _make_evaluator(evaluate, ctx=None):
         cb = _ffi.DEVICE_EVAL_CB(dtramp)
         ev.kind = _ffi.EVAL_DEVICE
         ev.device = cb
-        return ev, cb, holder
+        keep = [cb]
+        if getattr(evaluate, "probe", None) is not None:
+            def ptramp(_user, xpptr, dptr, step, n, stream, dg_out, failed):
+                try:
+                    f, dg = evaluate.probe(xpptr, dptr, step, n, stream)
+                    dg_out[0] = float(dg)
+                    return float(f)
+                except Exception as e:  # Err(..)
+                    holder["exc"] = e
+                    failed[0] = 1
+                    return 0.0
+
+            pcb = _ffi.DEVICE_PROBE_CB(ptramp)
+            ev.device_probe = pcb
+            keep.append(pcb)
+            if getattr(evaluate, "accept", None) is not None:
+                def atramp(_user, xpptr, dptr, step, xptr, gptr, n, stream, failed):
+                    try:
+                        evaluate.accept(xpptr, dptr, step, xptr, gptr, n, stream)
+                    except Exception as e:  # Err(..)
+                        holder["exc"] = e
+                        failed[0] = 1
+                    return 0.0
+
+                acb = _ffi.DEVICE_ACCEPT_CB(atramp)
+                ev.device_accept = acb
+                keep.append(acb)
+        return ev, keep, holder
 
     def tramp(_user, xp, gp, n, failed):
         x = np.ctypeslib.as_array(xp, shape=(n,))

@@ -112,6 +112,27 @@ hipError_t ipc_open_cached(const hipIpcMemHandle_t& hdl, void** out) {
     return e;
 }
 
+// Device-placed mailboxes created by THIS process, keyed by the 64 bytes of the IPC handle they export.  A process that hosts
+// several ranks (several contexts, one host thread each) reaches a same-process peer's mailbox through the pointer itself:
+// hipIpcOpenMemHandle refuses handles of the opening process's own allocations.  Entries stay for the life of the process (a
+// retired mailbox is pooled, never freed, and exports the same handle when it is used again).
+struct LocalMbox {
+    void* p;
+    int device;
+};
+std::map<std::string, LocalMbox> g_local_mbox;
+void local_mbox_register(const hipIpcMemHandle_t& hdl, void* p, int device) {
+    std::lock_guard<std::mutex> lk(g_uc_pool_mu);
+    g_local_mbox[std::string(reinterpret_cast<const char*>(&hdl), sizeof(hdl))] = LocalMbox{p, device};
+}
+bool local_mbox_lookup(const hipIpcMemHandle_t& hdl, LocalMbox* out) {
+    std::lock_guard<std::mutex> lk(g_uc_pool_mu);
+    auto it = g_local_mbox.find(std::string(reinterpret_cast<const char*>(&hdl), sizeof(hdl)));
+    if (it == g_local_mbox.end()) return false;
+    *out = it->second;
+    return true;
+}
+
 void host_mbox_unlink_all() {  // atexit: names of segments this process still owns
     std::lock_guard<std::mutex> lk(g_host_mbox_mu);
     for (auto& kv : g_host_mbox)
@@ -484,6 +505,7 @@ int lbfgs_hip_p2p_mailbox_create2(int device, int placement, void** mailbox_out,
         if (p) uc_mbox_retire(device, p);
         return fail(nullptr, LBFGS_HIP_ERR_COMM, "P2P mailbox: %s", hipGetErrorString(e));
     }
+    local_mbox_register(hdl, p, device);
     memcpy(ipc_handle64_out, &hdl, HIP_IPC_HANDLE_SIZE);
     *mailbox_out = p;
     return LBFGS_HIP_OK;
@@ -757,7 +779,21 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
             memcpy(&hdl, hraw, sizeof(hdl));
             // (LBFGS_HIP_TEST_FAIL_IPC_OPEN=1: tests of the host-placement fallback pretend the mapping is refused)
             const char* fail_hook = getenv("LBFGS_HIP_TEST_FAIL_IPC_OPEN");
-            hipError_t e = (fail_hook && atoi(fail_hook) != 0) ? hipErrorInvalidValue : ipc_open_cached(hdl, &p);
+            LocalMbox lm{nullptr, -1};
+            hipError_t e;
+            if (fail_hook && atoi(fail_hook) != 0) {
+                e = hipErrorInvalidValue;
+            } else if (local_mbox_lookup(hdl, &lm)) {  // a rank hosted by this same process: its mailbox is addressable as it is
+                e = hipSuccess;
+                p = lm.p;
+                if (lm.device != ctx->device) {  // (one process driving several GPUs: the stores need peer access)
+                    const hipError_t pe = hipDeviceEnablePeerAccess(lm.device, 0);
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) e = pe;
+                    (void)hipGetLastError();
+                }
+            } else {
+                e = ipc_open_cached(hdl, &p);
+            }
             if (e != hipSuccess) {
                 int rc = fail(nullptr, LBFGS_HIP_ERR_COMM, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
                 lbfgs_hip_ctx_destroy(ctx);

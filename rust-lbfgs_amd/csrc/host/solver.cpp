@@ -315,8 +315,82 @@ int evaluate_here(lbfgs_state* st, bool want_dg, double* dg_out) {
 }
 
 // take_line_step + evaluate + dg_unchecked (line.rs:283-288 / :740-753) for one trial step.
+// A deferred trial of a DEVICE closure (lbfgs_evaluator.device_probe): f and g.d at xp + t*d, no vector written.
+int probe_device(lbfgs_state* st, double t, double* dg_out) {
+    const uint64_t nl = st->shard.n_local;
+    int failed = 0;
+    double f = 0.0, dg = 0.0;
+    int local_rc = backend(st, lbfgs_hip_sync(st->ctx));  // (rank-local failures are folded into `failed`, as in call_user_evaluate)
+    const std::string local_err = st->err;
+    if (local_rc == LBFGS_OK)
+        f = st->eval.device_probe(st->eval.user, lbfgs_hip_vec_ptr(st->xp), lbfgs_hip_vec_ptr(st->d), t, nl,
+                                  lbfgs_hip_stream(st->ctx), &dg, &failed);
+    else
+        failed = 1;
+    if (st->shard.world > 1) {  // partial f and g.d per shard; a failure on any rank fails all
+        double v[2] = {failed ? 0.0 : f, failed ? 0.0 : dg}, nf = failed ? 1.0 : 0.0;
+        static_assert(S_DG == S_F + 1, "f and g.d travel in one all-reduce");
+        TRYB(st, lbfgs_hip_scalars_write(st->ctx, S_F, 2, v));
+        TRYB(st, lbfgs_hip_scalars_write(st->ctx, S_FAILED, 1, &nf));
+        TRYB(st, lbfgs_hip_scalars_allreduce(st->ctx, S_F, 2));
+        TRYB(st, lbfgs_hip_scalars_allreduce(st->ctx, S_FAILED, 1));
+        TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_FAILED, 1, &nf));
+        if (local_rc != LBFGS_OK) return fail(st, local_rc, local_err);
+        if (nf != 0.0) return fail(st, LBFGS_ERR_EVALUATE, "evaluate failed");
+        TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_F, 2, v));
+        f = v[0];
+        dg = v[1];
+    } else {
+        if (local_rc != LBFGS_OK) return fail(st, local_rc, local_err);
+        if (failed) return fail(st, LBFGS_ERR_EVALUATE, "evaluate failed");
+    }
+    st->fx = f;
+    if (dg_out) *dg_out = dg;
+    return LBFGS_OK;
+}
+
+// The accepted point of a search whose trials were device probes: x = xp + t*d, gx = grad f(x) -- by the closure's own
+// `device_accept`, or by take_line_step + the full evaluate (core.rs:155-158, 119-121).  Neither neval nor fx change: the
+// reference evaluated this point once, as the search's last trial, and that is the probe already counted.
+int materialise_device_point(lbfgs_state* st) {
+    const uint64_t nl = st->shard.n_local;
+    if (!st->eval.device_accept) {
+        TRYB(st, lbfgs_hip_line_step(st->x, st->xp, st->d, st->t_eval, nullptr, 0, 0));
+        const double fx = st->fx;
+        const int rc = call_user_evaluate(st);  // (collective when world > 1, like every evaluate)
+        st->fx = fx;
+        return rc;
+    }
+    int failed = 0;
+    int local_rc = backend(st, lbfgs_hip_sync(st->ctx));
+    const std::string local_err = st->err;
+    if (local_rc == LBFGS_OK)
+        (void)st->eval.device_accept(st->eval.user, lbfgs_hip_vec_ptr(st->xp), lbfgs_hip_vec_ptr(st->d), st->t_eval,
+                                     lbfgs_hip_vec_ptr(st->x), lbfgs_hip_vec_ptr(st->gx), nl, lbfgs_hip_stream(st->ctx), &failed);
+    else
+        failed = 1;
+    if (st->shard.world > 1) {
+        double nf = failed ? 1.0 : 0.0;
+        TRYB(st, lbfgs_hip_scalars_write(st->ctx, S_FAILED, 1, &nf));
+        TRYB(st, lbfgs_hip_scalars_allreduce(st->ctx, S_FAILED, 1));
+        TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_FAILED, 1, &nf));
+        failed = failed || nf != 0.0;
+    }
+    if (local_rc != LBFGS_OK) return fail(st, local_rc, local_err);
+    if (failed) return fail(st, LBFGS_ERR_EVALUATE, "evaluate failed (device_accept)");
+    return LBFGS_OK;
+}
+
 int trial(lbfgs_state* st, double t, bool want_dg, double* dg_out) {
     st->trials += 1;
+    if (st->defer_trials && st->eval.kind == LBFGS_EVAL_DEVICE) {
+        TRY(probe_device(st, t, dg_out));
+        st->norms_valid = false;
+        st->neval += 1;
+        st->t_eval = t;
+        st->point_deferred = true;
+        return LBFGS_OK;
+    }
     if (st->defer_trials) {  // f and g.d only; x and gx stay unwritten until the update
         TRYB(st, lbfgs_hip_objective_line_probe(&st->eval.builtin, st->xp, st->d, t, S_F));
         double b[2];
@@ -556,8 +630,10 @@ int line_search_find(lbfgs_state* st, double& step, uint64_t* ncall, bool may_de
     const lbfgs_param& pr = st->vars;
     st->trials = 0;
     st->point_deferred = false;
-    st->defer_trials = may_defer && st->eval.kind == LBFGS_EVAL_BUILTIN && st->eval.fuse_line_eval >= 2 &&
-                       !st->owlqn() && lbfgs_hip_objective_is_elementwise(&st->eval.builtin);
+    st->defer_trials = may_defer && !st->owlqn() &&
+                       ((st->eval.kind == LBFGS_EVAL_BUILTIN && st->eval.fuse_line_eval >= 2 &&
+                         lbfgs_hip_objective_is_elementwise(&st->eval.builtin)) ||
+                        (st->eval.kind == LBFGS_EVAL_DEVICE && st->eval.device_probe != nullptr));
     struct Reset {
         lbfgs_state* s;
         ~Reset() { s->defer_trials = false; }
@@ -813,8 +889,8 @@ int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
     st->norms_valid = false;
 
     uint64_t ncall = 0;
+    const double fx0 = st->fx;  // f at the point the search starts from
     {
-        const double fx0 = st->fx;  // f at the point the search starts from
         const int rc_ls = line_search_find(st, st->step, &ncall, true);  // :517-521
         if (rc_ls != LBFGS_OK) {
             // a hard error (negative step, gradient-only + More-Thuente, backend / communicator failure): the
@@ -841,7 +917,18 @@ int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
     // decision sits in between (Powell damping), the early read is kept.
     const int damping = st->vars.damping;
     const bool early = damping || !st->ls_err.empty();
-    if (st->point_deferred) {  // the trials left x and gx unwritten: take the accepted step in the update's pass
+    if (st->point_deferred && st->eval.kind == LBFGS_EVAL_DEVICE) {  // probes of a device closure: form the accepted point now
+        st->point_deferred = false;
+        const int rc_acc = materialise_device_point(st);
+        if (rc_acc != LBFGS_OK) {  // the closure refused the accepted point: as after a hard search error, x names the start point again
+            (void)lbfgs_hip_vec_swap(st->x, st->xp);
+            (void)lbfgs_hip_vec_swap(st->gx, st->gp);
+            st->fx = fx0;
+            st->norms_valid = false;
+            return rc_acc;
+        }
+        TRYB(st, lbfgs_hip_history_update(st->hist, st->end, st->x, st->xp, st->gx, st->gp, st->step, damping, S_UPD));
+    } else if (st->point_deferred) {  // the trials left x and gx unwritten: take the accepted step in the update's pass
         TRYB(st, lbfgs_hip_history_update_from_step(st->hist, st->end, &st->eval.builtin, st->x, st->xp, st->d, st->t_eval,
                                                     st->gx, st->gp, st->step, damping, S_UPD));
         st->point_deferred = false;

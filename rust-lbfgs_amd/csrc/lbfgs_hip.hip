@@ -262,7 +262,9 @@ int gram_combine_resident(lbfgs_hip_ctx* ctx, const double* const* cols, int nb,
     for (int j = 0; j < nb; ++j) a.in[j] = cols[j];
     a.d = d; a.delta = delta; a.n = n; a.nb = nb;
     a.pred = pred;
-    a.lead = ctx->shard.offset == 0 ? 1 : 0;  // (the rank that owns element 0 carries the prediction into the third sum)
+    // the rank that owns global element 0 carries the prediction into the third and fourth sums: exactly ONE rank (an empty
+    // rank 0 and its successor both have offset 0: the all-reduced prediction would double and every direction fail its check)
+    a.lead = (ctx->shard.offset == 0 && n > 0) ? 1 : 0;
     a.total_rounds = (uint32_t)total;
     a.tile_rounds = (uint32_t)tile;
     RedCtl red{};

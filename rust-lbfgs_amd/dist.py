@@ -29,6 +29,49 @@ def shard_range(n, rank, world, align=ALIGN):
     return lo, hi
 
 
+# ---- the rendezvous: torch.distributed by default.  Anything else that can tell a rank its number and gather / broadcast a small
+# Python object works as well -- pass it as `process_group`: an object with `.rank`, `.world`, `.all_gather_object(obj) -> list`
+# and `.broadcast_object(obj, src) -> obj` (tools/eight_ranks_one_gpu.py hosts several ranks per process that way).
+def _custom(pg):
+    return pg is not None and hasattr(pg, "all_gather_object") and hasattr(pg, "world")
+
+
+def _rank(pg):
+    if _custom(pg):
+        return pg.rank
+    import torch.distributed as dist
+
+    return dist.get_rank(pg)
+
+
+def _world(pg):
+    if _custom(pg):
+        return pg.world
+    import torch.distributed as dist
+
+    return dist.get_world_size(pg)
+
+
+def _all_gather(pg, obj):
+    if _custom(pg):
+        return pg.all_gather_object(obj)
+    import torch.distributed as dist
+
+    out = [None] * dist.get_world_size(pg)
+    dist.all_gather_object(out, obj, group=pg)
+    return out
+
+
+def _broadcast(pg, obj, src=0):
+    if _custom(pg):
+        return pg.broadcast_object(obj, src)
+    import torch.distributed as dist
+
+    box = [obj]
+    dist.broadcast_object_list(box, src=src, group=pg)
+    return box[0]
+
+
 class CommSpec:
     """Keeps the ctypes lbfgs_hip_comm and whatever it points at alive."""
 
@@ -45,17 +88,15 @@ class CommSpec:
 
 def rccl_comm(process_group=None):
     """RCCL communicator: rank 0 makes the unique id, torch.distributed broadcasts it."""
-    import torch.distributed as dist  # (torch is imported before librccl is touched: _ffi.torch_before_rccl)
-
+    _ffi.torch_before_rccl()  # (torch is imported before librccl is touched)
     L = _ffi.load()
     buf = (C.c_char * 128)()
-    if dist.get_rank(process_group) == 0:
+    if _rank(process_group) == 0:
         rc = L.lbfgs_hip_rccl_unique_id(buf)
         if rc != 0:
             raise LbfgsError(rc, L.lbfgs_hip_last_error(None).decode())
-    obj = [bytes(buf.raw)]
-    dist.broadcast_object_list(obj, src=0, group=process_group)
-    C.memmove(buf, obj[0], 128)
+    raw = _broadcast(process_group, bytes(buf.raw), 0)
+    C.memmove(buf, raw, 128)
     return CommSpec(_ffi.COMM_RCCL, unique_id=buf)
 
 
@@ -65,15 +106,12 @@ def p2p_comm(device, process_group=None, timeout_s=5.0, exclusive_device=False, 
     only then does it use kernels that fill the whole chip while they wait for their peers.
     placement: MAILBOX_DEVICE (uncached HBM, mapped by the peers through HIP IPC over xGMI), MAILBOX_HOST (a shared-memory
     segment registered with HIP: host-coherent, reached over PCIe) or MAILBOX_AUTO (LBFGS_HIP_P2P_MAILBOX, default device)."""
-    import torch.distributed as dist
-
     L = _ffi.load()
-    world = dist.get_world_size(process_group)
+    world = _world(process_group)
     mbox = C.c_void_p()
     hdl = (C.c_char * 64)()
     rc = L.lbfgs_hip_p2p_mailbox_create2(device, placement, C.byref(mbox), hdl)
-    ok = [None] * world
-    dist.all_gather_object(ok, (rc, bytes(hdl.raw)), group=process_group)
+    ok = _all_gather(process_group, (rc, bytes(hdl.raw)))
     if any(r != 0 for r, _ in ok):
         if rc == 0:
             L.lbfgs_hip_p2p_mailbox_destroy(device, mbox)
@@ -95,16 +133,13 @@ def _p2p_context(n, device, shard, process_group, stream, exclusive_device, plac
     """The P2P context of this rank, created COLLECTIVELY: every rank learns whether every rank succeeded (one rank that
     cannot map a peer's mailbox must not leave the others with a context nobody will answer in).  Returns
     (ctx or None, this rank's error or None)."""
-    import torch.distributed as dist
-
     ctx, err = None, None
     try:
         comm = p2p_comm(device, process_group, exclusive_device=exclusive_device, placement=placement)
         ctx = Context(n, device=device, shard=shard, comm=comm, stream=stream)
     except LbfgsError as e:
         err = e
-    oks = [None] * dist.get_world_size(process_group)
-    dist.all_gather_object(oks, err is None, group=process_group)
+    oks = _all_gather(process_group, err is None)
     if all(oks):
         # every rank has mapped every mailbox: a host-placed segment can lose its name now (nothing outlives the processes)
         placed = C.c_int(-1)
@@ -118,6 +153,21 @@ def _p2p_context(n, device, shard, process_group, stream, exclusive_device, plac
 
 def callback_comm(process_group=None):
     """Host all-reduce through torch.distributed (gloo or nccl group): slow, for tests."""
+    if _custom(process_group):  # (sums in rank order: the same bits on every rank)
+        def allreduce(_user, buf, count):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(count,))
+                parts = process_group.all_gather_object(a.copy())
+                tot = parts[0].copy()
+                for p in parts[1:]:
+                    tot += p
+                a[:] = tot
+                return 0
+            except Exception:
+                return 1
+
+        return CommSpec(_ffi.COMM_CALLBACK, callback=_ffi.ALLREDUCE_CB(allreduce))
+
     import torch
     import torch.distributed as dist
 
@@ -137,9 +187,7 @@ def callback_comm(process_group=None):
 def sharded_context(n, device=0, kind="rccl", process_group=None, stream=None, exclusive_device=False, bounds=None):
     """Context for this rank's shard of a global n-vector (world from torch.distributed).  exclusive_device: see p2p_comm.
     bounds: explicit shard boundaries [0, b_1, ..., b_{world-1}, n] (non-decreasing; default: shard_range's even split)."""
-    import torch.distributed as dist
-
-    rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+    rank, world = _rank(process_group), _world(process_group)
     if bounds is not None:
         if len(bounds) != world + 1 or bounds[0] != 0 or bounds[-1] != n or any(a > b for a, b in zip(bounds, bounds[1:])):
             raise ValueError("bounds must be [0, ..., n], non-decreasing, one entry more than there are ranks")

@@ -53,3 +53,44 @@ def test_c_caller_on_the_gpu(tmp_path):
     assert "c_caller: all checks passed" in r.stdout
     # tests/simple.rs:37-40, :52-54 were asserted by the program; echo its lines into the test log
     print(r.stdout)
+
+
+def test_the_hip_caller_compiles_for_gfx950(tmp_path):
+    """tests/support/device_closure_caller.hip (a caller with kernels of its own, deferred trial points) cross-compiles
+    against the headers: the GPU test below builds and runs it."""
+    obj = str(tmp_path / "device_closure_caller.o")
+    r = subprocess.run([_build.hipcc(), "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-std=c++17", "-Wall", "-I",
+                        os.path.join(ROOT, "include"), "-c", os.path.join(ROOT, "tests", "support", "device_closure_caller.hip"),
+                        "-o", obj], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and os.path.getsize(obj) > 0, r.stderr
+
+
+@pytest.mark.gpu
+def test_a_caller_with_its_own_hip_kernels_and_deferred_trials(tmp_path):
+    """tests/support/device_closure_caller.hip: LBFGS_EVAL_DEVICE with the caller's own kernels as `evaluate`, and the
+    deferred-trial callbacks of ABI version 4 (device_probe / device_accept: line.rs:283-288 reads f and g.d only) --
+    the three runs (full evaluations / probes + accept / probes only) take the same discrete decisions, agree to 1e-10 per
+    iteration and call the closure as often as lbfgs_solver.h says.  Built by hipcc here, on the GPU box."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs the GPU (the program launches kernels)")
+    import json
+
+    exe = str(tmp_path / "device_closure_caller")
+    libdir = os.path.dirname(_build.HIP_LIB)
+    cmd = [_build.hipcc(), "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "support", "device_closure_caller.hip"), "-L", libdir, "-llbfgs_solver", "-llbfgs_hip",
+           "-Wl,-rpath," + libdir, "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "4000000", "40"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "device_closure_caller: all checks passed" in r.stdout
+    j = json.loads(r.stdout.splitlines()[0])
+    print(json.dumps(j))
+    assert j["worst_relative_deviation"] <= 1e-10 and j["iterations"] == 40
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        json.dump(j, open(os.path.join(out, "device_closure_caller.json"), "w"), indent=1)
+    except OSError:
+        pass

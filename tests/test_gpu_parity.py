@@ -760,6 +760,41 @@ def test_device_closure_bridge_with_torch():
         assert abs(a[2] - b[2]) <= 1e-9 * abs(a[2]) and abs(a[3] - b[3]) <= 1e-7 * max(a[3], 1e-9)
     assert np.max(np.abs(xh - xd)) <= 1e-8
 
+    # ---- deferred trial points (lbfgs_evaluator.device_probe / device_accept, ABI version 4): the same closure with a probe
+    # (f and g.d at xp + step*d, nothing of the optimiser written) and an accept (x, g of the accepted step): T probes + one
+    # accept per search instead of T x (line step + evaluate + dot).  Same discrete decisions; values to 1e-9 (torch's sums
+    # of the probe's g.d and the library's OpDot differ in order -- on the CPU test double, where both are the oracle's
+    # sequential sums, the runs are bitwise equal: tests/test_host_logic_cpu.py)
+    calls = dict(evaluate=0, probe=0, accept=0)
+
+    def grad(x):
+        return 2.0 * wt * (x - 1.0) + x ** 3
+
+    def dev_counted(x, g):
+        calls["evaluate"] += 1
+        return dev(x, g)
+
+    def probe(xp, d, step):
+        calls["probe"] += 1
+        x = xp + step * d
+        return torch.sum(wt * (x - 1.0) ** 2) + 0.25 * torch.sum(x ** 4), torch.dot(grad(x), d)
+
+    def accept(xp, d, step, x_out, g_out):
+        calls["accept"] += 1
+        torch.add(xp, d, alpha=step, out=x_out)
+        g_out.copy_(grad(x_out))
+
+    xq, rq = np.zeros(n), []
+    R.lbfgs().with_max_iterations(25).minimize(xq, R.TorchEvaluate(dev_counted, probe=probe, accept=accept),
+                                               lambda p: rq.append((p.niter, p.neval, p.fx, p.gnorm)) and False)
+    assert len(rq) == len(rd)
+    for a, b in zip(rd, rq):
+        assert a[:2] == b[:2]
+        assert abs(a[2] - b[2]) <= 1e-9 * abs(a[2]) and abs(a[3] - b[3]) <= 1e-7 * max(a[3], 1e-9)
+    assert np.max(np.abs(xq - xd)) <= 1e-8
+    neval = rq[-1][1]
+    assert calls == dict(evaluate=1, probe=neval - 1, accept=len(rq) - 1), calls
+
 
 # ---------------------------------------------------------------------------------------------
 # device-resident Lennard-Jones objectives (BASELINE config 5)

@@ -313,6 +313,114 @@ def test_c_minimize_entry_point():
     ctx.close()
 
 
+class _HostSideDeviceClosure:
+    """A `DeviceEvaluate` for the test double, whose "device" pointers are host pointers: Rosenbrock (src/lib.rs:79-94) with
+    the deferred-trial callbacks of lbfgs_solver.h (device_probe / device_accept).  The probe forms f and g.d the way the
+    undeferred sequence does -- take_line_step's two roundings, the closure's f, dg_unchecked's sequential sum -- so the two
+    runs must agree bit for bit."""
+
+    def __init__(self, fail_probe_at=0, fail_accept_at=0):
+        self.calls = dict(evaluate=0, probe=0, accept=0)
+        self.fail_probe_at, self.fail_accept_at = fail_probe_at, fail_accept_at
+
+    @staticmethod
+    def _view(ptr, n):
+        import ctypes as C
+
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(n,))
+
+    def evaluate(self, xptr, gptr, n, stream):
+        self.calls["evaluate"] += 1
+        return R.default_evaluate()(self._view(xptr, n), self._view(gptr, n))
+
+    def probe(self, xpptr, dptr, step, n, stream):
+        self.calls["probe"] += 1
+        if self.calls["probe"] == self.fail_probe_at:
+            raise RuntimeError("probe refused")
+        xp, d = self._view(xpptr, n), self._view(dptr, n)
+        x = xp.copy()
+        O.vecadd(x, d, step)  # x = xp + step*d (core.rs:157-158)
+        g = np.zeros(n)
+        f = R.default_evaluate()(x, g)
+        return f, O.vecdot(g, d)
+
+    def accept(self, xpptr, dptr, step, xptr, gptr, n, stream):
+        self.calls["accept"] += 1
+        if self.calls["accept"] == self.fail_accept_at:
+            raise RuntimeError("accept refused")
+        x, g = self._view(xptr, n), self._view(gptr, n)
+        x[:] = self._view(xpptr, n)
+        O.vecadd(x, self._view(dptr, n), step)
+        R.default_evaluate()(x, g)
+
+
+@pytest.mark.parametrize("configure", [
+    lambda b: b,
+    lambda b: b.with_linesearch_algorithm("BacktrackingStrongWolfe").with_damping(True),
+    lambda b: b.with_linesearch_algorithm("BacktrackingArmijo").with_m(3),
+], ids=["morethuente", "strongwolfe_damped", "armijo_m3"])
+def test_deferred_trials_of_a_device_closure_follow_the_undeferred_run(configure):
+    """lbfgs_evaluator.device_probe / device_accept (ABI 4): T probes + one accept per search instead of T full evaluations,
+    same trajectory bit for bit -- and the same as the oracle's (line.rs:283-288, core.rs:155-164)."""
+    from rust_lbfgs_amd.api import DeviceEvaluate
+
+    fields = ("niter", "neval", "ncall", "fx", "xnorm", "gnorm", "step")
+    runs = {}
+    for mode in ("full", "probe+accept", "probe"):
+        c = _HostSideDeviceClosure()
+        ev = DeviceEvaluate(c.evaluate, probe=c.probe if mode != "full" else None, accept=c.accept if mode == "probe+accept" else None)
+        x, rows = P.rosenbrock_x0(), []
+        rep = configure(R.lbfgs()).with_max_iterations(40).minimize(x, ev, lambda p: rows.append(tuple(getattr(p, f) for f in fields)) and False)
+        runs[mode] = (x, rows, (rep.fx, rep.xnorm, rep.gnorm, rep.neval), c.calls)
+    xo, ro = P.rosenbrock_x0(), []
+    configure(O.lbfgs()).with_max_iterations(40).minimize(xo, O.rosenbrock(), lambda p: ro.append(tuple(p[f] for f in fields)) and False)
+    for mode in runs:
+        assert runs[mode][1] == ro and np.array_equal(runs[mode][0], xo), mode
+        assert runs[mode][2] == runs["full"][2], mode
+    neval, searches = runs["full"][2][3], len(ro) - 1
+    assert runs["full"][3] == dict(evaluate=neval, probe=0, accept=0)
+    # one full evaluate in build (lbfgs.rs:454); every trial of every search is a probe; one accept per search
+    assert runs["probe+accept"][3] == dict(evaluate=1, probe=neval - 1, accept=searches)
+    assert runs["probe"][3] == dict(evaluate=1 + searches, probe=neval - 1, accept=0)
+
+
+def test_deferred_trials_error_paths():
+    """A probe that fails is an evaluate that fails inside the search: swallowed, reverted, `x not changed` on the update
+    (line.rs:213-220, lbfgs.rs:646).  An accept that fails is a hard error and x names the search's start point again."""
+    from rust_lbfgs_amd.api import DeviceEvaluate
+
+    c = _HostSideDeviceClosure(fail_probe_at=3)
+    x = P.rosenbrock_x0()
+    with pytest.raises(R.LbfgsError) as e:
+        R.lbfgs().minimize(x, DeviceEvaluate(c.evaluate, probe=c.probe, accept=c.accept))
+    assert e.value.code == _ffi.ERR_X_NOT_CHANGED
+    # the reference run with an evaluate that fails at the same call ends the same way, at the same point
+    calls = {"n": 0}
+
+    def failing(xx, gx):
+        calls["n"] += 1
+        if calls["n"] == 4:  # build's evaluate + 3 trials
+            raise RuntimeError("refused")
+        return R.default_evaluate()(xx, gx)
+
+    x2 = P.rosenbrock_x0()
+    with pytest.raises(R.LbfgsError) as e2:
+        R.lbfgs().minimize(x2, failing)
+    assert e2.value.code == _ffi.ERR_X_NOT_CHANGED and np.array_equal(x, x2)
+
+    c = _HostSideDeviceClosure(fail_accept_at=2)
+    x = P.rosenbrock_x0()
+    st = R.lbfgs().build(x, DeviceEvaluate(c.evaluate, probe=c.probe, accept=c.accept))
+    st.propagate()
+    st.propagate()
+    x_before, fx_before = st.download("x"), st.report().fx
+    with pytest.raises(R.LbfgsError) as e3:
+        st.propagate()
+    assert e3.value.code == _ffi.ERR_EVALUATE
+    assert np.array_equal(st.download("x"), x_before) and st.report().fx == fx_before
+    st.close()
+
+
 def test_problem_and_linesearch_public_api():
     """src/line.rs:8-32 doctest: Problem::new + evaluate + update_search_direction + LineSearch::default().find,
     and the other public Problem methods (core.rs:59-217), against the oracle's first line search."""
