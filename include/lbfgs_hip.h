@@ -39,7 +39,8 @@
 extern "C" {
 #endif
 
-/* 4: lbfgs_evaluator (lbfgs_solver.h) grew device_probe / device_accept: deferred trial points for device closures (round 5).
+/* 4: lbfgs_evaluator (lbfgs_solver.h) grew device_probe / device_accept: deferred trial points for device closures;
+ *    lbfgs_hip_objective_owlqn_first_trial (round 5).
  * 3: lbfgs_hip_ctx_comm_info / lbfgs_hip_comm_info (round 4); lbfgs_hip_sync, lbfgs_hip_vec_download and
  *    lbfgs_hip_history_scalars_read report device errors (and recover from a timed-out resident two-loop) like
  *    lbfgs_hip_scalars_read.
@@ -380,6 +381,15 @@ int lbfgs_hip_history_update_from_step(lbfgs_hip_history* h, int slot, const lbf
 int lbfgs_hip_objective_owlqn_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
                                         const lbfgs_hip_vec* d, double step, const lbfgs_hip_vec* wp, lbfgs_hip_vec* g,
                                         lbfgs_hip_vec* pg, double c, uint64_t start, uint64_t end, int out_slot);
+
+/* The FIRST trial of an OWL-QN search, with Problem::update_orthant_new_point (line.rs:735, core.rs:167-180) folded in: the
+ * orthant wp_i = xp_i == 0 ? signum(-pg_i) : signum(xp_i) is formed from xp -- which the trial streams anyway -- and the
+ * pseudo-gradient of the point the search starts from (pg on entry), written to wp for the later trials of the search
+ * (lbfgs_hip_objective_owlqn_line_eval), and used at once; pg then receives the trial point's pseudo-gradient, as there.
+ * Same sums, same board layout.  3r 4w, where lbfgs_hip_orthant_select (2r 1w) + the trial (3r 3w) move 5r 4w. */
+int lbfgs_hip_objective_owlqn_first_trial(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
+                                          const lbfgs_hip_vec* d, double step, lbfgs_hip_vec* wp, lbfgs_hip_vec* g,
+                                          lbfgs_hip_vec* pg, double c, uint64_t start, uint64_t end, int out_slot);
 
 /* ------------------------------------------------------------------------- */
 /* measurement                                                                 */

@@ -236,7 +236,15 @@ LH_INTERNAL int two_loop_eager(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbf
                                int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end,
                                bool owl, uint64_t owl_start, uint64_t owl_end);
 // (lj.hip) Lennard-Jones objectives: x holds 3*natoms coordinates of ONE rank; f -> *out
-LH_INTERNAL int lj_eval(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, const lbfgs_hip_vec* x, lbfgs_hip_vec* g, double* out);
+// a line-search trial of LJ_CELLS: x = xp + t*d formed by the list check's pass, g.d summed by the evaluation kernel (lj.hip)
+struct LjTrial {
+    const double* xp;
+    const double* d;
+    double t;
+    double* dg_out;
+};
+LH_INTERNAL int lj_eval(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, const lbfgs_hip_vec* x, lbfgs_hip_vec* g, double* out,
+                        const LjTrial* step = nullptr);
 #if LH_RES_TRACE
 LH_INTERNAL void res_trace_print();  // (lbfgs_hip.hip; traced A/B builds only)
 #endif

@@ -195,6 +195,7 @@ struct lbfgs_state {
     bool defer_trials = false, point_deferred = false;
     double t_eval = 0.0;
     uint64_t trials = 0;  // trial steps evaluated by the running search
+    bool orthant_pending = false;  // OWL-QN: wp of the running search is still to be formed, by its first trial's kernel
     std::string err, ls_err;
 
     bool owlqn() const { return vars.orthantwise != 0; }
@@ -414,10 +415,16 @@ int trial(lbfgs_state* st, double t, bool want_dg, double* dg_out) {
         return LBFGS_OK;
     }
     if (st->eval.kind == LBFGS_EVAL_BUILTIN && st->eval.fuse_line_eval && st->owlqn()) {
-        // OWL-QN trial in one pass: projected line step + evaluate + x1norm + pseudo-gradient (+ g.d)
+        // OWL-QN trial in one pass: projected line step + evaluate + x1norm + pseudo-gradient (+ g.d); the first trial of a
+        // search also forms the orthant of the new point (line.rs:735, core.rs:167-180) -- see search_backtracking
         TRY(owl_range(st));
-        TRYB(st, lbfgs_hip_objective_owlqn_line_eval(&st->eval.builtin, st->x, st->xp, st->d, t, st->wp, st->gx, st->pg,
-                                                     st->vars.owl_c, st->owl_start, st->owl_end, S_F));
+        if (st->orthant_pending) {
+            st->orthant_pending = false;
+            TRYB(st, lbfgs_hip_objective_owlqn_first_trial(&st->eval.builtin, st->x, st->xp, st->d, t, st->wp, st->gx, st->pg,
+                                                           st->vars.owl_c, st->owl_start, st->owl_end, S_F));
+        } else
+            TRYB(st, lbfgs_hip_objective_owlqn_line_eval(&st->eval.builtin, st->x, st->xp, st->d, t, st->wp, st->gx, st->pg,
+                                                         st->vars.owl_c, st->owl_start, st->owl_end, S_F));
         double b[5];
         TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_F, 5, b));
         st->fx = b[S_F];
@@ -577,7 +584,11 @@ int search_backtracking(lbfgs_state* st, double& stp, uint64_t* ncall, const cha
     const double f0 = st->fx;
     const double dgtest = pr.ftol * dg0;
     const bool owl = st->owlqn();
-    if (owl) TRYB(st, lbfgs_hip_orthant_select(st->wp, st->xp, st->pg));  // line.rs:735, core.rs:167-180
+    // line.rs:735, core.rs:167-180: the orthant of the new point.  With a built-in objective and fused trials it is formed BY
+    // the first trial's kernel, which streams xp anyway and reads the pseudo-gradient of the start point before it overwrites
+    // it (lbfgs_hip_objective_owlqn_first_trial); a search that runs no trial (max_linesearch <= 1) never reads wp.
+    st->orthant_pending = owl && st->eval.kind == LBFGS_EVAL_BUILTIN && st->eval.fuse_line_eval;
+    if (owl && !st->orthant_pending) TRYB(st, lbfgs_hip_orthant_select(st->wp, st->xp, st->pg));
 
     const bool armijo_exit = pr.ls_algorithm == LBFGS_LS_BACKTRACKING_ARMIJO || owl;
     const bool want_dg = !armijo_exit || pr.gradient_only;

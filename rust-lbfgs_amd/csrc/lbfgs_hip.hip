@@ -1248,9 +1248,13 @@ int lbfgs_hip_objective_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec*
             op.step = step; op.obj = {obj->seed_a, obj->seed_b};
             return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
         }
+        case LBFGS_HIP_OBJ_LJ_CELLS: {  // the trial point is formed by the list check's pass, g.d summed where g is formed (lj.hip)
+            x->ctx->last_res.valid = false;
+            const LjTrial tr{xp->p, d->p, step, outs[1]};
+            return lj_eval(ctx, obj, x, g, outs[0], &tr);
+        }
         case LBFGS_HIP_OBJ_LJ_ALLPAIRS:
-        case LBFGS_HIP_OBJ_LJ_NEIGHBORS:
-        case LBFGS_HIP_OBJ_LJ_CELLS: {  // gather pattern: line step, evaluate, g.d as three launches
+        case LBFGS_HIP_OBJ_LJ_NEIGHBORS: {  // gather pattern: line step, evaluate, g.d as three launches
             int rc = lbfgs_hip_line_step(x, xp, d, step, nullptr, 0, 0);
             if (rc != LBFGS_HIP_OK) return rc;
             if ((rc = lj_eval(ctx, obj, x, g, outs[0])) != LBFGS_HIP_OK) return rc;
@@ -1342,36 +1346,60 @@ int lbfgs_hip_history_update_from_step(lbfgs_hip_history* h, int slot, const lbf
     return LBFGS_HIP_OK;
 }
 
-int lbfgs_hip_objective_owlqn_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
-                                        const lbfgs_hip_vec* d, double step, const lbfgs_hip_vec* wp, lbfgs_hip_vec* g,
-                                        lbfgs_hip_vec* pg, double c, uint64_t start, uint64_t end, int out_slot) {
+}  // extern "C"  (the template below needs C++ linkage)
+
+namespace {
+// one OWL-QN trial; FIRST: wp is an OUTPUT formed from xp and the previous pg (ops.h OpObjOwlLineEval<Obj, true>)
+template <bool FIRST>
+int owlqn_trial(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp, const lbfgs_hip_vec* d, double step,
+                lbfgs_hip_vec* wp, lbfgs_hip_vec* g, lbfgs_hip_vec* pg, double c, uint64_t start, uint64_t end, int out_slot) {
     if (!obj || !same_ctx(x, xp) || !same_ctx(x, d) || !same_ctx(x, wp) || !same_ctx(x, g) || !same_ctx(x, pg) ||
         !slot_ok(out_slot, 5))
         return LBFGS_HIP_ERR_ARG;
     lbfgs_hip_ctx* ctx = x->ctx;
     double* b = ctx->board + out_slot;
     double* outs[5] = {b, b + 1, b + 2, b + 3, b + 4};
+    auto fill = [&](auto& op) {
+        op.in[0] = xp->p; op.in[1] = d->p; op.in[2] = FIRST ? pg->p : wp->p;
+        op.out[0] = x->p; op.out[1] = g->p; op.out[2] = pg->p;
+        if (FIRST) op.out[3] = wp->p;
+        op.step = step; op.c = c; op.start = start; op.end = end; op.obj = {obj->seed_a, obj->seed_b};
+    };
     switch (obj->kind) {
         case LBFGS_HIP_OBJ_QUADRATIC: {
-            OpObjOwlLineEval<ObjQuadratic> op{};
-            op.in[0] = xp->p; op.in[1] = d->p; op.in[2] = wp->p; op.out[0] = x->p; op.out[1] = g->p; op.out[2] = pg->p;
-            op.step = step; op.c = c; op.start = start; op.end = end; op.obj = {obj->seed_a, obj->seed_b};
+            OpObjOwlLineEval<ObjQuadratic, FIRST> op{};
+            fill(op);
             return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
         }
         case LBFGS_HIP_OBJ_LOGISTIC: {
-            OpObjOwlLineEval<ObjLogistic> op{};
-            op.in[0] = xp->p; op.in[1] = d->p; op.in[2] = wp->p; op.out[0] = x->p; op.out[1] = g->p; op.out[2] = pg->p;
-            op.step = step; op.c = c; op.start = start; op.end = end; op.obj = {obj->seed_a, obj->seed_b};
+            OpObjOwlLineEval<ObjLogistic, FIRST> op{};
+            fill(op);
             return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
         }
-        default: {  // objectives without a fused form: the three separate passes
-            int rc = lbfgs_hip_line_step(x, xp, d, step, wp, start, end);
-            if (rc != LBFGS_HIP_OK) return rc;
+        default: {  // objectives without a fused form: the separate passes
+            int rc = LBFGS_HIP_OK;
+            if (FIRST && (rc = lbfgs_hip_orthant_select(wp, xp, pg)) != LBFGS_HIP_OK) return rc;
+            if ((rc = lbfgs_hip_line_step(x, xp, d, step, wp, start, end)) != LBFGS_HIP_OK) return rc;
             if ((rc = lbfgs_hip_objective_eval(obj, x, g, out_slot)) != LBFGS_HIP_OK) return rc;
             if ((rc = lbfgs_hip_owlqn_post_eval(x, g, pg, c, start, end, out_slot + 2)) != LBFGS_HIP_OK) return rc;
             return lbfgs_hip_vecdot(g, d, out_slot + 1);
         }
     }
+}
+}  // namespace
+
+extern "C" {
+
+int lbfgs_hip_objective_owlqn_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
+                                        const lbfgs_hip_vec* d, double step, const lbfgs_hip_vec* wp, lbfgs_hip_vec* g,
+                                        lbfgs_hip_vec* pg, double c, uint64_t start, uint64_t end, int out_slot) {
+    return owlqn_trial<false>(obj, x, xp, d, step, const_cast<lbfgs_hip_vec*>(wp), g, pg, c, start, end, out_slot);
+}
+
+int lbfgs_hip_objective_owlqn_first_trial(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
+                                          const lbfgs_hip_vec* d, double step, lbfgs_hip_vec* wp, lbfgs_hip_vec* g,
+                                          lbfgs_hip_vec* pg, double c, uint64_t start, uint64_t end, int out_slot) {
+    return owlqn_trial<true>(obj, x, xp, d, step, wp, g, pg, c, start, end, out_slot);
 }
 
 }  // extern "C"

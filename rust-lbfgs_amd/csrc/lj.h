@@ -537,19 +537,39 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_check_kernel(const double* __r
     if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(moved, 1u);
 }
 
+// take_line_step (core.rs:155-158: x = xp + t*d, a multiply then an add) fused with the staleness check above: the check reads
+// every coordinate of x anyway, so a line-search trial of the LJ_CELLS objective forms its point here and saves a launch.
+__global__ __launch_bounds__(BLOCK) void lj_cells_step_check_kernel(const double* __restrict__ xp, const double* __restrict__ d,
+                                                                     const double t, double* __restrict__ x,
+                                                                     const double* __restrict__ xref, const uint32_t natoms,
+                                                                     const double half_skin2, unsigned int* __restrict__ moved) {
+    bool any = false;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < natoms; i += gridDim.x * BLOCK) {
+        const size_t b = 3 * (size_t)i;
+        const double x0 = xp[b] + t * d[b], x1 = xp[b + 1] + t * d[b + 1], x2 = xp[b + 2] + t * d[b + 2];
+        x[b] = x0; x[b + 1] = x1; x[b + 2] = x2;
+        const double ux = x0 - xref[b], uy = x1 - xref[b + 1], uz = x2 - xref[b + 2];
+        any |= !(ux * ux + uy * uy + uz * uz <= half_skin2);
+    }
+    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(moved, 1u);
+}
+
 // The cutoff sum over the Verlet list, and (second total) the number of atoms that have left their skin/2 sphere.
+// DOT: a third total, g.d (dg_unchecked, core.rs:114-116) -- a trial's directional derivative summed where g is formed, so
+// that the search needs no separate pass over g and d.
 // `moved_flag` (lj_cells_check_kernel, same stream, just before): non-zero = the list is stale -- nothing is evaluated,
 // the second total is reported as 1 and the host rebuilds; the reduction still runs (the launch's tags are spoken for).
-template <bool ROWS>
+template <bool ROWS, bool DOT = false>
 __global__ __launch_bounds__(BLOCK) void lj_cells_eval_kernel(const double* __restrict__ x, double* __restrict__ g,
                                                                const int32_t* __restrict__ nbr,
                                                                const int32_t* __restrict__ cnt,
                                                                const double* __restrict__ xref, const uint32_t natoms,
                                                                const uint32_t max_nbr, const double rc2, const double eshift,
                                                                const double half_skin2,
-                                                               const unsigned int* __restrict__ moved_flag, const RedCtl red) {
+                                                               const unsigned int* __restrict__ moved_flag, const RedCtl red,
+                                                               const double* __restrict__ dir = nullptr) {
     const DevCounters c0 = load_counters(red);
-    double e = 0.0, stale = 0.0;
+    double e = 0.0, stale = 0.0, gd = 0.0;
     const bool skip = *moved_flag != 0u;
     if (skip) stale = (blockIdx.x == 0 && threadIdx.x == 0) ? 1.0 : 0.0;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < (skip ? 0u : natoms); i += gridDim.x * BLOCK) {
@@ -606,9 +626,15 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_eval_kernel(const double* __re
             }
         }
         g[3 * (size_t)i] = fx; g[3 * (size_t)i + 1] = fy; g[3 * (size_t)i + 2] = fz;
+        if constexpr (DOT) gd += fx * dir[3 * (size_t)i] + fy * dir[3 * (size_t)i + 1] + fz * dir[3 * (size_t)i + 2];
     }
-    double acc[2] = {0.5 * e, stale};
-    grid_reduce<2>(acc, red, c0);
+    if constexpr (DOT) {
+        double acc[3] = {0.5 * e, stale, gd};
+        grid_reduce<3>(acc, red, c0);
+    } else {
+        double acc[2] = {0.5 * e, stale};
+        grid_reduce<2>(acc, red, c0);
+    }
 }
 
 #pragma clang fp contract(off)

@@ -157,12 +157,24 @@ int lj_cells_rebuild(lbfgs_hip_ctx* ctx, const double* x) {
     return LBFGS_HIP_OK;
 }
 
+// `step` != nullptr: a line-search trial -- x is FORMED here as xp + t*d (step->xp, step->d, step->t) by the kernel that checks
+// the list, and g.d is summed by the evaluation kernel into *step->dg_out (lbfgs_hip_objective_line_eval)
 int lj_cells_eval(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, const lbfgs_hip_vec* x, lbfgs_hip_vec* g, double* out,
-                  uint32_t natoms) {
+                  uint32_t natoms, const LjTrial* step = nullptr) {
     int rc = lj_cells_prepare(ctx, obj, natoms);
     if (rc != LBFGS_HIP_OK) return rc;
     LjCells* lc = ctx->lj_cells;
-    if (!lc->built && (rc = lj_cells_rebuild(ctx, x->p)) != LBFGS_HIP_OK) return rc;
+    const double half_skin2_early = 0.25 * obj->skin * obj->skin;
+    bool formed = false;  // a trial's x = xp + t*d has been written
+    if (!lc->built) {
+        if (step) {  // (a trial before any evaluation -- a stand-alone Problem: the list is built AT the trial point, so form it first)
+            const uint32_t g0 = std::max(1u, std::min((natoms + BLOCK - 1) / BLOCK, 1024u));
+            hipLaunchKernelGGL(lj_cells_step_check_kernel, dim3(g0), dim3(BLOCK), 0, ctx->stream, step->xp, step->d, step->t, x->p,
+                               step->xp, natoms, half_skin2_early, lc->overflow + 1);
+            formed = true;
+        }
+        if ((rc = lj_cells_rebuild(ctx, x->p)) != LBFGS_HIP_OK) return rc;
+    }
     const double rc2 = obj->cutoff * obj->cutoff;
     const double i6 = 1.0 / (rc2 * rc2 * rc2);
     const double eshift = 4.0 * (i6 * i6 - i6);
@@ -171,24 +183,36 @@ int lj_cells_eval(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, const lbfg
     const uint32_t grid = std::max(1u, std::min(want, (uint32_t)MAX_GRID));
     for (int attempt = 0;; ++attempt) {
         RedCtl red{};
-        if ((rc = fill_handoff(ctx, red, 2)) != LBFGS_HIP_OK) return rc;
+        if ((rc = fill_handoff(ctx, red, step ? 3 : 2)) != LBFGS_HIP_OK) return rc;
         red.out[0] = out;
         red.out[1] = lc->host_dev;  // the "moved too far" count goes straight to host-mapped memory
+        if (step) red.out[2] = step->dg_out;
         // a cheap look first: has the list gone stale?  (then the evaluation kernel returns at once and the list is rebuilt)
         unsigned int* moved_flag = lc->overflow + 1;  // (a word of the 64-byte scratch next to the overflow counter)
         HIP_TRY(ctx, hipMemsetAsync(moved_flag, 0, sizeof(unsigned int), ctx->stream));
-        hipLaunchKernelGGL(lj_cells_check_kernel, dim3(std::min(grid, 1024u)), dim3(BLOCK), 0, ctx->stream, x->p, lc->xref, natoms,
-                           half_skin2, moved_flag);
+        if (step && attempt == 0 && !formed)  // (the trial point is formed by the same pass; after a rebuild x exists already)
+            hipLaunchKernelGGL(lj_cells_step_check_kernel, dim3(std::min(grid, 1024u)), dim3(BLOCK), 0, ctx->stream, step->xp,
+                               step->d, step->t, x->p, lc->xref, natoms, half_skin2, moved_flag);
+        else
+            hipLaunchKernelGGL(lj_cells_check_kernel, dim3(std::min(grid, 1024u)), dim3(BLOCK), 0, ctx->stream, x->p, lc->xref, natoms,
+                               half_skin2, moved_flag);
         // Which table?  The list kernel writes it row-major; turning it costs 0.17 ms at 1e6 atoms and makes every evaluation
         // 0.05 ms cheaper.  A list that is rebuilt after two or three evaluations (a system that relaxes fast) is read as
         // written; one that has served LJ_TRANSPOSE_AFTER evaluations -- or whose predecessor did -- is turned.
         if (!lc->transposed && lc->evals_this_list >= LJ_TRANSPOSE_AFTER) lj_cells_transpose(ctx, lc);
-        if (lc->transposed)
-            hipLaunchKernelGGL(lj_cells_eval_kernel<false>, dim3(grid), dim3(BLOCK), 0, ctx->stream, x->p, g->p, lc->nbr, lc->cnt,
-                               lc->xref, natoms, lc->max_nbr, rc2, eshift, half_skin2, moved_flag, red);
+        const double* dir = step ? step->d : nullptr;
+        if (lc->transposed && step)
+            hipLaunchKernelGGL((lj_cells_eval_kernel<false, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream, x->p, g->p, lc->nbr, lc->cnt,
+                               lc->xref, natoms, lc->max_nbr, rc2, eshift, half_skin2, moved_flag, red, dir);
+        else if (lc->transposed)
+            hipLaunchKernelGGL((lj_cells_eval_kernel<false, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, x->p, g->p, lc->nbr, lc->cnt,
+                               lc->xref, natoms, lc->max_nbr, rc2, eshift, half_skin2, moved_flag, red, dir);
+        else if (step)
+            hipLaunchKernelGGL((lj_cells_eval_kernel<true, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream, x->p, g->p, lc->nbr_rows,
+                               lc->cnt, lc->xref, natoms, lc->max_nbr, rc2, eshift, half_skin2, moved_flag, red, dir);
         else
-            hipLaunchKernelGGL(lj_cells_eval_kernel<true>, dim3(grid), dim3(BLOCK), 0, ctx->stream, x->p, g->p, lc->nbr_rows, lc->cnt,
-                               lc->xref, natoms, lc->max_nbr, rc2, eshift, half_skin2, moved_flag, red);
+            hipLaunchKernelGGL((lj_cells_eval_kernel<true, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, x->p, g->p, lc->nbr_rows,
+                               lc->cnt, lc->xref, natoms, lc->max_nbr, rc2, eshift, half_skin2, moved_flag, red, dir);
         HIP_TRY(ctx, hipGetLastError());
         lc->evals += 1;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -206,17 +230,21 @@ int lj_cells_eval(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, const lbfg
 }  // namespace
 
 // Lennard-Jones objectives (lj.h): x holds 3*natoms coordinates of ONE rank
-int lj_eval(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, const lbfgs_hip_vec* x, lbfgs_hip_vec* g, double* out) {
+int lj_eval(lbfgs_hip_ctx* ctx, const lbfgs_hip_objective* obj, const lbfgs_hip_vec* x, lbfgs_hip_vec* g, double* out,
+            const LjTrial* step) {
     if (ctx->shard.world != 1) return fail(ctx, LBFGS_HIP_ERR_ARG, "the LJ objectives need all atoms on one rank");
     const uint64_t n = ctx->shard.n_local;
     if (n % 3 != 0 || n / 3 > 0x7fffffffULL) return fail(ctx, LBFGS_HIP_ERR_ARG, "LJ needs n = 3*natoms");
     const uint32_t natoms = (uint32_t)(n / 3);
-    const long idx = out - ctx->board;
-    if (idx >= 0 && idx < LBFGS_HIP_BOARD_SLOTS + 2) ctx->mirror_valid[idx] = false;
+    for (const double* o : {(const double*)out, step ? (const double*)step->dg_out : (const double*)nullptr}) {
+        const long idx = o ? o - ctx->board : -1;
+        if (idx >= 0 && idx < LBFGS_HIP_BOARD_SLOTS + 2) ctx->mirror_valid[idx] = false;
+    }
     if (obj->kind == LBFGS_HIP_OBJ_LJ_CELLS) {
         ProfScope ps(ctx, LBFGS_HIP_K_EVAL);
-        return lj_cells_eval(ctx, obj, x, g, out, natoms);
+        return lj_cells_eval(ctx, obj, x, g, out, natoms, step);
     }
+    if (step) return fail(ctx, LBFGS_HIP_ERR_ARG, "only LJ_CELLS has a fused trial");
     RedCtl red{};
     {
         const int rc_h = fill_handoff(ctx, red, 1);

@@ -470,11 +470,15 @@ struct OpHistUpdateFromStep {
 // OWL-QN trial in ONE pass (line.rs:740-743 with core.rs:155-164, :119-126, :114-116):
 //   x = project(xp + step*d ; wp) ; g = grad f(x) ; pg = pseudo-gradient(x, g)
 //   sums: f, g.d, c*sum|x|, ||pg||^2, ||x||^2                                  3r 3w (separately: 6r 3w)
-template <class Obj>
+// FIRST = true: the FIRST trial of a search also does Problem::update_orthant_new_point (line.rs:735, core.rs:167-180): the
+//   orthant wp_i = xp_i == 0 ? signum(-pg_i) : signum(xp_i) is formed on the fly from xp (streamed anyway) and the PREVIOUS
+//   pseudo-gradient -- in[2] is pg, read before this element's new pg is written over it -- and stored for the later trials.
+//   3r 4w, where orthant_select (2r 1w) + the trial (3r 3w) move 5r 4w.
+template <class Obj, bool FIRST = false>
 struct OpObjOwlLineEval {
-    static constexpr int NIN = 3, NOUT = 3, NRED = 5;
-    const double* in[3];  // xp, d, wp
-    double* out[3];       // x, g, pg
+    static constexpr int NIN = 3, NOUT = FIRST ? 4 : 3, NRED = 5;
+    const double* in[3];  // xp, d, wp (FIRST: the previous pg)
+    double* out[4];       // x, g, pg (FIRST: + wp)
     double step, c;
     uint64_t start, end;
     Obj obj;
@@ -483,7 +487,12 @@ struct OpObjOwlLineEval {
     __device__ void elem(const Coef&, const double* v, double* w, double* acc, uint64_t gi) const {
         double x = v[0] + step * v[1];
         const bool reg = gi >= start && gi < end;
-        if (reg && signum0(x) != signum0(v[2])) x = 0.0;       // orthantwise.rs:165-171
+        double orthant = v[2];
+        if constexpr (FIRST) {
+            orthant = (v[0] == 0.0) ? signum0(-v[2]) : signum0(v[0]);  // core.rs:171-178, over ALL i
+            w[3] = orthant;
+        }
+        if (reg && signum0(x) != signum0(orthant)) x = 0.0;       // orthantwise.rs:165-171
         double f, g;
         obj.eval(x, gi, f, g);
         double pg = g;

@@ -150,3 +150,11 @@ def objective_owlqn_line_eval(obj: BuiltinObjective, x, xp, d, step, wp, g, pg, 
     o = obj.c_struct(x.ctx)
     x.ctx.check(x._L.lbfgs_hip_objective_owlqn_line_eval(C.byref(o), x._h, xp._h, d._h, float(step), wp._h, g._h, pg._h,
                                                          float(c), start, end, out_slot))
+
+
+def objective_owlqn_first_trial(obj: BuiltinObjective, x, xp, d, step, wp, g, pg, c, start, end, out_slot=0):
+    """The first trial of an OWL-QN search with update_orthant_new_point (core.rs:167-180) folded in: wp is an OUTPUT, formed
+    from xp and the pseudo-gradient pg holds on entry; pg then receives the trial point's.  3r 4w."""
+    o = obj.c_struct(x.ctx)
+    x.ctx.check(x._L.lbfgs_hip_objective_owlqn_first_trial(C.byref(o), x._h, xp._h, d._h, float(step), wp._h, g._h, pg._h,
+                                                           float(c), start, end, out_slot))

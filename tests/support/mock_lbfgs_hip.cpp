@@ -463,6 +463,14 @@ int lbfgs_hip_objective_owlqn_line_eval(const lbfgs_hip_objective* obj, lbfgs_hi
     return lbfgs_hip_vecdot(g, d, o + 1);
 }
 
+int lbfgs_hip_objective_owlqn_first_trial(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
+                                          const lbfgs_hip_vec* d, double step, lbfgs_hip_vec* wp, lbfgs_hip_vec* g,
+                                          lbfgs_hip_vec* pg, double c, uint64_t start, uint64_t end, int o) {
+    int rc = lbfgs_hip_orthant_select(wp, xp, pg);  // core.rs:167-180, then the trial (line.rs:735, :740-743)
+    if (rc) return rc;
+    return lbfgs_hip_objective_owlqn_line_eval(obj, x, xp, d, step, wp, g, pg, c, start, end, o);
+}
+
 int lbfgs_hip_prof_enable(lbfgs_hip_ctx*, int) { return LBFGS_HIP_OK; }
 int lbfgs_hip_prof_reset(lbfgs_hip_ctx*) { return LBFGS_HIP_OK; }
 int lbfgs_hip_prof_read(lbfgs_hip_ctx* c, int k, uint64_t* launches, double* ms) {

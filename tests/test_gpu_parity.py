@@ -933,6 +933,28 @@ def test_fused_owlqn_kernels_equal_their_unfused_sequences(n):
             assert np.array_equal(pg.to_numpy(), pg2.to_numpy())
             for a, b in zip(fused, ref):
                 assert abs(a - b) <= 1e-12 * max(abs(b), 1e-300), (fused, ref)
+            # the FIRST trial of a search with update_orthant_new_point folded in (core.rs:167-180 + line.rs:735): wp is an
+            # output formed from xp and the start point's pseudo-gradient, which the same kernel then overwrites in place
+            pg_prev = rnd(n, 44)
+            pg_prev[r.random(n) < 0.25] = 0.0
+            pg_prev[::7] = -0.0
+            if n > 20:
+                pg_prev[3], pg_prev[11] = np.nan, np.inf
+            x3, g3, pg3, wp3, wp_ref, pgp = (DeviceVec(ctx) for _ in range(6))
+            pgp.upload(pg_prev); pg3.upload(pg_prev)
+            H.objective_owlqn_first_trial(obj, x3, xp, d, 0.37, wp3, g3, pg3, c, start, end, 60)
+            first = ctx.scalars(60, 5)
+            H.orthant_select(wp_ref, xp, pgp)
+            H.objective_owlqn_line_eval(obj, x2, xp, d, 0.37, wp_ref, g2, pg2, c, start, end, 70)
+            ref = ctx.scalars(70, 5)
+            assert np.array_equal(wp3.to_numpy(), wp_ref.to_numpy())
+            assert np.array_equal(wp3.to_numpy(), np.where(xp_h == 0.0, np.nan_to_num(np.sign(-pg_prev), nan=0.0), np.sign(xp_h)))
+            for got, want in ((x3, x2), (g3, g2), (pg3, pg2)):
+                assert np.array_equal(got.to_numpy(), want.to_numpy(), equal_nan=True)
+            for a, b in zip(first, ref):
+                assert abs(a - b) <= 1e-12 * max(abs(b), 1e-300), (first, ref)
+            for v in (x3, g3, pg3, wp3, wp_ref, pgp):
+                v.free()
         # two-loop with the projection folded in
         m = 5
         S, Y, ys = _random_history(n, m, 7 + n)
