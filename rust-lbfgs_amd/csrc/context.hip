@@ -598,6 +598,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_FAULT")) ctx->resident_fault = atoi(e);
     if (const char* e = getenv("LBFGS_HIP_GRAM_COMBINE_RESIDENT")) ctx->gram_combine_resident = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_LJ_BUILD_FP32")) ctx->lj_build_fp32 = atoi(e) != 0;
+    if (const char* e = getenv("LBFGS_HIP_LJ_FUSED_TRIAL")) ctx->lj_fused_trial = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_HANDOFF_TIMEOUT_MS")) ctx->handoff_timeout_ticks = (unsigned long long)std::max(1, atoi(e)) * 100000ULL;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_FIRST_TIMEOUT_MS")) ctx->first_timeout_ticks = (unsigned long long)std::max(1, atoi(e)) * 100000ULL;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_NT_MB")) ctx->resident_nt_bytes = (size_t)std::max(0, atoi(e)) << 20;

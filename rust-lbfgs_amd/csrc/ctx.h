@@ -112,6 +112,8 @@ struct lbfgs_hip_ctx {
     unsigned long long resident_attr_mask = 0;  // which resident kernels have had their dynamic-LDS limit raised on this device
     int gram_combine_resident = 1;        // LBFGS_HIP_GRAM_COMBINE_RESIDENT=0: the vector-free combine as one streaming pass over all columns
     int lj_build_fp32 = 1;                // LBFGS_HIP_LJ_BUILD_FP32=0: the LJ_CELLS list from double-precision candidate tests
+    int lj_fused_trial = 1;               // LBFGS_HIP_LJ_FUSED_TRIAL=0: an LJ_CELLS trial as line step, evaluate, g.d in three launches
+                                          // (the form the other Lennard-Jones evaluators take)
     size_t resident_nt_bytes = (size_t)16 << 20;  // LBFGS_HIP_RESIDENT_NT_MB
     size_t resident_plain_bytes = (size_t)256 << 20;  // LBFGS_HIP_RESIDENT_PLAIN_MB: hybrid: so much of the HBM part of q keeps the default
                                           // cache policy and stays in the 256 MiB Infinity Cache between steps (resident.h res_hbm_rounds)

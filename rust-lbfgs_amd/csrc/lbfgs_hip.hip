@@ -1248,11 +1248,13 @@ int lbfgs_hip_objective_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec*
             op.step = step; op.obj = {obj->seed_a, obj->seed_b};
             return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
         }
-        case LBFGS_HIP_OBJ_LJ_CELLS: {  // the trial point is formed by the list check's pass, g.d summed where g is formed (lj.hip)
-            x->ctx->last_res.valid = false;
-            const LjTrial tr{xp->p, d->p, step, outs[1]};
-            return lj_eval(ctx, obj, x, g, outs[0], &tr);
-        }
+        case LBFGS_HIP_OBJ_LJ_CELLS:
+            if (ctx->lj_fused_trial) {  // the trial point is formed by the list check's pass, g.d summed where g is formed (lj.hip)
+                ctx->last_res.valid = false;
+                const LjTrial tr{xp->p, d->p, step, outs[1]};
+                return lj_eval(ctx, obj, x, g, outs[0], &tr);
+            }
+            [[fallthrough]];
         case LBFGS_HIP_OBJ_LJ_ALLPAIRS:
         case LBFGS_HIP_OBJ_LJ_NEIGHBORS: {  // gather pattern: line step, evaluate, g.d as three launches
             int rc = lbfgs_hip_line_step(x, xp, d, step, nullptr, 0, 0);

@@ -214,3 +214,43 @@ def test_lj_cells_single_precision_list_gives_the_same_bits(monkeypatch):
         assert res["1"][-1][2] >= res["0"][-1][2]                    # the single-precision list is a superset
         fo, go = O.eval_builtin(O.lj_cells(rc), np.ascontiguousarray(pts[2]))
         assert abs(res["1"][2][0] - fo) <= RTOL * abs(fo) and rel(res["1"][2][1], go) <= RTOL
+
+
+def test_lj_cells_trial_forms_its_point_and_sums_gd_in_the_evaluation(monkeypatch):
+    """A line-search trial of LJ_CELLS (lbfgs_hip_objective_line_eval: take_line_step + evaluate + dg_unchecked,
+    core.rs:155-158,119-121,114-116): the trial point is formed by the pass that checks the neighbour list and g.d is summed
+    by the kernel that forms g -- against the three-launch sequence the other Lennard-Jones evaluators take
+    (LBFGS_HIP_LJ_FUSED_TRIAL=0): x, g and f bit for bit, g.d to rounding; for a step that keeps the list, a step that makes
+    it stale (rebuild in the middle of the trial) and a trial before anything was evaluated (the list is built at the trial
+    point)."""
+    if ON_MOCK:
+        pytest.skip("a property of the HIP kernels")
+    rc, skin = 2.5, 0.3
+    obj = objectives.LennardJonesCells(rc, skin)
+    xp_h = _jittered_lattice(9, 1.15, 0.08, 31)
+    n = len(xp_h)
+    d_h = np.random.default_rng(5).standard_normal(n)
+    d_h *= 1.0 / np.max(np.abs(d_h))
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LBFGS_HIP_LJ_FUSED_TRIAL", mode)
+        out = []
+        with R.Context(n) as ctx:
+            x, xp, d, g = DeviceVec(ctx), DeviceVec(ctx, xp_h), DeviceVec(ctx, d_h), DeviceVec(ctx)
+            for t in (0.31 * skin, 0.02 * skin, 1.7 * skin, 0.4 * skin):   # no list yet; list kept; stale; rebuilt list kept
+                H.objective_line_eval(obj, x, xp, d, t, g, 20)
+                f, gd = ctx.scalars(20, 2)
+                out.append((t, f, gd, x.to_numpy(), g.to_numpy()))
+            out.append(ctx.lj_cells_stats())
+            for v in (x, xp, d, g):
+                v.free()
+        res[mode] = out
+    assert res["1"][-1][:2] == res["0"][-1][:2] and res["1"][-1][0] == 2    # the same builds: the first trial + the stale one
+    for a, b in zip(res["1"][:-1], res["0"][:-1]):
+        t = a[0]
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[3], xp_h + t * d_h)   # x = xp + t*d, two roundings
+        assert a[1] == b[1] and np.array_equal(a[4], b[4])
+        assert abs(a[2] - b[2]) <= 1e-12 * abs(b[2])
+        fo, go = O.eval_builtin(O.lj_cells(rc), np.ascontiguousarray(a[3]))
+        assert abs(a[1] - fo) <= RTOL * abs(fo) and rel(a[4], go) <= RTOL
+        assert abs(a[2] - O.vecdot(go, d_h)) <= RTOL * abs(O.vecdot(go, d_h))

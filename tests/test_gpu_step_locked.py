@@ -66,11 +66,17 @@ GRAM_MUST_BE_TRUSTED = ("config2_quadratic_n1e7_m7", "config3_owlqn_logistic_n1e
 VF_PRED_RTOL, VF_MAX_CANCELLATION = 1e-8, 1e4   # the solver's acceptance test (solver.cpp, lbfgs_propagate)
 
 
-def vector_free_row(ctx, hist, dv, src, st, end_before, m, slot=24):
+def vector_free_row(ctx, hist, dv, src, st, end_before, m, snorm, gnorm, slot=24):
     """EXTENSION in front of the oracle: lbfgs_hip_two_loop_gram on the history the caller has just made
     identical to the oracle's (the Gram matrix is incremental: one call per history update).  -> the guard's figures, the
     alphas it left, and whether the solver would have kept this direction (solver.cpp: prediction within 1e-8, cancellation
-    <= 1e4).  The direction is left in dv for the caller to compare."""
+    <= 1e4).  The direction is left in dv for the caller to compare.
+
+    The alphas (lbfgs.rs:587: alpha_j = s_j.q / ys_j) are held to their natural scale: a line search makes the newest s nearly
+    orthogonal to the new gradient -- exactly so on a quadratic, where iteration 2's alpha is -2e-15 against
+    ||s|| ||g|| / ys = 0.9 -- so the quotient's rounding error is eps * ||s_j|| ||q|| / |ys_j| in ANY summation order (the
+    exact device recursion shows the same: tools/vf_alpha_diag.py), and that, not the possibly tiny alpha itself, is what the
+    deviation is divided by.  `snorm`: ||s_j|| per slot (kept by the caller), `gnorm`: ||g|| (||pg|| under OWL-QN)."""
     hist.set_scalars(alpha=np.zeros(m))
     assert hist.two_loop_gram(dv, src, st.k - 1, end_before, 7, 8, slot) == st.end
     dn2, gd, pred, cancel = ctx.scalars(slot, 4)
@@ -80,8 +86,9 @@ def vector_free_row(ctx, hist, dv, src, st, end_before, m, slot=24):
     slots = [(st.end - 1 - i) % m for i in range(bound)]
     a_dev = hist.scalars()[1]
     a_ref = np.array([st.alpha(j) for j in range(m)])
+    scale = max(float(np.max(np.abs(a_ref[slots]))), max(snorm[j] * gnorm / abs(st.ys(j)) for j in slots))
     return dict(dn2=dn2, gd=gd, prediction_error=perr, cancellation=float(cancel), trusted=trusted,
-                alpha=rel(a_dev[slots], a_ref[slots]))
+                alpha=float(np.max(np.abs(a_dev[slots] - a_ref[slots])) / scale))
 
 
 def damp_like_the_host(ctx, hist, slot, gpv, step, out_slot):
@@ -108,6 +115,7 @@ def test_step_locked(case):
         worst = dict(f=0.0, g=0.0, d=0.0, s=0.0, y=0.0, ys=0.0, ls_step=0.0, ls_f=0.0, ls_x=0.0, d_fused=0.0, fused_sums=0.0,
                      d_vector_free=0.0, vector_free_sums=0.0, vector_free_alpha=0.0)
         vf = dict(kept=0, rejected=0, cancellation_max=0.0, prediction_error_max=0.0)
+        snorm = np.zeros(m)   # ||s_j|| of the oracle's history, slot by slot (the scale of alpha_j: vector_free_row)
         fused_paths = set()
         done = fired = 0
         damping = bool(b.param.damping)
@@ -198,8 +206,9 @@ def test_step_locked(case):
             worst["d"] = max(worst["d"], rel(dv.to_numpy(), st.vec("d")))
             # (3a) EXTENSION: the vector-free (Gram) recursion on the same history, held to the same bar whenever its own
             #      run-time check accepts the direction (a rejected one is redone exactly by the solver: that is (3))
+            snorm[end_before] = O.vec2norm(st.hist(end_before, "s"))
             if m <= 10:
-                row = vector_free_row(ctx, hist, dv, src, st, end_before, m)
+                row = vector_free_row(ctx, hist, dv, src, st, end_before, m, snorm, p["gnorm"])
                 if row["trusted"]:
                     vf["kept"] += 1
                     vf["cancellation_max"] = max(vf["cancellation_max"], row["cancellation"])
@@ -293,6 +302,7 @@ def _metric_size_case(n, m):
     st = O.lbfgs().with_m(m).with_epsilon(0.0).build(x, O.quadratic())
     rd = lambda a, b: abs(a - b) / abs(b)
     vf_rows = []
+    snorm = np.zeros(m)
     try:
         with R.Context(n) as ctx:
             hist = H.History(ctx, m)
@@ -311,7 +321,8 @@ def _metric_size_case(n, m):
                 hist.set_scalars(ys=np.array([st.ys(j) for j in range(m)]))
                 ctx.set_scalars(7, [st.gamma, 1.0])
                 gv.upload(st.vec("gx"))
-                row = vector_free_row(ctx, hist, dv, gv, st, end_before, m)
+                snorm[end_before] = O.vec2norm(st.hist(end_before, "s"))
+                row = vector_free_row(ctx, hist, dv, gv, st, end_before, m, snorm, p["gnorm"])
                 d_ref, g_ref = st.vec("d"), st.vec("gx")
                 want_dn2, want_gd = O.vecdot(d_ref, d_ref), O.vecdot(g_ref, d_ref)
                 row.update(iteration=int(p["niter"]), bound=int(min(m, st.k - 1)), d=rel(dv.to_numpy(), d_ref),
@@ -341,12 +352,14 @@ def _metric_size_case(n, m):
                 L.oracle_set_dot_mode(0)
             d_self = rel(d_pair, d_seq)
             alpha_seq = np.array([st.alpha(j) for j in range(m)])
-            alpha_self = rel(alpha_pair, alpha_seq)
+            alpha_scale = max(float(np.max(np.abs(alpha_seq))), max(snorm[j] * p["gnorm"] / abs(ys_all[j]) for j in range(m)))
+            arel = lambda a, b: float(np.max(np.abs(a - b)) / alpha_scale)  # noqa: E731  (see vector_free_row)
+            alpha_self = arel(alpha_pair, alpha_seq)
             # ---- the vector-free direction of the LAST iteration is still in dv (the loop's last call)
             d_vf = dv.to_numpy()
             vf_last = dict(vf_rows[-1])
             vf_last.update(d_vs_pair=rel(d_vf, d_pair), dn2_vs_pair=rd(ctx.scalars(24)[0], pair["dn2"]),
-                           gd_vs_pair=rd(ctx.scalars(25)[0], pair["gd"]), alpha_vs_pair=rel(hist.scalars()[1], alpha_pair))
+                           gd_vs_pair=rd(ctx.scalars(25)[0], pair["gd"]), alpha_vs_pair=arel(hist.scalars()[1], alpha_pair))
             del d_vf
             # ---- device, exact path
             xv.upload(x_h)
@@ -387,7 +400,7 @@ def _metric_size_case(n, m):
                      "oracle_self_distance": rd(pair[k], seq[k])}
     report["d"] = {"device_vs_sequential_oracle": d_vs_seq, "device_vs_pairwise_oracle": d_vs_pair,
                    "oracle_self_distance": d_self}
-    report["alpha"] = {"device_vs_sequential_oracle": rel(alpha_dev, alpha_seq), "device_vs_pairwise_oracle": rel(alpha_dev, alpha_pair),
+    report["alpha"] = {"device_vs_sequential_oracle": arel(alpha_dev, alpha_seq), "device_vs_pairwise_oracle": arel(alpha_dev, alpha_pair),
                        "oracle_self_distance": alpha_self}
     # the vector-free extension: every iteration of the oracle's run against the sequential oracle, the last one also
     # against the pairwise oracle; with the guard's own figures beside the deviations

@@ -19,5 +19,15 @@ c)
     step 200 config3.jsonl python tools/run_configs.py --only config3
     step 300 config5.jsonl python tools/run_configs.py --only config5
     ;;
+d)
+    step 300 steplock_m7.log python -m pytest tests/test_gpu_step_locked.py -m gpu -q -k "quadratic_m7 or rosenbrock"
+    step 300 lj_tests.log python -m pytest tests/test_gpu_lj.py -m gpu -x -q
+    for rep in 1 2; do
+        for fused in 1 0; do
+            LBFGS_HIP_LJ_FUSED_TRIAL=$fused step 300 config5_fused${fused}_$rep.jsonl python tools/run_configs.py --only config5
+        done
+    done
+    step 300 small_vector_ab.log python tools/small_vector_ab.py
+    ;;
 *) echo "unknown batch"; exit 2;;
 esac
