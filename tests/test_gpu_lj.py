@@ -237,7 +237,7 @@ def test_lj_cells_trial_forms_its_point_and_sums_gd_in_the_evaluation(monkeypatc
         out = []
         with R.Context(n) as ctx:
             x, xp, d, g = DeviceVec(ctx), DeviceVec(ctx, xp_h), DeviceVec(ctx, d_h), DeviceVec(ctx)
-            for t in (0.31 * skin, 0.02 * skin, 1.7 * skin, 0.4 * skin):   # no list yet; list kept; stale; rebuilt list kept
+            for t in (0.31 * skin, 0.02 * skin, 1.7 * skin, 1.6 * skin, 0.4 * skin):   # no list yet; kept; stale; kept; stale again
                 H.objective_line_eval(obj, x, xp, d, t, g, 20)
                 f, gd = ctx.scalars(20, 2)
                 out.append((t, f, gd, x.to_numpy(), g.to_numpy()))
@@ -245,7 +245,8 @@ def test_lj_cells_trial_forms_its_point_and_sums_gd_in_the_evaluation(monkeypatc
             for v in (x, xp, d, g):
                 v.free()
         res[mode] = out
-    assert res["1"][-1][:2] == res["0"][-1][:2] and res["1"][-1][0] == 2    # the same builds: the first trial + the stale one
+    # the same builds either way: the first trial's, the stale one's, and the last trial's (1.3 skin back from where the list was built)
+    assert res["1"][-1][:2] == res["0"][-1][:2] and res["1"][-1][0] == 3
     for a, b in zip(res["1"][:-1], res["0"][:-1]):
         t = a[0]
         assert np.array_equal(a[3], b[3]) and np.array_equal(a[3], xp_h + t * d_h)   # x = xp + t*d, two roundings

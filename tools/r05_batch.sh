@@ -5,7 +5,11 @@ mkdir -p gpurun_out
 step() {  # step <seconds> <log> <command...>
     local t=$1 log=$2; shift 2
     echo "== $* (limit ${t}s)" | tee -a gpurun_out/batch.log
-    timeout -k 10 "$t" "$@" > "gpurun_out/$log" 2>&1
+    mkdir -p "$(dirname "gpurun_out/$log")"
+    case "$log" in
+        *.json|*.jsonl) timeout -k 10 "$t" "$@" > "gpurun_out/$log" 2> "gpurun_out/$log.err";;  # (stdout is the record itself)
+        *) timeout -k 10 "$t" "$@" > "gpurun_out/$log" 2>&1;;
+    esac
     local rc=$?
     echo "   rc=$rc" | tee -a gpurun_out/batch.log
     tail -n 4 "gpurun_out/$log" | cut -c1-400
@@ -28,6 +32,28 @@ d)
         done
     done
     step 300 small_vector_ab.log python tools/small_vector_ab.py
+    ;;
+e1)  # final build: the whole GPU suite, then the judged profile of `python bench.py` and of the 8-GPU shard
+    step 900 r05_gpu_suite.log python -m pytest tests -m gpu -q
+    step 420 profile_r05.log bash tools/profile_round.sh r05
+    DIM=12500224 step 300 profile_r05_P8.log bash tools/profile_round.sh r05_shard_P8
+    ;;
+e2)
+    DIM=25000192 step 300 profile_r05_P4.log bash tools/profile_round.sh r05_shard_P4
+    DIM=50000128 step 300 profile_r05_P2.log bash tools/profile_round.sh r05_shard_P2
+    step 600 profile_r05_configs.log bash tools/profile_configs.sh r05 "2 3 5"
+    step 300 vf_profile.out bash tools/vector_free_profile.sh
+    step 400 eight_ranks.err python tools/eight_ranks_one_gpu.py
+    ;;
+e3)  # after the counter passes of THIS build are in profiles/: the un-profiled lines (roofline.traffic_is_current = true)
+    mkdir -p gpurun_out/final
+    step 300 final/bench_n1e8_m10.json python bench.py
+    for p in 8 4 2; do
+        case $p in 8) dim=12500224;; 4) dim=25000192;; 2) dim=50000128;; esac
+        step 200 final/shard_P${p}_bench.json python bench.py --dim $dim --no-cpu-baseline
+    done
+    step 200 final/bench_3e6.json python bench.py --dim 3000000 --hist 6 --no-cpu-baseline
+    step 200 config2.jsonl python tools/run_configs.py --only config2
     ;;
 *) echo "unknown batch"; exit 2;;
 esac
