@@ -546,7 +546,9 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_step_check_kernel(const double
     bool any = false;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < natoms; i += gridDim.x * BLOCK) {
         const size_t b = 3 * (size_t)i;
-        const double x0 = xp[b] + t * d[b], x1 = xp[b + 1] + t * d[b + 1], x2 = xp[b + 2] + t * d[b + 2];
+        // (this header contracts a*b+c into FMAs for the pair arithmetic; the line step is the reference's multiply-then-add)
+        const double x0 = __dadd_rn(xp[b], __dmul_rn(t, d[b])), x1 = __dadd_rn(xp[b + 1], __dmul_rn(t, d[b + 1])),
+                     x2 = __dadd_rn(xp[b + 2], __dmul_rn(t, d[b + 2]));
         x[b] = x0; x[b + 1] = x1; x[b + 2] = x2;
         const double ux = x0 - xref[b], uy = x1 - xref[b + 1], uz = x2 - xref[b + 2];
         any |= !(ux * ux + uy * uy + uz * uz <= half_skin2);
@@ -626,7 +628,11 @@ __global__ __launch_bounds__(BLOCK) void lj_cells_eval_kernel(const double* __re
             }
         }
         g[3 * (size_t)i] = fx; g[3 * (size_t)i + 1] = fy; g[3 * (size_t)i + 2] = fz;
-        if constexpr (DOT) gd += fx * dir[3 * (size_t)i] + fy * dir[3 * (size_t)i + 1] + fz * dir[3 * (size_t)i + 2];
+        if constexpr (DOT) {  // math.rs:41: acc += x*y, a multiply and an add with roundings of their own
+            gd = __dadd_rn(gd, __dmul_rn(fx, dir[3 * (size_t)i]));
+            gd = __dadd_rn(gd, __dmul_rn(fy, dir[3 * (size_t)i + 1]));
+            gd = __dadd_rn(gd, __dmul_rn(fz, dir[3 * (size_t)i + 2]));
+        }
     }
     if constexpr (DOT) {
         double acc[3] = {0.5 * e, stale, gd};

@@ -55,5 +55,9 @@ e3)  # after the counter passes of THIS build are in profiles/: the un-profiled 
     step 200 final/bench_3e6.json python bench.py --dim 3000000 --hist 6 --no-cpu-baseline
     step 200 config2.jsonl python tools/run_configs.py --only config2
     ;;
+f)
+    step 200 lj_tests.log python -m pytest tests/test_gpu_lj.py tests/test_gpu_parity.py -m gpu -x -q -k "lj or fused_owlqn"
+    # (here ran the vector-stagger A/B, a negative result: profiles/r05_vector_stagger_ab.log; its knob and script are gone)
+    ;;
 *) echo "unknown batch"; exit 2;;
 esac
