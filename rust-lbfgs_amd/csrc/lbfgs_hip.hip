@@ -874,7 +874,8 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     if (ctx->resident_plain_bytes == 0) ra.hbm_plain_pairs = 0;
     // rounds a waiting workgroup touches behind the window (resident.h TOUCHING): 16 of two vectors fill an XCD's L2, which
     // pays from ~64 rounds per thread up; shorter steps want 8 (profiles/r04_touch_sweep.log)
-    ra.touch_rounds = (uint32_t)(ctx->resident_touch >= 0 ? ctx->resident_touch : (E >= 64 ? 16 : 8));
+    // (the kernels are instantiated with exactly these depths: resident.h, TOUCH)
+    ra.touch_rounds = (uint32_t)(ctx->resident_touch >= 0 ? ctx->resident_touch : (er == 60 ? 16 : 8));
     int ns = 0;
     auto add = [&](const double* u, const double* v, int j, int mode_b, int scale, int aidx, int last) {
         ResStep& st = ra.step[ns++];

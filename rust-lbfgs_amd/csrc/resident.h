@@ -126,17 +126,11 @@ __device__ __forceinline__ void res_touch(const ResTouch& t, ResSink& sink, cons
         // run-time choice between the two pointers is compiled to an indexed read of this struct, i.e. to scratch memory)
         static_assert((32 * D) % RES_TOUCHERS == 0, "LH_RES_TOUCH must be a multiple of the touching threads / 32");
         constexpr int PER_VEC = 32 * D / RES_TOUCHERS;
-        constexpr uint32_t ROUNDS_PER_TRIP = RES_TOUCHERS / 32;  // rounds of one vector the touching threads cover per iteration
-        const uint32_t depth = t.r_end - t.r0;                   // (wave-uniform: the branch below costs a scalar compare)
+        // STRAIGHT-LINE code on purpose: a branch around a trip (tried in round 5 to skip trips beyond a run-time depth) ends in a
+        // join, at which the compiler waits for every load in flight -- the touches land on the critical path and the kernel is
+        // 1-2 % slower (profiles/r05_build_ab.log).  The depth is a compile-time fact of the instantiation instead (D).
 #pragma unroll
         for (int i = 0; i < 2 * PER_VEC; ++i) {
-            // iterations whose rounds lie beyond the requested depth touch NOTHING (before: they fell back on the last round
-            // touched, i.e. re-requested lines that had just been requested -- requests that queue ahead of the step's own
-            // operand loads; depth 0 = no touching at all)
-            if (ROUNDS_PER_TRIP * (uint32_t)(i % PER_VEC) >= depth) {
-                sink.w[i] = 0u;
-                continue;
-            }
             const uint32_t L = tt + (uint32_t)(RES_TOUCHERS * (i % PER_VEC));  // line among this vector's 32 * D
             const uint32_t r = min(t.r0 + L / 32u, t.r_end - 1u), line = L % 32u;
             const uint32_t off = min(t.first + r * t.round_stride + line * 128u, t.limit);
@@ -884,7 +878,10 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         ResFetch<ER, NT, true>::window(win, ps, up, vp);
     };
     prefetch(0);
-    constexpr int TOUCH = (HYB || ER == 0) ? 0 : LH_RES_TOUCH;  // (see TOUCHING at the top; the depth is a.touch_rounds <= TOUCH)
+    // (see TOUCHING at the top) the depth is a property of the instantiation: 16 rounds where a thread owns >= 61 rounds (ER = 60),
+    // 8 below -- the host asks for exactly that (a.touch_rounds), so no toucher issues a load for a line it has just requested
+    // (round 4 instantiated 16 everywhere and clamped: half of a toucher's loads were repeats on the shorter shards)
+    constexpr int TOUCH = (HYB || ER == 0) ? 0 : (ER == 60 ? LH_RES_TOUCH : LH_RES_TOUCH / 2);
     ResSink sink{};
     ResXchgAcc xacc;
     // (LH_RES_TOUCH) what a workgroup touches while it waits in the hand-off BEFORE step `si`: the rounds behind the window
@@ -892,9 +889,9 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
     tch.first = B * (uint32_t)(BLOCK * 16);
     tch.round_stride = G * (uint32_t)(BLOCK * 16);
     tch.r0 = (uint32_t)(RES_AHEAD * RES_UNROLL);
-    // (a thread's rounds beyond its last one fall back on the last one touched; whole trips beyond the depth are skipped;
-    // touch_rounds == 0: r_end == r0, nothing is touched)
-    tch.r_end = max(tch.r0, min(tch.r0 + min(a.touch_rounds, (uint32_t)(TOUCH > 0 ? TOUCH : 0)), max(a.pairs_per_thread, 1u)));
+    // (rounds beyond the depth asked for at run time, or beyond the thread's last round, fall back on the last one touched: lines
+    // that are in the L2 already.  touch_rounds = 0 touches one round: next to nothing)
+    tch.r_end = min(tch.r0 + max(min(a.touch_rounds, (uint32_t)(TOUCH > 0 ? TOUCH : 1)), 1u), max(a.pairs_per_thread, 1u));
     tch.limit = (uint32_t)(a.n * 8ull - 8ull);
     auto touch_for = [&](const int si) {
         ResTouch t = tch;

@@ -52,6 +52,9 @@ e3)  # after the counter passes of THIS build are in profiles/: the un-profiled 
         case $p in 8) dim=12500224;; 4) dim=25000192;; 2) dim=50000128;; esac
         step 200 final/shard_P${p}_bench.json python bench.py --dim $dim --no-cpu-baseline
     done
+    # the launch form the RCCL leg takes (a kernel per two-loop step), alone at the 8- and 4-GPU shard sizes: for the scaling model
+    LBFGS_HIP_RESIDENT=0 step 200 final/shard_P8_per_step_bench.json python bench.py --dim 12500224 --no-cpu-baseline --no-vector-free
+    LBFGS_HIP_RESIDENT=0 step 200 final/shard_P4_per_step_bench.json python bench.py --dim 25000192 --no-cpu-baseline --no-vector-free
     step 200 final/bench_3e6.json python bench.py --dim 3000000 --hist 6 --no-cpu-baseline
     step 200 config2.jsonl python tools/run_configs.py --only config2
     ;;

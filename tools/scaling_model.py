@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""A strong-scaling model the 8-GPU SCALE run can be read against (round 4; profiles/r04_scaling_model.md).
+"""A strong-scaling model the 8-GPU SCALE run can be read against (profiles/rNN_scaling_model.md).
 
-    python tools/scaling_model.py profiles/r04_bench_n1e8_m10.json P2=profiles/r04_shard_P2_bench.json \
-           P4=profiles/r04_shard_P4_bench.json P8=profiles/r04_shard_P8_bench.json [--exchange-measured-us 1.9]
+    python tools/scaling_model.py profiles/r05_bench_n1e8_m10.json P2=profiles/r05_shard_P2_bench.json \
+           P4=profiles/r05_shard_P4_bench.json P8=profiles/r05_shard_P8_bench.json [--round=5] \
+           [--exchange-measured-us=7.0 --exchange-measured-where="eight ranks (4 processes x 2 threads) ... (file)"]
 
 Inputs are `bench.py` lines MEASURED ON ONE GPU: the metric's configuration (n = 1e8, m = 10) and the rank-0 shards of the
 2-, 4- and 8-GPU runs alone (`bench.py --dim 50000128 / 25000192 / 12500224`: what ONE rank of such a run does between its
@@ -49,19 +50,25 @@ def facts(j):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    measured = None
+    measured, where, rnd = None, None, "5"
     for a in sys.argv[1:]:
         if a.startswith("--exchange-measured-us"):
             measured = float(a.split("=", 1)[1]) if "=" in a else None
+        elif a.startswith("--exchange-measured-where="):
+            where = a.split("=", 1)[1]
+        elif a.startswith("--round="):
+            rnd = a.split("=", 1)[1]
     one = facts(load(args[0]))
-    shards = {}
+    shards, per_step = {}, {}
     for a in args[1:]:
         k, p = a.split("=", 1)
-        shards[int(k[1:])] = facts(load(p))
+        # P<k>= the rank-0 shard of a k-GPU run alone (default launch form: the persistent kernel);
+        # S<k>= the same with LBFGS_HIP_RESIDENT=0 (a kernel per two-loop step: the launch form the RCCL leg takes)
+        (shards if k[0] == "P" else per_step)[int(k[1:])] = facts(load(p))
     m = one["m"]
     lat = [0.0, 2.0, 5.0, 10.0, 20.0, 50.0]
     out = []
-    out.append("# Strong-scaling model for BASELINE.json's metric (n = 1e8, m = 10) -- round 4\n")
+    out.append(f"# Strong-scaling model for BASELINE.json's metric (n = 1e8, m = 10) -- round {rnd}\n")
     out.append("NOT a multi-GPU measurement (no 8-GPU node has been offered to this build so far): one-GPU measurements of what a rank "
                "does between its exchanges, plus N exchanges of latency L per iteration.  Script: `tools/scaling_model.py`; inputs: the "
                "`bench.py` lines named below.\n")
@@ -103,6 +110,27 @@ def main():
             cells.append(f"{lcrit:.0f} us (speed-up {target:g})" if lcrit > 0 else "never (below it already alone)")
             out.append(f"| {p} | {nx:.1f} | " + " | ".join(cells) + " |")
         out.append("")
+    if per_step:
+        out.append("## Predicted: the RCCL leg (ncclAllReduce per reduction; the two-loop as one kernel per step)\n")
+        out.append(f"Exchanges per iteration: {2 * m + 1} (two-loop: every dot product is closed by an all-reduce launch of its own) + 1 "
+                   "(history update) + trials (line search).  L = what one ncclAllReduce of <= 48 bytes adds to the stream "
+                   "(`config.rccl.allreduce_us_mean` in a real run).\n")
+        lat_r = [0.0, 10.0, 15.0, 20.0, 30.0, 50.0]
+        out.append("| P | one rank alone, kernel per step: iters/s | " + " | ".join(f"L = {x:g} us: iters/s (speed-up)" for x in lat_r) +
+                   " | L at which speed-up = 6 (P = 8) / = P/2 |")
+        out.append("|---|---|" + "---|" * (len(lat_r) + 1))
+        for p in sorted(per_step):
+            f = per_step[p]
+            t0 = f["ms"]
+            if f["eval_ms"] and f["trials"]:
+                t0 += f["eval_ms"] / f["trials"] * (one["trials"] - f["trials"])
+            nx = 2 * m + 1 + 1 + one["trials"]
+            cells = [f"{1e3 / (t0 + nx * x * 1e-3):.0f} ({one['ms'] / (t0 + nx * x * 1e-3):.1f}x)" for x in lat_r]
+            target = 6.0 if p == 8 else p / 2.0
+            lcrit = (one["ms"] / target - t0) / nx * 1e3
+            cells.append(f"{lcrit:.0f} us (speed-up {target:g})" if lcrit > 0 else "never (below it already alone)")
+            out.append(f"| {p} | {f['ips']:.0f} | " + " | ".join(cells) + " |")
+        out.append("")
     out.append("## Reading\n")
     p8 = shards.get(8)
     if p8:
@@ -113,11 +141,12 @@ def main():
         out.append(f"* With {nx:.1f} exchanges per iteration, every microsecond of exchange latency costs {nx * 1e-3 / p8['ms'] * 100:.1f} % "
                    f"of an iteration at P = 8.")
     if measured is not None:
-        out.append(f"* Measured on ONE GPU shared by two ranks (no xGMI in it): {measured:.1f} us per exchange inside the persistent kernel "
-                   "(`profiles/r04_bench_two_ranks_sharing_one_gpu.json`, `roofline.exchange_us_mean`).  Over xGMI a store + poll "
-                   "round trip is expected at 2-5 us; rank skew adds to it.")
-    out.append("* If `SCALE_r04.json` arrives: compare each leg's `exchange_us_mean` and `exchanges_per_two_loop` with the L column that "
-               "matches, and its `two_loop_ms` with (two-loop ms of the row above + 2m * L).")
+        out.append(f"* Measured on ONE GPU (no xGMI in it), {where or 'several ranks sharing it'}: {measured:.1f} us per exchange inside the "
+                   "persistent kernel (`roofline.exchange_us_mean`; it includes waiting for ranks that share the same HBM).  Over xGMI a "
+                   "store + poll round trip is expected at 2-5 us; rank skew adds to it.")
+    out.append(f"* If `SCALE_r{int(rnd):02d}.json` arrives: compare each leg's `exchange_us_mean` and `exchanges_per_two_loop` with the L column that "
+               "matches, and its `two_loop_ms` with (two-loop ms of the row above + 2m * L); `config.rccl` carries the RCCL leg's figures "
+               "whichever leg `value` comes from.")
     print("\n".join(out))
 
 
