@@ -94,3 +94,40 @@ def test_a_caller_with_its_own_hip_kernels_and_deferred_trials(tmp_path):
         json.dump(j, open(os.path.join(out, "device_closure_caller.json"), "w"), indent=1)
     except OSError:
         pass
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# include/lbfgs.hpp: the crate's public API for C++ callers; tests/support/cpp_api_tests.cpp = the reference's own tests on it
+# ------------------------------------------------------------------------------------------------------------------
+CPP_SRC = os.path.join(ROOT, "tests", "support", "cpp_api_tests.cpp")
+
+
+def _build_cpp(tmp_path, libdir, libs):
+    exe = str(tmp_path / "cpp_api_tests")
+    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"), CPP_SRC, "-L", libdir, *libs,
+           "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_cpp_api_mirror_on_the_test_double(tmp_path):
+    """include/lbfgs.hpp (lbfgs().with_*().minimize(x, evaluate, progress), build / propagate, Progress, Report, the
+    setters' assert!s, Err propagation) through the reference's own tests -- tests/simple.rs:16-83, tests/owlqn.rs:6-63 with
+    its CSV fixtures -- linked against the CPU test double of the C-ABI (a logic check of header and program)."""
+    lib = mock.build()
+    exe = _build_cpp(tmp_path, os.path.dirname(lib), ["-l:" + os.path.basename(lib)])
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    assert "cpp_api_tests: all checks passed" in r.stdout and "test_owlqn: fx = -42724.136705" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_api_mirror_on_the_gpu(tmp_path):
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs the GPU")
+    exe = _build_cpp(tmp_path, os.path.dirname(_build.HIP_LIB), ["-llbfgs_solver", "-llbfgs_hip"])
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    assert "cpp_api_tests: all checks passed" in r.stdout
+    print("\n".join(ln for ln in r.stdout.splitlines() if ln.startswith("test_") or ln.startswith("cpp_api")))
