@@ -57,6 +57,7 @@ e3)  # after the counter passes of THIS build are in profiles/: the un-profiled 
     LBFGS_HIP_RESIDENT=0 step 200 final/shard_P4_per_step_bench.json python bench.py --dim 25000192 --no-cpu-baseline --no-vector-free
     step 200 final/bench_3e6.json python bench.py --dim 3000000 --hist 6 --no-cpu-baseline
     step 200 config2.jsonl python tools/run_configs.py --only config2
+    step 300 c_callers.log python -m pytest tests/test_c_caller.py -m gpu -q -s
     ;;
 f)
     step 200 lj_tests.log python -m pytest tests/test_gpu_lj.py tests/test_gpu_parity.py -m gpu -x -q -k "lj or fused_owlqn"
