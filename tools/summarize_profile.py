@@ -38,6 +38,7 @@ PASSES = [
     (r"OpNorms2", (2, 0), "norms"),
     (r"OpCopy<", (1, 1), "copy / ncopy"),
     # OWL-QN (config 3)
+    (r"OpObjOwlLineEval<.*, true>", (3, 4), "FIRST OWL-QN trial of a search: the orthant of the new point (core.rs:167-180) + line step + projection + eval + x1norm + pseudo-gradient + g.d"),
     (r"OpObjOwlLineEval<", (3, 3), "OWL-QN trial: line step + projection + eval + x1norm + pseudo-gradient + g.d (orthantwise.rs:70-133)"),
     (r"OpOrthantSelect", (2, 1), "orthant of the new point (core.rs:167-180)"),
     (r"OpOwlPost", (2, 1), "x1norm + pseudo-gradient (orthantwise.rs:70-112)"),
