@@ -27,7 +27,8 @@ start-up self-test (known-answer reductions, a reduction closed inside a streami
 an exact answer).  Phase 2, MEASUREMENTS, only for communicators whose probe passed, each with a share of what is left of
 the budget: "p2p" (direct exchange inside the reducing kernels, mailboxes in device memory mapped over xGMI; the two-loop
 runs as one persistent kernel), "p2p-per-step" (the same communicator with a kernel per two-loop step) only if the p2p
-MEASUREMENT failed, "rccl" (ncclAllReduce on the compute stream), "p2p-host" (the p2p exchange with host-coherent
+MEASUREMENT failed, "rccl" (ncclAllReduce; inside the two-loop gated on a second stream under the persistent kernel, and
+"rccl-per-step" -- a kernel per step, every all-reduce on the compute stream -- only if that measurement failed), "p2p-host" (the p2p exchange with host-coherent
 mailboxes: the placement a machine falls back to when device memory cannot be mapped between its GPUs; tried before rccl
 when p2p gave nothing), "callback" (host-staged all-reduce through gloo) only if nothing produced a result.  Every job's
 outcome is echoed to stderr as it lands; SIGTERM / SIGINT kill the running job and print the best line so far.  The run
@@ -319,8 +320,9 @@ def make_context(env, kind):
 
     a = env.a
     if env.world == 1:
-        if env.dist is not None and os.environ.get("LBFGS_FORCE_RCCL") == "1":
-            return sharded_context(a.n, device=env.dev, kind="rccl"), "rccl"
+        if env.dist is not None and os.environ.get("LBFGS_FORCE_RCCL") == "1":  # (the RCCL code path with a 1-rank communicator)
+            return sharded_context(a.n, device=env.dev, kind="rccl",
+                                   exclusive_device=(a.device < 0) if a.exclusive_device < 0 else bool(a.exclusive_device)), "rccl"
         return R.Context(a.n, device=env.dev), "none"
     ok, ctx = 1.0, None
     try:
@@ -477,8 +479,10 @@ def exchange_figures(ctx, ci_sum, roof):
     if timed:
         comm["exchange_us_mean"] = dd("exchange_us", "two_loop") / timed
         comm["local_wait_us_mean"] = dd("local_wait_us", "two_loop") / timed
-        comm["exchange_timing"] = ("measured on the device by the workgroup that closes a reduction across ranks (wall clock): "
-                                   "stores to every peer's mailbox + wait for every peer's values; exchanges inside two-loops only")
+        comm["exchange_timing"] = ("measured on the device by the workgroup that closes a reduction across ranks (wall clock): " + (
+            "its sums into the slot + flag, until the gate kernel, the ncclAllReduce behind it and the post kernel on the second "
+            "stream have answered (gated exchange); exchanges inside two-loops only" if ci["kind"] == "rccl" else
+            "stores to every peer's mailbox + wait for every peer's values; exchanges inside two-loops only"))
     elif ci["kind"] == "rccl" and roof.get("per_iteration_ms", {}).get("allreduce_launches"):
         pi = roof["per_iteration_ms"]
         comm["exchange_us_mean"] = pi["allreduce"] / pi["allreduce_launches"] * 1e3
@@ -844,7 +848,7 @@ def free_port():
     return p
 
 
-LEG_COMM = {"p2p": "p2p", "p2p-per-step": "p2p", "p2p-host": "p2p-host", "rccl": "rccl", "callback": "callback"}
+LEG_COMM = {"p2p": "p2p", "p2p-per-step": "p2p", "p2p-host": "p2p-host", "rccl": "rccl", "rccl-per-step": "rccl", "callback": "callback"}
 # what closes the scalar reductions of a leg, in words: an N > 1 line says it in `metric` and `config.allreduce`, so that nobody
 # reads a number of the in-kernel exchange as a number of RCCL (BASELINE.json's north star names "a scalar RCCL all-reduce")
 LEG_SAYS = {
@@ -852,7 +856,9 @@ LEG_SAYS = {
            "is one persistent kernel) -- NOT RCCL",
     "p2p-per-step": "p2p in-kernel exchange (device mailboxes over xGMI), one kernel per two-loop step -- NOT RCCL",
     "p2p-host": "p2p in-kernel exchange through host-coherent mailboxes (reached over PCIe) -- NOT RCCL",
-    "rccl": "rccl ncclAllReduce(ncclDouble, ncclSum) on the compute stream, one per reduction; the two-loop is one kernel per step",
+    "rccl": "rccl ncclAllReduce(ncclDouble, ncclSum), one per reduction; inside the two-loop the all-reduces run on a second stream "
+            "behind gate kernels while the recursion stays ONE persistent kernel (gated exchange)",
+    "rccl-per-step": "rccl ncclAllReduce(ncclDouble, ncclSum) on the compute stream, one per reduction; the two-loop is one kernel per step",
     "callback": "host-staged all-reduce through torch.distributed/gloo (last resort) -- NOT RCCL",
     "none": "single GPU: no communicator",
 }
@@ -866,8 +872,10 @@ def rccl_beside(report, lines):
            "ranks_seen": None, "status": "not run" if rep is None else rep.get("status"),
            "says": LEG_SAYS["rccl"]}
     for lg, j in lines:
-        if lg != "rccl":
+        if lg not in ("rccl", "rccl-per-step") or (lg == "rccl-per-step" and out["iters_per_sec"] is not None):
             continue
+        out["says"] = LEG_SAYS[lg]
+        out["status"] = (report.get(lg) or {}).get("status", out["status"])
         roof = j.get("roofline") or {}
         ci = j["config"].get("comm_info") or {}
         out.update(iters_per_sec=round(j["value"], 3), two_loop_ms=(roof.get("two_loop") or {}).get("ms"),
@@ -1067,6 +1075,8 @@ def supervisor_main(a):
         leg_env = dict(base_env)
         if leg == "p2p-per-step":  # the p2p communicator with one kernel per two-loop step (no persistent kernel)
             leg_env["LBFGS_HIP_RESIDENT"] = "0"
+        if leg == "rccl-per-step":  # RCCL with one kernel per two-loop step (no gated exchange under the persistent kernel)
+            leg_env["LBFGS_HIP_RCCL_RESIDENT"] = "0"
         if hook:
             cmd_tail, child = None, [sys.executable, "-c", "import time; time.sleep(100000)"]
         else:
@@ -1179,7 +1189,9 @@ def supervisor_main(a):
         else:                # comparisons
             rest.sort(key=lambda c: {"rccl": 0, "p2p-host": 1}.get(c, 2))
         for i, leg in enumerate(rest):
-            measure_leg(leg, len(rest) - 1 - i)
+            got = measure_leg(leg, len(rest) - 1 - i)
+            if leg == "rccl" and not decided(got):  # the gated form gave nothing: RCCL's plain form, a kernel per step
+                measure_leg("rccl-per-step", len(rest) - 1 - i)
     if not sync_have() and (a.comm == "auto") and "callback" not in report:
         # last resort: the host-staged all-reduce through gloo, only if nothing has produced a result
         measure_leg("callback", 0)

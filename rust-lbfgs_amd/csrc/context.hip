@@ -300,6 +300,96 @@ int fill_handoff(lbfgs_hip_ctx* ctx, RedCtl& red, int nred) {
 }
 
 
+// ---- the gated exchange's plumbing (stream.h ext_exchange) ---------------------------------------------------------------
+constexpr size_t EXT_BUF_OFFSET = 256;  // bytes from the start of the uncached block to the ring of exchange slots
+static_assert(P2P_MBOX_WORDS * sizeof(unsigned long long) >= EXT_BUF_OFFSET + (size_t)EXT_SLOTS * EXT_SLOT_DOUBLES * sizeof(double),
+              "the gated exchange keeps its flags and slots in one block of the mailbox pool");
+// The two streams of the gated exchange must be served CONCURRENTLY: the gate kernel spins while the persistent kernel runs,
+// and the persistent kernel waits for what comes behind the gate.  HIP deals its streams onto a handful of hardware queues
+// (four by default), so two streams of a process that has many -- PyTorch's, RCCL's -- can share one, and then the second
+// kernel never starts while the first waits for it.  The second stream therefore gets the HIGHEST priority (priorities have
+// hardware queues of their own), and a handshake at first use proves the concurrency before anything relies on it.
+__global__ __launch_bounds__(64) void ext_selftest_wait_kernel(unsigned long long* flags, unsigned long long magic, unsigned long long ticks) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    unsigned long long seen = 0;
+    while ((seen = __hip_atomic_load(flags + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != magic &&
+           (unsigned long long)(wall_clock64() - t0) < ticks)
+        __builtin_amdgcn_s_sleep(2);
+    __hip_atomic_store(flags + 4, seen == magic ? 1ull : 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ __launch_bounds__(64) void ext_selftest_set_kernel(unsigned long long* flags, unsigned long long magic) {
+    if (threadIdx.x == 0) __hip_atomic_store(flags + 3, magic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int ext_prepare(lbfgs_hip_ctx* ctx) {
+    const bool first_use = !ctx->xstream || !ctx->ext_block;
+    if (!ctx->xstream) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // (numerically lowest = highest priority)
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->xstream, hipStreamNonBlocking, hi));
+    }
+    if (!ctx->ext_block) {
+        void* p = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_uc_pool_mu);  // (uncached blocks are pooled per process, never freed: see lbfgs_hip_ctx_create)
+            auto& pool = g_uc_mbox_pool[ctx->device];
+            if (!pool.empty()) {
+                p = pool.back();
+                pool.pop_back();
+            }
+        }
+        const size_t bytes = P2P_MBOX_WORDS * sizeof(unsigned long long);
+        if (!p) HIP_TRY(ctx, hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached));
+        ctx->ext_block = static_cast<unsigned long long*>(p);
+        HIP_TRY(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (first_use) {
+        // handshake: a kernel on the compute stream waits (<= 20 ms) for a word that a kernel on the second stream sets
+        const unsigned long long magic = 0x6761746564ull;
+        hipLaunchKernelGGL(ext_selftest_wait_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->ext_block, magic, 2000000ull);
+        hipLaunchKernelGGL(ext_selftest_set_kernel, dim3(1), dim3(64), 0, ctx->xstream, ctx->ext_block, magic);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->xstream));
+        unsigned long long verdict = 0;
+        HIP_TRY(ctx, hipMemcpy(&verdict, ctx->ext_block + 4, sizeof(verdict), hipMemcpyDeviceToHost));
+        if (verdict == 1ull && ctx->nccl) {
+            // RCCL's first collective on a stream may set things up (channels, buffers) and wait for the device: let it do so
+            // NOW, not with a persistent kernel waiting for it.  Collective: every rank of the communicator comes here from
+            // lbfgs_hip_ctx_create under the same settings (LBFGS_HIP_RCCL_RESIDENT, exclusive_device).
+            double* const slot0 = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->ext_block) + EXT_BUF_OFFSET);
+            const int rc_w = rccl_allreduce_on(ctx, slot0, 1, ctx->xstream);
+            if (rc_w != LBFGS_HIP_OK) return rc_w;
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->xstream));
+            HIP_TRY(ctx, hipMemsetAsync(slot0, 0, EXT_SLOT_DOUBLES * sizeof(double), ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        if (verdict != 1ull) {
+            ctx->rccl_resident = 0;
+            fprintf(stderr, "[lbfgs_hip] warning: the compute stream and the second stream of the gated RCCL exchange are not served "
+                            "concurrently on this device (they share a hardware queue: GPU_MAX_HW_QUEUES); the two-loop runs with a "
+                            "kernel per step under RCCL\n");
+            return 1;  // (not an error: the caller takes the kernel-per-step form)
+        }
+    }
+    return LBFGS_HIP_OK;
+}
+// Give the chain of the latest gated launch up: its gates leave at once (abort word >= their launch id), the all-reduces behind
+// them reduce whatever the slots hold -- on every rank alike, nobody reads it -- and the second stream runs empty.
+void ext_abort(lbfgs_hip_ctx* ctx) {
+    if (!ctx->xstream || !ctx->ext_block) return;
+    const unsigned long long id = ctx->ext_launches;
+    (void)hipMemcpy(ctx->ext_block + 2, &id, sizeof(id), hipMemcpyHostToDevice);
+    (void)hipStreamSynchronize(ctx->xstream);
+}
+int rccl_allreduce_on(lbfgs_hip_ctx* ctx, double* buf, int count, hipStream_t stream) {
+    const int rc = g_rccl.AllReduce(buf, buf, (size_t)count, kNcclDouble, kNcclSum, ctx->nccl, stream);
+    if (rc != 0) return fail(ctx, LBFGS_HIP_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString(rc));
+    return LBFGS_HIP_OK;
+}
+
 P2PCtl next_p2p(lbfgs_hip_ctx* ctx) {
     P2PCtl c{};
     for (int r = 0; r < ctx->shard.world && r < P2P_MAX_WORLD; ++r) c.mbox[r] = ctx->p2p_mbox[r];
@@ -599,6 +689,7 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     if (const char* e = getenv("LBFGS_HIP_GRAM_COMBINE_RESIDENT")) ctx->gram_combine_resident = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_LJ_BUILD_FP32")) ctx->lj_build_fp32 = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_LJ_FUSED_TRIAL")) ctx->lj_fused_trial = atoi(e) != 0;
+    if (const char* e = getenv("LBFGS_HIP_RCCL_RESIDENT")) ctx->rccl_resident = atoi(e) != 0;
     if (const char* e = getenv("LBFGS_HIP_HANDOFF_TIMEOUT_MS")) ctx->handoff_timeout_ticks = (unsigned long long)std::max(1, atoi(e)) * 100000ULL;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_FIRST_TIMEOUT_MS")) ctx->first_timeout_ticks = (unsigned long long)std::max(1, atoi(e)) * 100000ULL;
     if (const char* e = getenv("LBFGS_HIP_RESIDENT_NT_MB")) ctx->resident_nt_bytes = (size_t)std::max(0, atoi(e)) << 20;
@@ -751,6 +842,17 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
         ctx->rccl_ranks_seen = cnt;
         ctx->rccl_rank_seen = urank;
         ctx->comm_kind = LBFGS_HIP_COMM_RCCL;
+        ctx->p2p_exclusive = comm->exclusive_device != 0;  // (the persistent kernel with the gated exchange needs the GPU to itself)
+        const double tmo = comm->p2p_timeout_s > 0 ? comm->p2p_timeout_s : 5.0;
+        ctx->p2p_timeout_ticks = (unsigned long long)(tmo * 1e8);
+        if (ctx->p2p_exclusive && ctx->rccl_resident) {  // the gated exchange's second stream, slots, handshake and RCCL warm-up
+            const int rc_x = ext_prepare(ctx);
+            if (rc_x < 0) {
+                const std::string msg = ctx->err;
+                lbfgs_hip_ctx_destroy(ctx);
+                return fail(nullptr, rc_x, "%s", msg.c_str());
+            }
+        }
     } else if (kind == LBFGS_HIP_COMM_P2P) {
         const int W = ctx->shard.world, me = ctx->shard.rank;
         if (W > P2P_MAX_WORLD || !comm->p2p_mailbox || !comm->p2p_handles) {
@@ -828,7 +930,10 @@ void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* ctx) {
 #endif
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ext_abort(ctx);  // (a gated chain that is still waiting for a kernel that will never come)
     if (ctx->nccl && g_rccl.ok) g_rccl.CommDestroy(ctx->nccl);
+    if (ctx->xstream) (void)hipStreamDestroy(ctx->xstream);
+    if (ctx->ext_block) uc_mbox_retire(ctx->device, ctx->ext_block);
     for (int r = 0; r < P2P_MAX_WORLD; ++r) {
         if (!ctx->p2p_mbox[r]) continue;
         if (ctx->p2p_opened[r]) continue;  // (a peer's mailbox: stays mapped, see ipc_open_cached)
@@ -1028,12 +1133,15 @@ int lbfgs_hip_vec_swap(lbfgs_hip_vec* a, lbfgs_hip_vec* b) {
 
 // ==================================================================================== board
 static int device_error(lbfgs_hip_ctx* ctx, unsigned int flag, bool after_rerun = false) {
+    ext_abort(ctx);  // (a gated launch that failed: its gates and all-reduces on the second stream are given up with it)
     if (flag == 2u)
         return fail(ctx, LBFGS_HIP_ERR_HIP, "a reduction timed out waiting for a workgroup's partial sums (the latest reducing launch was %s; "
                     "resident two-loops so far %llu, of which re-run per step %llu; resident path %s)",
                     after_rerun ? "the per-step re-run of a resident two-loop" : "not a resident two-loop (or its inputs have changed since)",
                     ctx->resident_launches, ctx->resident_fallbacks, ctx->resident_ok == 1 ? (ctx->resident_proven ? "in use" : "unproven") : "off");
-    return fail(ctx, LBFGS_HIP_ERR_COMM, "P2P all-reduce timed out waiting for a peer");
+    return fail(ctx, LBFGS_HIP_ERR_COMM, ctx->comm_kind == LBFGS_HIP_COMM_RCCL
+                    ? "the gated RCCL exchange of a resident two-loop timed out (no all-reduce answered within the bound)"
+                    : "P2P all-reduce timed out waiting for a peer");
 }
 
 // one read; *flag receives the device error word that travelled with the results (0 = none)

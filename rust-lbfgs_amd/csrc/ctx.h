@@ -109,6 +109,11 @@ struct lbfgs_hip_ctx {
     unsigned long long* gran = nullptr;   // tagged partial granules [MAX_RED][MAX_GRID][2] (stream.h)
     bool gran_pooled = false;             // ... in an uncached block of the process-wide pool (returned there, never freed)
     bool p2p_exclusive = false;           // lbfgs_hip_comm.exclusive_device: no other rank shares this GPU
+    // GATED exchange (RCCL under the persistent two-loop kernel; stream.h ext_exchange, lbfgs_hip.hip enqueue_gated_chain)
+    int rccl_resident = 1;                // LBFGS_HIP_RCCL_RESIDENT=0: under RCCL the two-loop always runs with a kernel per step
+    hipStream_t xstream = nullptr;        // the second stream: gate -> ncclAllReduce -> post, one triple per exchange
+    unsigned long long* ext_block = nullptr;  // one uncached block: flags A, B, abort at words 0..2, the ring of exchange slots at byte 256
+    unsigned long long ext_launches = 0;  // gated launches so far (the abort word names the launch that is given up)
     unsigned long long resident_attr_mask = 0;  // which resident kernels have had their dynamic-LDS limit raised on this device
     int gram_combine_resident = 1;        // LBFGS_HIP_GRAM_COMBINE_RESIDENT=0: the vector-free combine as one streaming pass over all columns
     int lj_build_fp32 = 1;                // LBFGS_HIP_LJ_BUILD_FP32=0: the LJ_CELLS list from double-precision candidate tests
@@ -193,6 +198,10 @@ inline bool slot_ok(int first, int count) {
 }
 
 LH_INTERNAL int grid_for(const lbfgs_hip_ctx* ctx, int x32 = 27);
+// gated exchange: make sure the second stream and the uncached block exist (-> status); give the running chain up and drain it
+LH_INTERNAL int ext_prepare(lbfgs_hip_ctx* ctx);
+LH_INTERNAL void ext_abort(lbfgs_hip_ctx* ctx);
+LH_INTERNAL int rccl_allreduce_on(lbfgs_hip_ctx* ctx, double* buf, int count, hipStream_t stream);
 
 // ---- profiling: one event pair per launch of a timed class --------------------------------
 struct ProfScope {

@@ -774,6 +774,59 @@ int resident_launch(lbfgs_hip_ctx* ctx, const ResArgs& ra, const RedCtl& red, in
     return LBFGS_HIP_OK;
 }
 
+// (stream.h describes it; anonymous namespace: this translation unit only)
+__global__ __launch_bounds__(64) void ext_post_gate_kernel(const ExtGateArgs a) {
+    if (threadIdx.x != 0) return;
+    if (a.post_epoch) __hip_atomic_store(a.flags + 1, a.post_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.gate_epoch) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.gate_epoch) {
+            if (__hip_atomic_load(a.flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= a.abort_id) break;
+            if ((unsigned long long)(wall_clock64() - t0) > a.timeout_ticks) {
+                atomicExch(a.err, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+
+// The GATED exchange's second stream (stream.h): for each of the launch's `handoffs` exchanges  gate(epoch) -> ncclAllReduce of
+// the slot -> post(epoch), the post of one exchange and the gate of the next in ONE kernel.  Enqueued right behind the launch of
+// the persistent kernel: every element is in the stream long before the kernel reaches the hand-off it serves (a step takes
+// tens of microseconds, an element a few to enqueue); a pre-enqueued round trip through two kernel boundaries costs 3.9 us
+// on one GPU (tools/gated_exchange_probe.hip) + whatever the all-reduce itself takes.
+// Epochs: DevCounters::p2p_epoch as the kernel will walk it -- exchange number c (counted from 0 over the context's life) has
+// epoch c % (2^32 - 1) + 1, never 0.  Every hand-off carries one sum except the last (2, or 4 under OWL-QN).
+int enqueue_gated_chain(lbfgs_hip_ctx* ctx, unsigned long long first_exchange, int handoffs, int last_count) {
+    auto epoch_of = [](unsigned long long c) { return (unsigned long long)(c % 0xFFFFFFFFull) + 1ull; };
+    double* const ring = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->ext_block) + 256);
+    ctx->ext_launches += 1;
+    ExtGateArgs ga{};
+    ga.flags = ctx->ext_block;
+    ga.err = ctx->p2p_err;
+    ga.abort_id = ctx->ext_launches;
+    ga.timeout_ticks = ctx->p2p_timeout_ticks + ctx->handoff_timeout_ticks;  // (the kernel may itself be waiting for its workgroups)
+    ga.post_epoch = 0;
+    for (int i = 0; i < handoffs; ++i) {
+        const unsigned long long e = epoch_of(first_exchange + (unsigned long long)i);
+        ga.gate_epoch = e;
+        hipLaunchKernelGGL(ext_post_gate_kernel, dim3(1), dim3(64), 0, ctx->xstream, ga);
+        const int rc = rccl_allreduce_on(ctx, ring + (size_t)(e % (unsigned long long)EXT_SLOTS) * EXT_SLOT_DOUBLES,
+                                         i + 1 == handoffs ? last_count : 1, ctx->xstream);
+        if (rc != LBFGS_HIP_OK) {
+            ext_abort(ctx);
+            return rc;
+        }
+        ga.post_epoch = e;
+        ctx->allreduce_calls += 1;
+    }
+    ga.gate_epoch = 0;
+    hipLaunchKernelGGL(ext_post_gate_kernel, dim3(1), dim3(64), 0, ctx->xstream, ga);
+    HIP_TRY(ctx, hipGetLastError());
+    return LBFGS_HIP_OK;
+}
+
 // -> 1 if the recursion was launched as the resident kernel, 0 if this case is not eligible (caller falls back), < 0 error
 int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
                       int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end, bool owl,
@@ -783,10 +836,15 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     const int bound = (int)std::min<uint64_t>((uint64_t)m, k);
     // One rank -- or several that each have their GPU to themselves: a kernel that fills the chip and waits for its peers
     // inside would starve ranks sharing the GPU (lbfgs_hip_comm.exclusive_device).
-    const bool comm_ok = ctx->comm_kind == LBFGS_HIP_COMM_NONE || (ctx->comm_kind == LBFGS_HIP_COMM_P2P && ctx->p2p_exclusive);
+    // Under RCCL the exchange is GATED (stream.h ext_exchange): ncclAllReduce only exists as a host-enqueued kernel, so the host
+    // enqueues one per hand-off on a second stream, each behind a gate kernel that waits for this kernel's flag -- q stays on the chip.
+    const bool gated = ctx->comm_kind == LBFGS_HIP_COMM_RCCL && ctx->rccl_resident && ctx->p2p_exclusive && ctx->xstream && ctx->ext_block;
+    const bool comm_ok = ctx->comm_kind == LBFGS_HIP_COMM_NONE || (ctx->comm_kind == LBFGS_HIP_COMM_P2P && ctx->p2p_exclusive) || gated;
     if (!ctx->resident_on || !comm_ok || ctx->handoff_ticket || bound < 1 || ctx->grid_override > 0 ||
         2 * bound > RES_MAX_STEPS)
         return 0;
+    // (gated: lbfgs_hip_ctx_create made the second stream and the uncached block, proved that both streams are served concurrently
+    // -- else rccl_resident is off -- and let RCCL run its first collective on that stream)
     // one workgroup per CU: all of them resident at once (fewer on request -- tests run two ranks on one GPU -- and for
     // vectors of a few MB, where a hand-off among fewer workgroups is worth more than the idle CUs' bandwidth: >= 8 pairs per
     // thread, at least 64 workgroups; measured at n = 1e5 / 3e5 / 1e6, profiles/r02_resident_small_n.log)
@@ -796,7 +854,10 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     const bool mostly_streaming = (n >> 1) > 5ull * (uint64_t)(60 + RES_LDS_PAIRS_MAX) * (uint64_t)ctx->cu_count * BLOCK;
     const int grid_auto = mostly_streaming ? std::max(1, ctx->cu_count * 27 / 32)
         : (int)std::min<uint64_t>((uint64_t)ctx->cu_count, std::max<uint64_t>(64, ((n >> 1) + BLOCK * 8 - 1) / (BLOCK * 8)));
-    const int grid = ctx->resident_grid > 0 ? std::min(ctx->resident_grid, ctx->cu_count) : grid_auto;
+    // (gated: RCCL's kernel and the gates need CUs of their own while this kernel waits -- one per XCD is left free, workgroups
+    // being dealt to the XCDs round robin; tools/gated_exchange_probe.hip measured the same round trip with 1, 8 or 16 free)
+    const int grid_cap = gated ? std::max(1, ctx->cu_count - 8) : ctx->cu_count;
+    const int grid = std::min(ctx->resident_grid > 0 ? std::min(ctx->resident_grid, ctx->cu_count) : grid_auto, grid_cap);
     if (grid < 1 || grid > BLOCK || grid > MAX_GRID) return 0;  // (every thread polls one workgroup's granules)
     const uint64_t per_round = (uint64_t)grid * BLOCK;
     const uint64_t E = ((n >> 1) + per_round - 1) / per_round;  // 16-byte pairs per thread
@@ -899,6 +960,35 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
 #endif
     const int rc_p = prep_red(ctx, red, owl ? 4 : 2, outs2, nullptr, 0, &in_kernel_exchange);
     if (rc_p != LBFGS_HIP_OK) return rc_p;
+    const unsigned long long first_exchange = ctx->p2p_count;  // (gated: exchanges closed so far = the epochs this launch starts behind)
+    if (gated) {
+        red.p2p.world = ctx->shard.world;
+        red.p2p.rank = ctx->shard.rank;
+        red.p2p.err = ctx->p2p_err;
+        red.p2p.timeout_ticks = ctx->p2p_timeout_ticks;
+        red.p2p.ext_flags = ctx->ext_block;
+        red.p2p.ext_buf = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->ext_block) + 256);
+        in_kernel_exchange = true;  // (the totals are final when the kernel ends; the counters below are the P2P form's)
+        ctx->p2p_count += 1;
+        ctx->two_loop_exchanges += 1;
+        // the totals ARE final inside the kernel: mirror them like the P2P form does (prep_red decided for "not final")
+        if (ctx->mirror) {
+            bool any_public = false;
+            for (int k = 0; k < (owl ? 4 : 2); ++k) any_public = any_public || (outs2[k] - ctx->board >= 0 && outs2[k] - ctx->board < LBFGS_HIP_BOARD_SLOTS);
+            if (any_public) {
+                for (int k = 0; k < (owl ? 4 : 2); ++k) {
+                    const long idx = outs2[k] - ctx->board;
+                    if (idx >= 0 && idx < LBFGS_HIP_BOARD_SLOTS + 2) ctx->mirror_valid[idx] = true;
+                }
+                red.mirror.host_board = ctx->mirror_dev;
+                red.mirror.board = ctx->board;
+                red.mirror.host_seq = reinterpret_cast<unsigned long long*>(ctx->mirror_dev + LBFGS_HIP_BOARD_SLOTS + 2);
+                ctx->mirror_seq += 1;
+                red.mirror.host_err = reinterpret_cast<unsigned long long*>(ctx->mirror_dev + LBFGS_HIP_BOARD_SLOTS + 3);
+                red.mirror.slots = LBFGS_HIP_BOARD_SLOTS + 2;
+            }
+        }
+    }
     // until a resident launch of this context has been seen to complete, a missing workgroup costs milliseconds (see
     // lbfgs_hip_ctx::first_timeout_ticks); one rank only: with peers a hand-off also waits for THEIR start-up
     if (!ctx->resident_proven && ctx->comm_kind == LBFGS_HIP_COMM_NONE)
@@ -940,6 +1030,10 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
         }
     }
     if (rc != LBFGS_HIP_OK) return rc;
+    if (gated) {  // the chain that closes this launch's hand-offs across the ranks, behind the kernel that is already running
+        const int rc_c = enqueue_gated_chain(ctx, first_exchange, (int)handoffs, owl ? 4 : 2);
+        if (rc_c != LBFGS_HIP_OK) return rc_c;
+    }
 #if LH_RES_TRACE
     res_trace_collect(ctx, trace_first_tag, (int)handoffs, grid);
 #endif

@@ -195,7 +195,7 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
     LH_TR(const long long tr0 = wall_clock64(); long long tr1 = 0; unsigned int tr_polls = 0;)
     res_block_total<NS>(acc, lds);  // (every thread holds the workgroup's sums)
     const unsigned int G = gridDim.x;  // (<= BLOCK: the host launches no larger grid -- thread t polls workgroup t)
-    const bool multi = red.p2p.world > 1;
+    const bool multi = p2p_active(red.p2p);
     const unsigned long long t = (unsigned long long)tag << 32;
     if (threadIdx.x == 0) {
 #pragma unroll
@@ -303,7 +303,8 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
             }
             __syncthreads();
             const long long t1 = wall_clock64();
-            p2p_exchange(red.p2p, p2p_tag, s_tot, NS, s_bits);
+            if (red.p2p.ext_buf) ext_exchange(red.p2p, p2p_tag, s_tot, NS);  // (gated: ncclAllReduce on the second stream)
+            else p2p_exchange(red.p2p, p2p_tag, s_tot, NS, s_bits);
             xacc.p2p_ticks += (unsigned long long)(wall_clock64() - t1);
             xacc.local_ticks += (unsigned long long)(t1 - t0);
             xacc.count += 1ull;
@@ -1011,7 +1012,7 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         if (a.owl) { outv[1] = 0.0; outv[2] = acc[1]; outv[3] = acc[2]; }
         for (int k = 0; k < nout; ++k) a.out_dn[k] = outv[k];
         red.ctr->red_epoch = tag;  // every workgroup has left the last hand-off with `tag - 1`: nobody reads the counter again
-        if (red.p2p.world > 1) {
+        if (p2p_active(red.p2p)) {
             red.ctr->p2p_epoch = ptag;
             DevXchg* const xs = dev_xchg(red.ctr, 1u);  // (this kernel's exchanges all belong to a two-loop)
             DevXchg x = *xs;

@@ -67,7 +67,14 @@ struct P2PCtl {
     int world, rank;                          // world <= 1: no exchange
     unsigned int* err;
     unsigned long long timeout_ticks;         // wall_clock64 ticks (100 MHz)
+    // GATED exchange (RCCL under the persistent two-loop kernel, resident.h): the reduction across ranks is closed OUTSIDE
+    // the kernel, by ncclAllReduce launches the host has enqueued on a second stream behind gate kernels -- the kernel stores
+    // its sums into ext_buf (uncached), raises flag A, and reads the reduced sums back once flag B carries the same epoch.
+    double* ext_buf;                          // nullptr: the mailbox exchange above.  [EXT_SLOTS][EXT_SLOT_DOUBLES]
+    unsigned long long* ext_flags;            // uncached: [0] = A (kernel -> gate), [1] = B (post -> kernel), [2] = abort
 };
+constexpr int EXT_SLOTS = 64, EXT_SLOT_DOUBLES = 8;  // a ring of exchange buffers: one per exchange of a launch (<= 2*24 + 1)
+__device__ __forceinline__ bool p2p_active(const P2PCtl& c) { return c.world > 1 || c.ext_buf != nullptr; }
 
 // Host mirror of the scalar board: when the totals are FINAL (one rank, or closed by the in-kernel exchange)
 // the last workgroup also stores them into host-mapped memory and then bumps a sequence word, so the host
@@ -187,6 +194,45 @@ __device__ __forceinline__ void p2p_exchange(const P2PCtl& c, const unsigned int
     p2p_publish(c, epoch, vals, count);
     p2p_collect(c, epoch, vals, count, bits);
 }
+// The gated form (P2PCtl::ext_buf): called by ALL threads of one workgroup; vals[0..count) in LDS, in = this rank's sums, out =
+// the global sums.  Slot epoch % EXT_SLOTS of the ring is the send AND receive buffer of the all-reduce the host enqueued for
+// this epoch (in place).  Uncached memory, system-scope accesses: the values must have left the CU before the flag does
+// (s_waitcnt, no L2 write-back: nothing here is cached), and the kernel that reduces them starts behind a kernel boundary.
+__device__ __forceinline__ void ext_exchange(const P2PCtl& c, const unsigned int epoch, double* vals, int count) {
+    double* const slot = c.ext_buf + (size_t)(epoch % (unsigned int)EXT_SLOTS) * EXT_SLOT_DOUBLES;
+    if ((int)threadIdx.x < count) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + threadIdx.x), (unsigned long long)__double_as_longlong(vals[threadIdx.x]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(c.ext_flags, (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(c.ext_flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (unsigned long long)epoch) {
+            if ((unsigned long long)(wall_clock64() - t0) > c.timeout_ticks) {
+                atomicExch(c.err, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < count)
+        vals[threadIdx.x] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(slot + threadIdx.x),
+                                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    __syncthreads();
+}
+// The kernels of the second stream (host: lbfgs_hip.hip enqueue_gated_chain).  post: flag B = post_epoch (0: none) -- the
+// all-reduce in front of it has completed (stream order).  gate: wait until the persistent kernel has raised flag A to
+// gate_epoch (0: none) -- only then may the all-reduce behind it read the slot.  Bounded: a timeout or the abort word (the host
+// gave the launch up) ends the wait; whatever is reduced then is discarded with the launch.
+struct ExtGateArgs {
+    unsigned long long* flags;
+    unsigned int* err;
+    unsigned long long post_epoch, gate_epoch, abort_id, timeout_ticks;
+};
+// (the kernel itself: lbfgs_hip.hip ext_post_gate_kernel -- this header is included by three translation units)
 
 // ---- agent-scope accesses for the cross-workgroup hand-off -------------------------------
 // Two forms, both built on 8-byte agent-scope atomics on both sides (no L2 write-back fence):

@@ -86,8 +86,10 @@ class CommSpec:
             self.c.callback = callback
 
 
-def rccl_comm(process_group=None):
-    """RCCL communicator: rank 0 makes the unique id, torch.distributed broadcasts it."""
+def rccl_comm(process_group=None, exclusive_device=False):
+    """RCCL communicator: rank 0 makes the unique id, torch.distributed broadcasts it.
+    exclusive_device=True (one process per GPU, nobody else on it): the two-loop may run as the persistent kernel with the
+    all-reduces GATED on a second stream (csrc/stream.h ext_exchange) instead of one kernel per step."""
     _ffi.torch_before_rccl()  # (torch is imported before librccl is touched)
     L = _ffi.load()
     buf = (C.c_char * 128)()
@@ -97,7 +99,9 @@ def rccl_comm(process_group=None):
             raise LbfgsError(rc, L.lbfgs_hip_last_error(None).decode())
     raw = _broadcast(process_group, bytes(buf.raw), 0)
     C.memmove(buf, raw, 128)
-    return CommSpec(_ffi.COMM_RCCL, unique_id=buf)
+    spec = CommSpec(_ffi.COMM_RCCL, unique_id=buf)
+    spec.c.exclusive_device = int(bool(exclusive_device))
+    return spec
 
 
 def p2p_comm(device, process_group=None, timeout_s=5.0, exclusive_device=False, placement=_ffi.MAILBOX_AUTO):
@@ -198,7 +202,7 @@ def sharded_context(n, device=0, kind="rccl", process_group=None, stream=None, e
     if world == 1 and not (kind == "rccl" and os.environ.get("LBFGS_FORCE_RCCL") == "1"):
         comm = None  # (LBFGS_FORCE_RCCL=1 exercises the RCCL code path with a 1-rank communicator)
     elif kind == "rccl":
-        comm = rccl_comm(process_group)
+        comm = rccl_comm(process_group, exclusive_device=exclusive_device)
     elif kind == "callback":
         comm = callback_comm(process_group)
     elif kind in ("p2p", "p2p-device", "p2p-host"):

@@ -153,9 +153,9 @@ def test_the_n_gt_1_line_says_which_leg_its_value_comes_from():
     r = cfg["rccl"]
     assert r["iters_per_sec"] is None and r["two_loop_ms"] is None and r["allreduce_us_mean"] is None
     assert r["status"] == "not run" and cfg["probes"]["rccl"]["status"] != "ok" and "ncclAllReduce" in r["says"]
-    # every leg has its sentence, and only the rccl one may be read as an RCCL number
+    # every leg has its sentence, and only the two rccl ones may be read as RCCL numbers
     for leg, says in bench.LEG_SAYS.items():
-        assert ("NOT RCCL" in says) == (leg not in ("rccl", "none")), leg
+        assert ("NOT RCCL" in says) == (leg not in ("rccl", "rccl-per-step", "none")), leg
 
 
 def test_rccl_beside_reads_the_rccl_leg_whichever_leg_won():

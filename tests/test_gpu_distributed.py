@@ -432,3 +432,73 @@ def test_world_8_on_one_gpu_as_processes_times_threads(tmp_path):
         assert ci["exchange_us_mean"] and ci["resident_fallbacks"] == 0
         assert line["roofline"]["kernel"].startswith("two_loop_resident_kernel")
         assert "NOT RCCL" in line["metric"]
+
+
+@pytest.mark.parametrize("n,m,owl", [(1_300_003, 6, None), (20_000_003, 5, None), (400_001, 6, (0.5, 30_000, 390_000))],
+                         ids=["on_chip", "hybrid", "owlqn"])
+def test_rccl_gated_exchange_under_the_persistent_kernel(n, m, owl, monkeypatch):
+    """RCCL under the persistent two-loop kernel (round 5): ncclAllReduce only exists as a host-enqueued kernel, so the host
+    enqueues one per hand-off on a SECOND stream, each behind a gate kernel that waits for the persistent kernel's flag; the
+    kernel stores its sums into an uncached slot, raises flag A, and reads the reduced sums back once flag B carries the same
+    epoch -- q never leaves the chip (csrc/stream.h ext_exchange, lbfgs_hip.hip enqueue_gated_chain).  One GPU can only host
+    a 1-rank communicator, whose all-reduce is the identity: what is checked here is the whole mechanism -- gates, epochs,
+    the ring of slots, both streams, the mirror, the counters -- on whole optimisations against the ORACLE and against the same
+    communicator with a kernel per step (LBFGS_HIP_RCCL_RESIDENT=0), and that the kernel really ran resident."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs RCCL and the GPU")
+    from oracle import oracle as O
+    from rust_lbfgs_amd import objectives
+    from rust_lbfgs_amd.dist import CommSpec
+
+    L = _ffi.load()
+    _ffi.torch_before_rccl()
+    iters = 14
+
+    def run(resident):
+        monkeypatch.setenv("LBFGS_HIP_RCCL_RESIDENT", "1" if resident else "0")
+        buf = (C.c_char * 128)()
+        assert L.lbfgs_hip_rccl_unique_id(buf) == 0, L.lbfgs_hip_last_error(None)
+        spec = CommSpec(_ffi.COMM_RCCL, unique_id=buf)
+        spec.c.exclusive_device = 1
+        rows = []
+        with R.Context(n, shard=_ffi.Shard(0, 1, n, 0, n), comm=spec) as ctx:
+            b = R.lbfgs().with_m(m).with_epsilon(0.0).with_max_iterations(iters)
+            if owl:
+                b = b.with_orthantwise(*owl)
+            x = np.zeros(n)
+            b.minimize(x, objectives.Logistic() if owl else objectives.Quadratic(),
+                       lambda p: rows.append((p.niter, p.neval, p.ncall, p.fx, p.xnorm, p.gnorm, p.step)) and False, ctx=ctx)
+            ci = ctx.comm_info()
+            stats = dict(resident=ctx.resident_two_loops(), on_chip=ctx.resident_elements(), two_loops=ci["two_loops"],
+                         exchanges=ci["two_loop_exchanges"], timed=ci["timed_exchanges"]["two_loop"],
+                         us=ci["exchange_us"]["two_loop"], ranks_seen=ci["ranks_seen"], fallbacks=ci["resident_fallbacks"])
+        return x, rows, stats
+
+    xg, rg, sg = run(True)
+    xs, rs, ss = run(False)
+    # the gated form really ran: every two-loop with history resident, 2*bound (+1 under OWL-QN) exchanges each, timed on the device
+    assert sg["resident"] == iters - 1 and ss["resident"] == 0 and sg["fallbacks"] == 0 and sg["ranks_seen"] == 1
+    assert (sg["on_chip"] < n) == (n > 12_582_912)
+    assert sg["timed"] == sg["exchanges"] > 2 * (iters - 1 - m) * m and sg["us"] > 0.0
+    # a 1-rank all-reduce is the identity: the gated run is the per-step run up to the two launch forms' summation orders
+    # (the persistent kernel's workgroups own other elements than the streaming kernels' do) ...
+    assert len(rg) == len(rs)
+    for a, b in zip(rg, rs):
+        assert a[:3] == b[:3]
+        for u, v in zip(a[3:], b[3:]):
+            assert abs(u - v) <= 1e-11 * max(abs(u), 1e-6), (a, b)
+    # ... and both are the oracle's run
+    ro, xo = [], np.zeros(n)
+    bo = O.lbfgs().with_m(m).with_epsilon(0.0).with_max_iterations(iters)
+    if owl:
+        bo = bo.with_orthantwise(*owl)
+    bo.minimize(xo, O.logistic() if owl else O.quadratic(),
+                lambda p: ro.append((p["niter"], p["neval"], p["ncall"], p["fx"], p["xnorm"], p["gnorm"], p["step"])) and False)
+    assert len(ro) == len(rg)
+    for a, b in zip(ro, rg):
+        assert a[:3] == b[:3]
+        for u, v in zip(a[3:], b[3:]):
+            assert abs(u - v) <= 1e-9 * max(abs(u), 1e-6), (a, b)
+    assert np.max(np.abs(xg - xo)) <= 1e-9 * max(np.max(np.abs(xo)), 1e-12)
+    print(f"gated RCCL exchange, n={n}: {sg['exchanges']} exchanges in {sg['two_loops']} two-loops, {sg['us'] / sg['timed']:.2f} us each "
+          f"(1-rank communicator: gate + post, no all-reduce kernel), {sg['on_chip']} of {n} elements on the chip")

@@ -1,6 +1,9 @@
 #!/bin/bash
-# Same-box A/B of two builds of the whole tree: tools/bin/r04tree (round 4's HEAD, built in a git worktree and copied there;
-# git-ignored) against the checked-out one.  bench.py of each tree, alternating.   bash tools/build_ab.sh
+# Same-box A/B of two builds of the whole tree: tools/bin/r04tree (round 4's HEAD; git-ignored) against the checked-out one.
+# bench.py of each tree, alternating.   bash tools/build_ab.sh
+# The old tree is made on the CPU box first:
+#   git worktree add /tmp/r04tree 78b8ab8 && (cd /tmp/r04tree && python -c "import sys; sys.path.insert(0, '.'); import rust_lbfgs_amd as R; R.build()")
+#   mkdir -p tools/bin/r04tree/profiles && cp -r /tmp/r04tree/{rust-lbfgs_amd,rust_lbfgs_amd.py,bench.py,include} tools/bin/r04tree/ && git worktree remove /tmp/r04tree --force
 mkdir -p gpurun_out
 out=gpurun_out/build_ab.log
 : > $out

@@ -59,12 +59,16 @@ def main():
         elif a.startswith("--round="):
             rnd = a.split("=", 1)[1]
     one = facts(load(args[0]))
-    shards, per_step = {}, {}
+    shards, per_step, gated = {}, {}, {}
     for a in args[1:]:
         k, p = a.split("=", 1)
         # P<k>= the rank-0 shard of a k-GPU run alone (default launch form: the persistent kernel);
-        # S<k>= the same with LBFGS_HIP_RESIDENT=0 (a kernel per two-loop step: the launch form the RCCL leg takes)
-        (shards if k[0] == "P" else per_step)[int(k[1:])] = facts(load(p))
+        # S<k>= the same under a 1-rank RCCL communicator with a kernel per two-loop step (LBFGS_HIP_RCCL_RESIDENT=0; or
+        #       LBFGS_HIP_RESIDENT=0 without a communicator): the RCCL leg's fallback form;
+        # G<k>= the same under a 1-rank RCCL communicator with the GATED exchange (the RCCL leg's default form: the persistent
+        #       kernel + gate / ncclAllReduce / post on a second stream; a 1-rank all-reduce launches no kernel, so the figure
+        #       contains the machinery and nothing of RCCL's own time)
+        {"P": shards, "S": per_step, "G": gated}[k[0]][int(k[1:])] = facts(load(p))
     m = one["m"]
     lat = [0.0, 2.0, 5.0, 10.0, 20.0, 50.0]
     out = []
@@ -110,8 +114,29 @@ def main():
             cells.append(f"{lcrit:.0f} us (speed-up {target:g})" if lcrit > 0 else "never (below it already alone)")
             out.append(f"| {p} | {nx:.1f} | " + " | ".join(cells) + " |")
         out.append("")
+    if gated:
+        out.append("## Predicted: the RCCL leg, gated exchange (ncclAllReduce on a second stream under the persistent kernel)\n")
+        out.append(f"Exchanges per iteration: {2 * m} (two-loop, gated) + 1 (history update) + trials (line search), the last two closed by an "
+                   "all-reduce behind their kernel.  The one-rank figure already contains the gates, the posts and both kernel boundaries "
+                   "of every exchange; L = what ncclAllReduce ITSELF takes for <= 32 bytes across the ranks.\n")
+        lat_r = [0.0, 10.0, 15.0, 20.0, 30.0, 50.0]
+        out.append("| P | one rank alone, gated machinery included: iters/s | " + " | ".join(f"L = {x:g} us: iters/s (speed-up)" for x in lat_r) +
+                   " | L at which speed-up = 6 (P = 8) / = P/2 |")
+        out.append("|---|---|" + "---|" * (len(lat_r) + 1))
+        for p in sorted(gated):
+            f = gated[p]
+            t0 = f["ms"]
+            if f["eval_ms"] and f["trials"]:
+                t0 += f["eval_ms"] / f["trials"] * (one["trials"] - f["trials"])
+            nx = 2 * m + 1 + one["trials"]
+            cells = [f"{1e3 / (t0 + nx * x * 1e-3):.0f} ({one['ms'] / (t0 + nx * x * 1e-3):.1f}x)" for x in lat_r]
+            target = 6.0 if p == 8 else p / 2.0
+            lcrit = (one["ms"] / target - t0) / nx * 1e3
+            cells.append(f"{lcrit:.0f} us (speed-up {target:g})" if lcrit > 0 else "never (below it already alone)")
+            out.append(f"| {p} | {f['ips']:.0f} | " + " | ".join(cells) + " |")
+        out.append("")
     if per_step:
-        out.append("## Predicted: the RCCL leg (ncclAllReduce per reduction; the two-loop as one kernel per step)\n")
+        out.append("## Predicted: the RCCL leg's fallback form (ncclAllReduce per reduction; the two-loop as one kernel per step)\n")
         out.append(f"Exchanges per iteration: {2 * m + 1} (two-loop: every dot product is closed by an all-reduce launch of its own) + 1 "
                    "(history update) + trials (line search).  L = what one ncclAllReduce of <= 48 bytes adds to the stream "
                    "(`config.rccl.allreduce_us_mean` in a real run).\n")
