@@ -1124,7 +1124,8 @@ def supervisor_main(a):
     else:
         comms = [a.comm]
     passed = []
-    for i, leg in enumerate(comms):
+    comms = list(comms)
+    for i, leg in enumerate(comms):  # (the list may grow: a failed "rccl" probe appends "rccl-per-step")
         t0 = time.monotonic()
         # (the first probe also pays for paging the libraries in; RCCL's first communicator over 8 GPUs takes its time)
         tmo = decided(min(a.probe_timeout * (2.0 if (i == 0 or leg == "rccl") else 1.0), left() - RESERVE))
@@ -1137,6 +1138,10 @@ def supervisor_main(a):
             probes[leg]["mailboxes"] = j["mailboxes"]
         if status == "ok":
             passed.append(leg)
+        elif leg == "rccl" and "rccl-per-step" not in comms:
+            # the gated exchange (the persistent kernel served by ncclAllReduce on a second stream) is what no single GPU can try
+            # with peers: should RCCL itself be fine and only that form fail, its plain form -- a kernel per step -- is probed too
+            comms.append("rccl-per-step")
         if rank == 0:
             print(f"[bench] probe {leg}: {probes[leg]}  ({left():.0f} s of the budget left)", file=sys.stderr)
 
@@ -1185,12 +1190,12 @@ def supervisor_main(a):
                 measure_leg("p2p-per-step", len(others))
         rest = [c for c in todo if c != "p2p"]
         if not sync_have():  # fallback order
-            rest.sort(key=lambda c: {"p2p-host": 0, "rccl": 1}.get(c, 2))
+            rest.sort(key=lambda c: {"p2p-host": 0, "rccl": 1, "rccl-per-step": 1}.get(c, 2))
         else:                # comparisons
-            rest.sort(key=lambda c: {"rccl": 0, "p2p-host": 1}.get(c, 2))
+            rest.sort(key=lambda c: {"rccl": 0, "rccl-per-step": 0, "p2p-host": 1}.get(c, 2))
         for i, leg in enumerate(rest):
             got = measure_leg(leg, len(rest) - 1 - i)
-            if leg == "rccl" and not decided(got):  # the gated form gave nothing: RCCL's plain form, a kernel per step
+            if leg == "rccl" and not decided(got) and "rccl-per-step" not in rest:  # the gated form gave nothing: RCCL's plain form
                 measure_leg("rccl-per-step", len(rest) - 1 - i)
     if not sync_have() and (a.comm == "auto") and "callback" not in report:
         # last resort: the host-staged all-reduce through gloo, only if nothing has produced a result

@@ -310,14 +310,15 @@ def test_bench_supervisor_survives_a_hung_and_a_failed_leg(launcher):
 
 
 def test_bench_supervisor_default_leg_order():
-    """No --comm: the communicators are probed in the order p2p, p2p-host, rccl; the test double has none of them, so no leg
+    """No --comm: the communicators are probed in the order p2p, p2p-host, rccl (+ rccl-per-step when rccl failed); the test double has none of them, so no leg
     is measured and the host-staged callback runs as the last resort -- only because nothing else produced a result."""
     p = _run_bench(["--probe-timeout", "60"], False)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout
     cfg = json.loads(lines[0])["config"]
-    assert list(cfg["probes"]) == ["p2p", "p2p-host", "rccl"]
+    # (a failed rccl probe -- the gated exchange is that leg's default form -- makes the supervisor probe RCCL's plain form too)
+    assert list(cfg["probes"]) == ["p2p", "p2p-host", "rccl", "rccl-per-step"]
     assert all(v["status"] != "ok" for v in cfg["probes"].values())
     assert list(cfg["legs"]) == ["callback"] and cfg["legs"]["callback"]["status"] == "ok"
 
