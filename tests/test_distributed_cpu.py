@@ -398,3 +398,30 @@ def test_bench_supervisor_sigterm_prints_the_best_line_so_far():
     time.sleep(0.5)
     with pytest.raises(ProcessLookupError):
         os.killpg(int(m.group(1)), 0)
+
+
+def test_eight_ranks_as_processes_times_threads_tool_on_the_test_double(tmp_path):
+    """tools/eight_ranks_one_gpu.py -- world 8 as 4 processes x 2 host threads behind a rendezvous made of files, bench.py's own
+    make_context + measure per rank -- dry-run on the CPU test double (callback communicator; the GPU suite runs it with the P2P
+    exchange inside the persistent kernel): the duck-typed process group of rust_lbfgs_amd.dist, eight shards, trajectories
+    equal to the oracle's, one bench line."""
+    out = os.path.join(ROOT, "gpurun_out", "bench_eight_ranks_sharing_one_gpu.json")
+    keep = out + ".kept_by_the_cpu_test"
+    if os.path.exists(out):
+        os.replace(out, keep)
+    try:
+        env = dict(os.environ, LBFGS_TEST_BACKEND="mock", LBFGS_EIGHT_SMALL="1", OMP_NUM_THREADS="1")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "eight_ranks_one_gpu.py"), "--dim", "40003", "--hist", "5", "--steps",
+                            "4", "--repeats", "2", "--legs", "callback"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+        rec = json.load(open(out))
+    finally:
+        if os.path.exists(keep):
+            os.replace(keep, out)
+        elif os.path.exists(out):
+            os.unlink(out)
+    assert rec["ok"] and rec["exit_codes"] == [0, 0, 0, 0]
+    assert len(rec["result"]["trajectories"]) == 3 and all(t["ok"] and t["identical_rows_on_every_rank"] for t in rec["result"]["trajectories"])
+    line = rec["result"]["legs"]["callback"]["line"]
+    assert line["n_gpus"] == 8 and line["value"] > 0 and line["config"]["comm_info"]["world"] == 8
+    assert line["config"]["comm_info"]["exchanges_per_two_loop"] == pytest.approx(12.0)

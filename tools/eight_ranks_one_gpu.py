@@ -39,6 +39,10 @@ CASES = [  # whole runs against the oracle: 24 workgroups keep 1.18e6 elements o
 ]
 
 
+if os.environ.get("LBFGS_EIGHT_SMALL") == "1":  # the CPU suite's dry run of this tool on the test double: the same cases, small
+    CASES = [dict(c, n=c["n"] // 100 + 3, **({"owl": [0.5, 3_000, 29_000]} if c.get("owl") else {})) for c in CASES]
+
+
 class FileGroup:
     """rank / world / all_gather_object / broadcast_object / barrier over a directory: works between threads and processes
     alike.  Every rank calls the collectives in the same order (a sequence number names each one)."""
