@@ -86,10 +86,12 @@ typedef int (*lbfgs_hip_allreduce_cb)(void* user, double* buf, int32_t count);
 
 typedef struct lbfgs_hip_comm {
     int32_t kind;
-    int32_t exclusive_device;    /* P2P: non-zero = this rank has its GPU to itself (one process per GPU, the deployment this
+    int32_t exclusive_device;    /* P2P, RCCL: non-zero = this rank has its GPU to itself (one process per GPU, the deployment this
                                     library is built for).  Only then may a kernel that occupies the WHOLE chip while it waits
                                     for its peers be used (the on-chip-resident two-loop, rust-lbfgs_amd/csrc/resident.h): ranks
-                                    that share a GPU would keep each other from running.  0 = assume the GPU may be shared. */
+                                    that share a GPU would keep each other from running.  0 = assume the GPU may be shared.
+                                    (RCCL: that kernel's all-reduces then run gated on a second stream the context owns;
+                                    lbfgs_hip_ctx_create is collective -- same value, and same LBFGS_HIP_RCCL_RESIDENT, on every rank.) */
     const void* rccl_unique_id;  /* 128 bytes from lbfgs_hip_rccl_unique_id() on rank 0, shared out of band */
     lbfgs_hip_allreduce_cb callback;
     void* callback_user;

@@ -301,7 +301,6 @@ int fill_handoff(lbfgs_hip_ctx* ctx, RedCtl& red, int nred) {
 
 
 // ---- the gated exchange's plumbing (stream.h ext_exchange) ---------------------------------------------------------------
-constexpr size_t EXT_BUF_OFFSET = 256;  // bytes from the start of the uncached block to the ring of exchange slots
 static_assert(P2P_MBOX_WORDS * sizeof(unsigned long long) >= EXT_BUF_OFFSET + (size_t)EXT_SLOTS * EXT_SLOT_DOUBLES * sizeof(double),
               "the gated exchange keeps its flags and slots in one block of the mailbox pool");
 // The two streams of the gated exchange must be served CONCURRENTLY: the gate kernel spins while the persistent kernel runs,

@@ -800,7 +800,7 @@ __global__ __launch_bounds__(64) void ext_post_gate_kernel(const ExtGateArgs a) 
 // epoch c % (2^32 - 1) + 1, never 0.  Every hand-off carries one sum except the last (2, or 4 under OWL-QN).
 int enqueue_gated_chain(lbfgs_hip_ctx* ctx, unsigned long long first_exchange, int handoffs, int last_count) {
     auto epoch_of = [](unsigned long long c) { return (unsigned long long)(c % 0xFFFFFFFFull) + 1ull; };
-    double* const ring = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->ext_block) + 256);
+    double* const ring = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->ext_block) + EXT_BUF_OFFSET);
     ctx->ext_launches += 1;
     ExtGateArgs ga{};
     ga.flags = ctx->ext_block;
@@ -856,6 +856,8 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
         : (int)std::min<uint64_t>((uint64_t)ctx->cu_count, std::max<uint64_t>(64, ((n >> 1) + BLOCK * 8 - 1) / (BLOCK * 8)));
     // (gated: RCCL's kernel and the gates need CUs of their own while this kernel waits -- one per XCD is left free, workgroups
     // being dealt to the XCDs round robin; tools/gated_exchange_probe.hip measured the same round trip with 1, 8 or 16 free)
+    // (leaving ONE free so that rank 0's shard of the metric's 8-GPU run -- 12 500 224 elements = 255 workgroups of 96 rounds -- stays
+    // all on the chip was measured and is no better: 783 us against 755 us for the hybrid launch on 248, profiles/r05_rccl_one_rank.log)
     const int grid_cap = gated ? std::max(1, ctx->cu_count - 8) : ctx->cu_count;
     const int grid = std::min(ctx->resident_grid > 0 ? std::min(ctx->resident_grid, ctx->cu_count) : grid_auto, grid_cap);
     if (grid < 1 || grid > BLOCK || grid > MAX_GRID) return 0;  // (every thread polls one workgroup's granules)
@@ -967,7 +969,7 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
         red.p2p.err = ctx->p2p_err;
         red.p2p.timeout_ticks = ctx->p2p_timeout_ticks;
         red.p2p.ext_flags = ctx->ext_block;
-        red.p2p.ext_buf = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->ext_block) + 256);
+        red.p2p.ext_buf = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->ext_block) + EXT_BUF_OFFSET);
         in_kernel_exchange = true;  // (the totals are final when the kernel ends; the counters below are the P2P form's)
         ctx->p2p_count += 1;
         ctx->two_loop_exchanges += 1;

@@ -74,6 +74,7 @@ struct P2PCtl {
     unsigned long long* ext_flags;            // uncached: [0] = A (kernel -> gate), [1] = B (post -> kernel), [2] = abort
 };
 constexpr int EXT_SLOTS = 64, EXT_SLOT_DOUBLES = 8;  // a ring of exchange buffers: one per exchange of a launch (<= 2*24 + 1)
+constexpr size_t EXT_BUF_OFFSET = 256;               // bytes from the start of the context's uncached block (flags) to that ring
 __device__ __forceinline__ bool p2p_active(const P2PCtl& c) { return c.world > 1 || c.ext_buf != nullptr; }
 
 // Host mirror of the scalar board: when the totals are FINAL (one rank, or closed by the in-kernel exchange)
