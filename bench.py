@@ -546,6 +546,15 @@ def measure(env, ctx, label, vector_free=False, repeats=1):
         try:
             if ok:
                 fresh()
+        except R.LbfgsError as e:
+            print(f"[bench] rank {env.rank}: {label} failed to build its state: {e}", file=sys.stderr)
+            ok = 0.0
+        # Every rank has torn its old state down and built the new one before any rank launches a kernel that waits for its
+        # peers.  One process per GPU does not need this; ranks that share a PROCESS do (tools/eight_ranks_one_gpu.py): hipFree
+        # waits for every stream of its process, the sibling rank's included -- whose kernel may be waiting for this very rank.
+        env.barrier(ctx)
+        try:
+            if ok:
                 for _ in range(prefill + a.warmup):
                     step()
                 if not a.no_prof and rep == 0:
@@ -859,7 +868,7 @@ LEG_SAYS = {
     "rccl": "rccl ncclAllReduce(ncclDouble, ncclSum), one per reduction; inside the two-loop the all-reduces run on a second stream "
             "behind gate kernels while the recursion stays ONE persistent kernel (gated exchange)",
     "rccl-per-step": "rccl ncclAllReduce(ncclDouble, ncclSum) on the compute stream, one per reduction; the two-loop is one kernel per step",
-    "callback": "host-staged all-reduce through torch.distributed/gloo (last resort) -- NOT RCCL",
+    "callback": "host-staged all-reduce through a host callback (torch.distributed/gloo in this program's own legs; last resort) -- NOT RCCL",
     "none": "single GPU: no communicator",
 }
 

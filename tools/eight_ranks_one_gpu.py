@@ -119,6 +119,9 @@ def trajectory(env, case, kind):
     rows, err = [], ""
     try:
         st = b.build(np.zeros(hi - lo), ev, ctx=ctx)
+        # (ranks that share a process: every allocation is over before any kernel waits for a peer -- hipMalloc / hipFree of one
+        # thread can wait for every stream of the process, the sibling rank's included)
+        g.barrier()
         try:
             while not st.is_converged():
                 p = st.propagate()
@@ -126,6 +129,7 @@ def trajectory(env, case, kind):
         except R.LbfgsError as e:
             err = str(e)
         xs = st.download("x")
+        g.barrier()  # (... and nobody frees while a sibling's kernels may still be waiting for this rank)
         st.close()
     except R.LbfgsError as e:
         err, xs = str(e), np.zeros(hi - lo)
