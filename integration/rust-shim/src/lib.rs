@@ -317,7 +317,7 @@ where
 }
 
 fn no_objective() -> ffi::lbfgs_hip_objective {
-    ffi::lbfgs_hip_objective { kind: 0, _pad: 0, seed_a: 0, seed_b: 0, nbr_index: ptr::null(), max_nbr: 0, _pad2: 0, cutoff: 0.0 }
+    ffi::lbfgs_hip_objective { kind: 0, _pad: 0, seed_a: 0, seed_b: 0, nbr_index: ptr::null(), max_nbr: 0, _pad2: 0, cutoff: 0.0, skin: 0.0 }
 }
 
 // ---- the host closure behind the C callback ----------------------------------------------------------

@@ -195,6 +195,39 @@ def test_rust_shim_mirrors_the_abi(libs):
             assert int(m.group(1)) == int(val), name
 
 
+def test_rust_shim_uses_only_what_its_ffi_module_declares():
+    """Second line of defence for the uncompiled shim: every `ffi::NAME` that lib.rs mentions is declared in ffi.rs, and every
+    struct literal `ffi::S { .. }` in lib.rs names exactly the fields of S (rustc rejects a literal with a field missing --
+    round 5 found `skin` missing from the objective's literal by reading)."""
+    ffi = open(RUST_FFI).read()
+    lib = open(os.path.join(os.path.dirname(RUST_FFI), "lib.rs")).read()
+    lib_code = "\n".join(ln for ln in lib.splitlines() if not ln.lstrip().startswith("//"))
+    declared = set(re.findall(r"pub (?:const|fn|struct|type) (\w+)", ffi))
+    used = set(re.findall(r"(?<!std::)\bffi::(\w+)", lib_code))
+    assert used and not (used - declared), sorted(used - declared)
+    rs = _rust_structs()
+    literals = 0
+    for m in re.finditer(r"ffi::(\w+) \{", lib_code):
+        name = m.group(1)
+        if name not in rs or lib_code[:m.start()].rstrip().endswith("->"):  # (a return type in front of a body)
+            continue
+        depth, i = 1, m.end()
+        while depth:  # the literal's closing brace
+            depth += {"{": 1, "}": -1}.get(lib_code[i], 0)
+            i += 1
+        body = lib_code[m.end():i - 1]
+        flat, depth = "", 0
+        for ch in body:  # drop nested braces / parentheses: only this literal's own `field:` tokens remain
+            depth += ch in "{(["
+            if depth == 0:
+                flat += ch
+            depth -= ch in "})]"
+        named = re.findall(r"(?:^|[,{;\s])(\w+)\s*:(?!:)", flat)
+        assert sorted(named) == sorted(f for f, _ in rs[name]), (name, named)
+        literals += 1
+    assert literals >= 3  # the evaluator (twice) and the objective
+
+
 def test_no_kernel_uses_scratch_memory(libs):
     """Every gfx950 kernel of the library keeps its state in registers: a single kernel that spills or indexes a local
     array dynamically gets a private-segment (scratch) allocation, and on MI355X that costs ~12 us of extra dispatch
