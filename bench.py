@@ -873,6 +873,16 @@ LEG_SAYS = {
 }
 
 
+def ran_as(leg, line):
+    """The leg a measurement really took.  "rccl" and "p2p" ASK for the persistent two-loop kernel; the library decides -- e.g.
+    lbfgs_hip_ctx_create's trial of the gated exchange failed on some rank (all ranks then run a kernel per step), or the shard is
+    not eligible -- and the record shows it: roofline.two_loop.resident_kernel."""
+    tl = (line.get("roofline") or {}).get("two_loop") or {}
+    if leg in ("rccl", "p2p") and tl.get("resident_kernel") is False:
+        return leg + "-per-step"
+    return leg
+
+
 def rccl_beside(report, lines):
     """config.rccl: the RCCL leg at the top level of `config` whatever leg `value` comes from -- its iterations/sec, its
     two-loop and what one ncclAllReduce cost (HIP events around the launches), or why there is no such figure."""
@@ -1178,7 +1188,10 @@ def supervisor_main(a):
                                exchanges_per_two_loop=ci.get("exchanges_per_two_loop"),
                                two_loop_ms=((j.get("roofline") or {}).get("two_loop") or {}).get("ms"))
         if j:
-            lines.append((leg, j))
+            ran = ran_as(leg, j)  # (the library may have taken the kernel-per-step form by itself: the line must say what RAN)
+            if ran != leg:
+                report[leg]["ran_as"] = ran
+            lines.append((ran, j))
         if rank == 0:
             print(f"[bench] leg {leg}: {report[leg]}  ({left():.0f} s of the budget left)", file=sys.stderr)
         return j is not None

@@ -91,7 +91,9 @@ typedef struct lbfgs_hip_comm {
                                     for its peers be used (the on-chip-resident two-loop, rust-lbfgs_amd/csrc/resident.h): ranks
                                     that share a GPU would keep each other from running.  0 = assume the GPU may be shared.
                                     (RCCL: that kernel's all-reduces then run gated on a second stream the context owns;
-                                    lbfgs_hip_ctx_create is collective -- same value, and same LBFGS_HIP_RCCL_RESIDENT, on every rank.) */
+                                    lbfgs_hip_ctx_create is collective -- same value, and same LBFGS_HIP_RCCL_RESIDENT, on every rank:
+                                    it tries one such exchange under a chip-wide kernel on this communicator and the ranks agree on
+                                    the outcome; if any rank fails, every rank runs the two-loop with a kernel per step and says so.) */
     const void* rccl_unique_id;  /* 128 bytes from lbfgs_hip_rccl_unique_id() on rank 0, shared out of band */
     lbfgs_hip_allreduce_cb callback;
     void* callback_user;

@@ -321,6 +321,20 @@ __global__ __launch_bounds__(64) void ext_selftest_set_kernel(unsigned long long
     if (threadIdx.x == 0) __hip_atomic_store(flags + 3, magic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// *bad (0 / 1: this rank's outcome) -> the number of ranks that reported 1.  Slot 0 of the ring is the buffer.
+static int ext_agree(lbfgs_hip_ctx* ctx, int* bad) {
+    double* const slot0 = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->ext_block) + EXT_BUF_OFFSET);
+    double v = *bad ? 1.0 : 0.0;
+    HIP_TRY(ctx, hipMemcpy(slot0, &v, sizeof(v), hipMemcpyHostToDevice));
+    const int rc = rccl_allreduce_on(ctx, slot0, 1, ctx->stream);
+    if (rc != LBFGS_HIP_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(&v, slot0, sizeof(v), hipMemcpyDeviceToHost));
+    *bad = (int)v;
+    v = 0.0;
+    HIP_TRY(ctx, hipMemcpy(slot0, &v, sizeof(v), hipMemcpyHostToDevice));
+    return LBFGS_HIP_OK;
+}
 int ext_prepare(lbfgs_hip_ctx* ctx) {
     const bool first_use = !ctx->xstream || !ctx->ext_block;
     if (!ctx->xstream) {
@@ -354,7 +368,15 @@ int ext_prepare(lbfgs_hip_ctx* ctx) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->xstream));
         unsigned long long verdict = 0;
         HIP_TRY(ctx, hipMemcpy(&verdict, ctx->ext_block + 4, sizeof(verdict), hipMemcpyDeviceToHost));
-        if (verdict == 1ull && ctx->nccl) {
+        // Every rank must take the same form -- a rank with a kernel per step and a rank with the gated chain would pair their
+        // all-reduces wrongly -- so the ranks AGREE on each outcome: a sum of 0 / 1 over the communicator, on the compute
+        // stream (which works whatever the second stream does).
+        int bad = verdict == 1ull ? 0 : 1, stage = 1;
+        if (ctx->nccl) {
+            const int rc_a = ext_agree(ctx, &bad);
+            if (rc_a != LBFGS_HIP_OK) return rc_a;
+        }
+        if (bad == 0 && ctx->nccl) {
             // RCCL's first collective on a stream may set things up (channels, buffers) and wait for the device: let it do so
             // NOW, not with a persistent kernel waiting for it.  Collective: every rank of the communicator comes here from
             // lbfgs_hip_ctx_create under the same settings (LBFGS_HIP_RCCL_RESIDENT, exclusive_device).
@@ -364,12 +386,26 @@ int ext_prepare(lbfgs_hip_ctx* ctx) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->xstream));
             HIP_TRY(ctx, hipMemsetAsync(slot0, 0, EXT_SLOT_DOUBLES * sizeof(double), ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            // ... and then the exchange itself, once, under a kernel that fills the chip the way the two-loop will
+            bool ok = false;
+            const int rc_s = ext_selftest_resident(ctx, &ok);
+            if (rc_s != LBFGS_HIP_OK) return rc_s;
+            if (ctx->resident_fault == -1) ok = false;  // (tests)
+            bad = ok ? 0 : 1;
+            stage = 2;
+            const int rc_b = ext_agree(ctx, &bad);
+            if (rc_b != LBFGS_HIP_OK) return rc_b;
         }
-        if (verdict != 1ull) {
+        if (bad != 0) {
             ctx->rccl_resident = 0;
-            fprintf(stderr, "[lbfgs_hip] warning: the compute stream and the second stream of the gated RCCL exchange are not served "
-                            "concurrently on this device (they share a hardware queue: GPU_MAX_HW_QUEUES); the two-loop runs with a "
-                            "kernel per step under RCCL\n");
+            if (stage == 1)
+                fprintf(stderr, "[lbfgs_hip] warning: the compute stream and the second stream of the gated RCCL exchange are not served "
+                                "concurrently on %d of %d ranks (they share a hardware queue: GPU_MAX_HW_QUEUES); the two-loop runs with a "
+                                "kernel per step under RCCL\n", bad, ctx->shard.world);
+            else
+                fprintf(stderr, "[lbfgs_hip] warning: the gated RCCL exchange's self-test (an all-reduce enqueued on the second stream, "
+                                "awaited by a kernel that fills the chip) did not come back right within 1 s on %d of %d ranks; the "
+                                "two-loop runs with a kernel per step under RCCL\n", bad, ctx->shard.world);
             return 1;  // (not an error: the caller takes the kernel-per-step form)
         }
     }

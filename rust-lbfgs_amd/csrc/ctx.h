@@ -142,7 +142,8 @@ struct lbfgs_hip_ctx {
         bool owl = false;
     } last_res;
     unsigned long long resident_fallbacks = 0;  // how often that happened
-    int resident_fault = 0;               // LBFGS_HIP_RESIDENT_FAULT=k (tests): the k-th resident launch of this context loses its last workgroup
+    int resident_fault = 0;               // LBFGS_HIP_RESIDENT_FAULT=k (tests): the k-th resident launch of this context loses its last workgroup;
+                                          // -1: this rank reports the gated exchange's self-test as failed (context.hip ext_prepare)
     bool defer_inner_sums = true;         // LBFGS_HIP_DEFER_SUMS=0: the two-loop's inner dots are reduced by their own kernels (A/B)
     double* dot_parts = nullptr;          // 2 x MAX_GRID: workgroup partials of the two-loop's inner dot products (ping-pong)
     DevCounters* dev_ctr = nullptr;       // device-resident sequence numbers (stream.h); the three fields below shadow them
@@ -202,6 +203,8 @@ LH_INTERNAL int grid_for(const lbfgs_hip_ctx* ctx, int x32 = 27);
 LH_INTERNAL int ext_prepare(lbfgs_hip_ctx* ctx);
 LH_INTERNAL void ext_abort(lbfgs_hip_ctx* ctx);
 LH_INTERNAL int rccl_allreduce_on(lbfgs_hip_ctx* ctx, double* buf, int count, hipStream_t stream);
+// (lbfgs_hip.hip) one exchange of the gated form under a chip-wide kernel, on the context's own communicator; collective
+LH_INTERNAL int ext_selftest_resident(lbfgs_hip_ctx* ctx, bool* ok);
 
 // ---- profiling: one event pair per launch of a timed class --------------------------------
 struct ProfScope {

@@ -827,6 +827,89 @@ int enqueue_gated_chain(lbfgs_hip_ctx* ctx, unsigned long long first_exchange, i
     return LBFGS_HIP_OK;
 }
 
+// The gated exchange PROVEN on this context's own communicator before a two-loop relies on it (lbfgs_hip_ctx_create ->
+// ext_prepare; collective).  What cannot be known without trying: that RCCL's all-reduce kernel is dispatched, finds compute
+// units and reaches its peers while a kernel of one workgroup per CU (the whole LDS each, like the resident two-loop) sits on
+// all but eight CUs waiting for it.  So exactly that runs once: workgroup 0 hands (rank + 1) to ext_exchange, the chain
+// gate -> ncclAllReduce -> post is enqueued on the second stream, and the sum must come back as world*(world+1)/2 within a
+// second.  The other workgroups wait for workgroup 0's word, bounded.  A rank that times out still lets its chain run to the
+// end (the gate has seen its flag), so no peer is left waiting inside RCCL; the ranks then agree on the outcome (ext_prepare).
+__global__ __launch_bounds__(BLOCK) void ext_selftest_resident_kernel(const P2PCtl c, const unsigned int epoch, const double mine) {
+    extern __shared__ char whole_cu[];  // (a CU's LDS: nothing else shares the CU)
+    (void)whole_cu;
+    __shared__ double vals[EXT_SLOT_DOUBLES];
+    unsigned long long* const done = c.ext_flags + 5;
+    if (blockIdx.x != 0) {
+        if (threadIdx.x == 0) {
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (unsigned long long)epoch &&
+                   (unsigned long long)(wall_clock64() - t0) < 2ull * c.timeout_ticks)
+                __builtin_amdgcn_s_sleep(8);
+        }
+        return;
+    }
+    if (threadIdx.x == 0) vals[0] = mine;
+    __syncthreads();
+    ext_exchange(c, epoch, vals, 1);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(c.ext_flags + 6, (unsigned long long)__double_as_longlong(vals[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(done, (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+}  // namespace
+int ext_selftest_resident(lbfgs_hip_ctx* ctx, bool* ok) {
+    *ok = false;
+    constexpr unsigned long long EPOCH = 0x7E57ull;         // (any non-zero epoch: the words are cleared again below)
+    constexpr unsigned long long TICKS = 100000000ull;      // 1 s of the 100 MHz wall clock
+    unsigned long long* const w = ctx->ext_block;           // words: 0 A, 1 B, 2 abort, (3, 4: the stream handshake), 5 done, 6 sum, 7 err
+    double* const ring = reinterpret_cast<double*>(reinterpret_cast<char*>(w) + EXT_BUF_OFFSET);
+    double* const slot = ring + (size_t)(EPOCH % (unsigned long long)EXT_SLOTS) * EXT_SLOT_DOUBLES;
+    P2PCtl c{};
+    c.world = ctx->shard.world;
+    c.rank = ctx->shard.rank;
+    c.err = reinterpret_cast<unsigned int*>(w + 7);
+    c.timeout_ticks = TICKS;
+    c.ext_buf = ring;
+    c.ext_flags = w;
+    const size_t lds_bytes = (size_t)RES_LDS_PAIRS_MAX * BLOCK * sizeof(d2);  // (what the resident two-loop asks for)
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ext_selftest_resident_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    const int grid = std::max(1, ctx->cu_count - 8);  // (two_loop_resident's grid_cap under the gated exchange)
+    hipLaunchKernelGGL(ext_selftest_resident_kernel, dim3(grid), dim3(BLOCK), lds_bytes, ctx->stream, c, (unsigned int)EPOCH,
+                       (double)(ctx->shard.rank + 1));
+    ctx->ext_launches += 1;
+    ExtGateArgs ga{};
+    ga.flags = w;
+    ga.err = c.err;
+    ga.abort_id = ctx->ext_launches;
+    ga.timeout_ticks = 3ull * TICKS;
+    ga.gate_epoch = EPOCH;
+    hipLaunchKernelGGL(ext_post_gate_kernel, dim3(1), dim3(64), 0, ctx->xstream, ga);
+    const int rc = rccl_allreduce_on(ctx, slot, 1, ctx->xstream);
+    ga.post_epoch = EPOCH;
+    ga.gate_epoch = 0;
+    hipLaunchKernelGGL(ext_post_gate_kernel, dim3(1), dim3(64), 0, ctx->xstream, ga);  // (also after a failed enqueue: the kernel is let go)
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->xstream));
+    if (rc != LBFGS_HIP_OK) return rc;
+    unsigned long long seen[3] = {0, 0, 0};
+    HIP_TRY(ctx, hipMemcpy(seen, w + 5, sizeof(seen), hipMemcpyDeviceToHost));
+    double sum = 0.0;
+    memcpy(&sum, &seen[1], sizeof(sum));
+    const double W = (double)ctx->shard.world;
+    *ok = seen[0] == EPOCH && (seen[2] & 0xFFFFFFFFull) == 0ull && sum == 0.5 * W * (W + 1.0);
+    // back to the state the first launch expects: flags, handshake and self-test words and the slot cleared (the abort word stays)
+    HIP_TRY(ctx, hipMemsetAsync(w, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(w + 3, 0, 5 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(slot, 0, EXT_SLOT_DOUBLES * sizeof(double), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LBFGS_HIP_OK;
+}
+namespace {
+
 // -> 1 if the recursion was launched as the resident kernel, 0 if this case is not eligible (caller falls back), < 0 error
 int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
                       int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end, bool owl,

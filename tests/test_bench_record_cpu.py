@@ -169,6 +169,21 @@ def test_rccl_beside_reads_the_rccl_leg_whichever_leg_won():
     assert got["iters_per_sec"] is None and "timed out" in got["status"]
 
 
+def test_a_leg_is_named_by_what_ran_not_by_what_was_asked_for():
+    """"rccl" asks for the gated exchange under the persistent kernel; lbfgs_hip_ctx_create may decide otherwise for every rank
+    (its trial of the exchange failed somewhere) and the run is then RCCL with a kernel per step.  The line must not call that
+    "gated": the supervisor files a measurement under the leg its record shows (roofline.two_loop.resident_kernel)."""
+    gated = {"value": 900.0, "roofline": {"two_loop": {"ms": 0.8, "resident_kernel": True}}, "config": {"comm_info": {}}}
+    fell_back = {"value": 500.0, "roofline": {"two_loop": {"ms": 1.7, "resident_kernel": False}}, "config": {"comm_info": {"ranks_seen": 8}}}
+    assert bench.ran_as("rccl", gated) == "rccl" and bench.ran_as("rccl", fell_back) == "rccl-per-step"
+    assert bench.ran_as("p2p", fell_back) == "p2p-per-step" and bench.ran_as("p2p", gated) == "p2p"
+    for leg in ("p2p-host", "callback", "rccl-per-step", "p2p-per-step"):
+        assert bench.ran_as(leg, fell_back) == leg
+    assert bench.ran_as("rccl", {"value": 1.0, "config": {}}) == "rccl"   # (no record of the launch form: nothing to correct)
+    got = bench.rccl_beside({"rccl": {"status": "ok", "ran_as": "rccl-per-step"}}, [(bench.ran_as("rccl", fell_back), fell_back)])
+    assert got["iters_per_sec"] == 500.0 and got["says"] == bench.LEG_SAYS["rccl-per-step"] and "gated" not in got["says"]
+
+
 def test_world_8_through_the_supervisor_on_the_test_double():
     """The metric's own world through bench.py's N > 1 launch form (plain `python bench.py --gpus 8`: one
     torch.distributed.run child of eight ranks per job) on the CPU test double: eight shards -- seven of 12 500 224 / 1e8-like

@@ -502,3 +502,51 @@ def test_rccl_gated_exchange_under_the_persistent_kernel(n, m, owl, monkeypatch)
     assert np.max(np.abs(xg - xo)) <= 1e-9 * max(np.max(np.abs(xo)), 1e-12)
     print(f"gated RCCL exchange, n={n}: {sg['exchanges']} exchanges in {sg['two_loops']} two-loops, {sg['us'] / sg['timed']:.2f} us each "
           f"(1-rank communicator: gate + post, no all-reduce kernel), {sg['on_chip']} of {n} elements on the chip")
+
+
+def test_rccl_gated_exchange_is_proven_at_context_creation_or_not_used(monkeypatch, capfd):
+    """lbfgs_hip_ctx_create tries the gated exchange once on the context's own communicator -- an all-reduce enqueued on the second
+    stream, awaited by a kernel of one workgroup per CU on all but eight CUs -- and the ranks agree on the outcome (a sum over
+    the communicator): if ANY rank reports a failure, every rank takes the kernel-per-step form and says so.  The failure is
+    injected here (LBFGS_HIP_RESIDENT_FAULT=-1: this rank reports its self-test as failed after running it); the run that follows
+    must be the per-step run of the same communicator, and the context without the fault must run gated."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs RCCL and the GPU")
+    from rust_lbfgs_amd import objectives
+    from rust_lbfgs_amd.dist import CommSpec
+
+    L = _ffi.load()
+    _ffi.torch_before_rccl()
+    n, m, iters = 1_300_003, 6, 10
+
+    def run(fault):
+        if fault:
+            monkeypatch.setenv("LBFGS_HIP_RESIDENT_FAULT", "-1")
+        else:
+            monkeypatch.delenv("LBFGS_HIP_RESIDENT_FAULT", raising=False)
+        monkeypatch.setenv("LBFGS_HIP_RCCL_RESIDENT", "1")
+        buf = (C.c_char * 128)()
+        assert L.lbfgs_hip_rccl_unique_id(buf) == 0, L.lbfgs_hip_last_error(None)
+        spec = CommSpec(_ffi.COMM_RCCL, unique_id=buf)
+        spec.c.exclusive_device = 1
+        rows = []
+        with R.Context(n, shard=_ffi.Shard(0, 1, n, 0, n), comm=spec) as ctx:
+            x = np.zeros(n)
+            R.lbfgs().with_m(m).with_epsilon(0.0).with_max_iterations(iters).minimize(
+                x, objectives.Quadratic(), lambda p: rows.append((p.niter, p.neval, p.fx, p.gnorm)) and False, ctx=ctx)
+            return x, rows, ctx.resident_two_loops(), ctx.comm_info()
+
+    capfd.readouterr()
+    xf, rf, resident_f, cif = run(True)
+    err = capfd.readouterr().err
+    assert "self-test" in err and "1 of 1 ranks" in err and "kernel per step" in err, err
+    assert resident_f == 0 and cif["two_loops"] == iters - 1
+    xg, rg, resident_g, cig = run(False)
+    assert "self-test" not in capfd.readouterr().err
+    assert resident_g == iters - 1 and cig["resident_fallbacks"] == 0
+    assert len(rf) == len(rg) == iters
+    for a, b in zip(rf, rg):
+        assert a[:2] == b[:2]
+        for u, v in zip(a[2:], b[2:]):
+            assert abs(u - v) <= 1e-11 * max(abs(u), 1e-6), (a, b)
+    assert np.max(np.abs(xf - xg)) <= 1e-11 * np.max(np.abs(xg))
