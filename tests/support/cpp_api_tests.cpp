@@ -58,8 +58,8 @@ static void test_lbfgs_rosenbrock() {
 
 static void test_lbfgs_booth() {
     std::vector<double> x = {-1.2, 1.0};
-    auto evaluate = [](const double* x, double* gx, std::size_t) {
-        const double x1 = x[0], x2 = x[1];
+    auto evaluate = [](const double* xs, double* gx, std::size_t) {
+        const double x1 = xs[0], x2 = xs[1];
         const double fx = std::pow(x1 + 2.0 * x2 - 7.0, 2) + std::pow(2.0 * x1 + x2 - 5.0, 2);
         gx[0] = 10.0 * x1 + 8.0 * x2 - 34.0;
         gx[1] = 8.0 * x1 + 10.0 * x2 - 38.0;
