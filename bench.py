@@ -61,12 +61,18 @@ and, so that an N > 1 line can be cross-checked and a scaling shortfall attribut
   roofline.exchange_us_mean, roofline.exchanges_per_two_loop, config.legs[leg].*   one cross-rank exchange inside a
                 two-loop as the device timed it (P2P: the exchanging workgroup's wall clock; RCCL: HIP events around
                 the all-reduce launches) and how many a two-loop made, over the timed regions only;
-  roofline.traffic_build_id / traffic_is_current   which build the committed counter passes behind `traffic` were made
+  roofline.traffic   N = 1: HBM bytes per launch of the dominant kernel taken BY THIS RUN -- after the timed region two child
+                runs of this command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, --kernel-trace
+                only; a second or two each; --no-live-traffic skips them), `traffic_source` says so and `traffic_committed` keeps the
+                figure of the committed passes (profiles/pmc_traffic*.json) beside it.  Without the live passes (N > 1, under
+                a profiler, rocprofv3 missing or failing: `traffic_live_error`) the committed figure is quoted, with
+  roofline.traffic_build_id / traffic_is_current   which build the counter passes behind `traffic` were made
                 with, and whether it is the build measuring now.
 """
 import argparse
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -123,6 +129,9 @@ def parse(argv=None):
     ap.add_argument("--exclusive-device", type=int, default=-1, choices=[-1, 0, 1],
                     help="tell the communicator that every rank owns its GPU (-1: yes unless --device is given); experiments "
                          "with several ranks on ONE GPU pass 1 together with LBFGS_HIP_RESIDENT_GRID = CUs / ranks")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="N = 1: do not re-take roofline.traffic with two rocprofv3 --pmc child runs of this command after the "
+                         "measurement (the committed counter passes of profiles/ are quoted instead)")
     ap.add_argument("--_rank-mode", dest="rank_mode", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--_probe", dest="probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--_cpu-baseline-child", dest="cpu_child", action="store_true", help=argparse.SUPPRESS)
@@ -442,6 +451,93 @@ def traffic_lookup(n_local, m, kernel, build_id=None, profiles_dir=None, residen
                "traffic_source": pm.get("_source"), "traffic_file": os.path.relpath(path, ROOT),
                "traffic_build_id": pm.get("build_id"), "traffic_is_current": bool(cur), "loaded_build_id": build_id}
     return out
+
+
+def live_traffic_wanted(a):
+    """N = 1 only, not inside a profiler (tools/profile_round.sh runs this program under rocprofv3), not in a child of itself."""
+    if a.no_live_traffic or a.no_prof or os.environ.get("LBFGS_BENCH_LIVE_TRAFFIC", "1") == "0":
+        return False
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "RANK" in os.environ or a.gpus > 1:
+        return False
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock" or os.environ.get("LBFGS_BENCH_WORKER"):  # (the CPU test double)
+        return False
+    return not any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+
+
+def live_traffic(a, roof, timeout_s=150.0):
+    """roofline.traffic taken BY this run: two child runs of this very command under `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` (separate passes, --kernel-trace only: /opt/skills/guides/MI355X_MICROARCH.md, HBM section), a few
+    iterations each with the history full, after the timed region and after this process has given its GPU memory back.
+    FETCH_SIZE x2 (gfx950), KiB; averaged over the full-depth launches of the dominant kernel (tools/summarize_profile.py:
+    the same arithmetic as the committed passes).  Counters cannot be read from inside the measuring process, and a profiled
+    run is not a timed run -- hence children.  Any failure leaves the committed look-up in place and says why."""
+    import importlib.util
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return {"traffic_live": None, "traffic_live_error": "rocprofv3 not found"}
+    spec = importlib.util.spec_from_file_location("summarize_profile", os.path.join(ROOT, "tools", "summarize_profile.py"))
+    sp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sp)
+    work = tempfile.mkdtemp(prefix="lbfgs_bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", LBFGS_BENCH_LIVE_TRAFFIC="0")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--dim", str(a.n), "--hist", str(a.m), "--steps", "4", "--warmup",
+             str(max(a.warmup, a.m + 2)), "--repeats", "1", "--line-eval", str(a.line_eval), "--no-cpu-baseline", "--no-prof",
+             "--no-vector-free", "--no-live-traffic"]
+    if a.grid:
+        child += ["--grid", str(a.grid)]
+    got, t0 = {}, time.monotonic()
+    try:
+        for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+            print(f"[bench] roofline.traffic: rocprofv3 --pmc {counter} pass of this command (a child run of a few seconds)", file=sys.stderr)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(work, sub), "--"] + child
+            p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                                 start_new_session=True)
+            try:
+                _, err = p.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)  # (the group this call started: rocprofv3 and the program under it)
+                except OSError:
+                    pass
+                p.communicate()
+                return {"traffic_live": None, "traffic_live_error": f"the {counter} pass did not finish within {timeout_s:.0f} s"}
+            if p.returncode != 0:
+                return {"traffic_live": None, "traffic_live_error": f"the {counter} pass exited with {p.returncode}: {err[-300:]}"}
+            per_kernel = sp.pmc(os.path.join(work, sub), counter)
+            want = "two_loop_resident_kernel<" if "resident" in roof["kernel"] else "OpTwoLoopStep<false, false, 0"
+            keys = [k for k in per_kernel if want in k]
+            if not keys:
+                return {"traffic_live": None, "traffic_live_error": f"no {counter} rows for {roof['kernel']}"}
+            got[counter] = per_kernel[keys[0]]
+            got["kernel"] = keys[0]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    rd, wr = got["FETCH_SIZE"] * 1024 * 2, got["WRITE_SIZE"] * 1024
+    return {"traffic_live": (rd + wr) / 1e9, "traffic_live_read_GB": rd / 1e9, "traffic_live_write_GB": wr / 1e9,
+            "traffic_live_kernel": got["kernel"], "traffic_live_seconds": round(time.monotonic() - t0, 1),
+            "traffic_live_source": "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (--kernel-trace only) in two separate child "
+                                   "runs of `python3 bench.py` at this size (4 timed steps after the warm-up, history full), "
+                                   "averaged over the full-depth dispatches of the kernel; FETCH_SIZE x2 (gfx950 correction of "
+                                   "MI355X_MICROARCH.md section HBM), KiB"}
+
+
+def apply_live_traffic(roof, live):
+    """The live figure becomes roofline.traffic; what the committed passes say stays beside it (traffic_committed*)."""
+    roof.update({k: v for k, v in live.items()})
+    if live.get("traffic_live") is None:
+        return roof
+    if roof.get("traffic") is not None:
+        roof["traffic_committed"] = roof["traffic"]
+        roof["traffic_committed_file"] = roof.get("traffic_file")
+        roof["traffic_committed_build_id"] = roof.get("traffic_build_id")
+    build = roof.get("loaded_build_id") or loaded_build_id()
+    roof.update(traffic=live["traffic_live"], traffic_source=live["traffic_live_source"], traffic_file=None,
+                traffic_unit="GB per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)",
+                traffic_build_id=build, traffic_is_current=True, loaded_build_id=build)
+    return roof
 
 
 COMM_COUNTERS = ("two_loops", "two_loop_exchanges", "allreduce_launches", "p2p_exchanges")
@@ -826,6 +922,11 @@ def worker_main(a):
                                                     "run-time ||d||^2 check and was redone by the exact recursion",
                                   "two_loop_passes": 4 * a.m + 3, "repeats_iters_per_sec": rv["repeats"]}
         ctx.close()
+        if results and results[0]["roofline"].get("achieved") and live_traffic_wanted(a):
+            try:  # (after ctx.close(): the children get the whole GPU)
+                apply_live_traffic(results[0]["roofline"], live_traffic(a, results[0]["roofline"]))
+            except Exception as e:  # noqa: BLE001  (the committed look-up stays)
+                results[0]["roofline"]["traffic_live_error"] = f"{type(e).__name__}: {e}"
 
     out = None
     rc = 0

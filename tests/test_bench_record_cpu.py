@@ -5,6 +5,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -207,3 +208,93 @@ def test_world_8_through_the_supervisor_on_the_test_double():
     assert leg["status"] == "ok" and leg["exchanges_per_two_loop"] == pytest.approx(2 * 5 + 2)
     assert j["config"]["comm_info"]["world"] == 8 and j["config"]["budget"]["used_s"] < 400
     assert j["cpu_baseline"]["value"] > 0 and j["config"]["rccl"]["status"] == "not run"
+
+
+# ---------------------------------------------------------------------------------------------
+# roofline.traffic taken by the run itself: two rocprofv3 --pmc child runs after the timed region (bench.live_traffic)
+# ---------------------------------------------------------------------------------------------
+FAKE_ROCPROF = r'''#!/usr/bin/env python3
+# stands in for rocprofv3 in the CPU suite: checks the command line bench.py builds and lays the committed raw counter rows
+# out the way rocprofv3 does (<-d>/<host>/<pid>_counter_collection.csv)
+import os, shutil, sys, time
+argv = sys.argv[1:]
+mode = os.environ.get("FAKE_ROCPROF_MODE", "ok")
+assert argv[0] == "--pmc" and argv[1] in ("FETCH_SIZE", "WRITE_SIZE"), argv
+assert "--kernel-trace" in argv and "--sys-trace" not in argv and "--hip-trace" not in argv and "-s" not in argv, argv
+out = argv[argv.index("-d") + 1]
+prog = argv[argv.index("--") + 1:]
+assert os.path.basename(prog[0]).startswith("python") and prog[1].endswith("bench.py"), prog   # the program itself follows `--`
+for flag in ("--no-live-traffic", "--no-prof", "--no-cpu-baseline", "--no-vector-free"):
+    assert flag in prog, (flag, prog)
+assert os.environ.get("LBFGS_BENCH_LIVE_TRAFFIC") == "0"
+if mode == "fail":
+    sys.stderr.write("rocprofv3: no agents found\n"); sys.exit(3)
+if mode == "hang":
+    time.sleep(60)
+os.makedirs(os.path.join(out, "box"), exist_ok=True)
+src = os.environ["FAKE_ROCPROF_ROWS_" + argv[1]]
+if mode != "empty":
+    shutil.copy(src, os.path.join(out, "box", "123_counter_collection.csv"))
+'''
+
+
+def _fake_rocprof(tmp_path, monkeypatch, mode="ok"):
+    exe = tmp_path / "bin" / "rocprofv3"
+    exe.parent.mkdir(exist_ok=True)
+    exe.write_text(FAKE_ROCPROF)
+    exe.chmod(0o755)
+    monkeypatch.setenv("PATH", str(exe.parent) + os.pathsep + os.environ["PATH"])
+    monkeypatch.setenv("FAKE_ROCPROF_MODE", mode)
+    monkeypatch.setenv("FAKE_ROCPROF_ROWS_FETCH_SIZE", os.path.join(ROOT, "profiles", "r05_pmc_fetch_counter_collection.csv"))
+    monkeypatch.setenv("FAKE_ROCPROF_ROWS_WRITE_SIZE", os.path.join(ROOT, "profiles", "r05_pmc_write_counter_collection.csv"))
+
+
+def _args(**kw):
+    import argparse
+    base = dict(n=100_000_000, m=10, warmup=12, line_eval=2, grid=0, no_live_traffic=False, no_prof=False, gpus=1)
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+def test_live_traffic_reads_the_counter_rows_of_its_own_child_runs(tmp_path, monkeypatch):
+    """The orchestration without a GPU: the command lines are what /opt/skills/guides prescribe (one counter per pass,
+    --kernel-trace only, the program itself behind `--`), the children cannot recurse, and the figure is the summariser's
+    arithmetic over the rows -- here the committed rows of this build, so the live figure must equal the committed one."""
+    _fake_rocprof(tmp_path, monkeypatch)
+    roof = {"kernel": "two_loop_resident_kernel<ER,NT>", "achieved": 6400.0}
+    roof.update(bench.traffic_lookup(100_000_000, 10, roof["kernel"]))
+    committed = roof["traffic"]
+    live = bench.live_traffic(_args(), roof, timeout_s=30.0)
+    assert live["traffic_live"] == pytest.approx(committed, rel=1e-9) and live["traffic_live_kernel"].startswith("two_loop_resident_kernel<60")
+    assert live["traffic_live_read_GB"] > 40 and live["traffic_live_write_GB"] > 10
+    out = bench.apply_live_traffic(dict(roof), live)
+    assert out["traffic"] == live["traffic_live"] and out["traffic_committed"] == committed
+    assert out["traffic_is_current"] is True and out["traffic_file"] is None and "this run" in out["traffic_source"]
+    assert out["traffic_committed_file"] == "profiles/pmc_traffic.json"
+
+
+@pytest.mark.parametrize("mode,says", [("fail", "exited with 3"), ("empty", "no FETCH_SIZE rows"), ("hang", "did not finish")])
+def test_live_traffic_failures_leave_the_committed_figure_in_place(tmp_path, monkeypatch, mode, says):
+    _fake_rocprof(tmp_path, monkeypatch, mode)
+    roof = {"kernel": "two_loop_resident_kernel<ER,NT>", "achieved": 6400.0}
+    roof.update(bench.traffic_lookup(100_000_000, 10, roof["kernel"]))
+    before = dict(roof)
+    live = bench.live_traffic(_args(), roof, timeout_s=2.0 if mode == "hang" else 30.0)
+    assert live["traffic_live"] is None and says in live["traffic_live_error"]
+    out = bench.apply_live_traffic(dict(roof), live)
+    assert out["traffic"] == before["traffic"] and out["traffic_file"] == before["traffic_file"] and "traffic_committed" not in out
+    assert not [d for d in os.listdir("/tmp") if d.startswith("lbfgs_bench_pmc_") and os.path.getmtime(os.path.join("/tmp", d)) > time.time() - 1.0]
+
+
+def test_live_traffic_is_for_the_plain_single_gpu_run_only(monkeypatch):
+    for k in list(os.environ):
+        if k.startswith(("ROCPROF", "ROCP_")) or k in ("RANK", "WORLD_SIZE", "LBFGS_BENCH_LIVE_TRAFFIC", "LBFGS_TEST_BACKEND", "LBFGS_BENCH_WORKER"):
+            monkeypatch.delenv(k)
+    assert bench.live_traffic_wanted(_args())
+    assert not bench.live_traffic_wanted(_args(no_live_traffic=True)) and not bench.live_traffic_wanted(_args(no_prof=True))
+    assert not bench.live_traffic_wanted(_args(gpus=8))
+    for k, v in (("RANK", "0"), ("WORLD_SIZE", "2"), ("ROCPROFILER_LIBRARY_CTOR", "1"), ("ROCP_TOOL_LIBRARIES", "x"),
+                 ("LBFGS_BENCH_LIVE_TRAFFIC", "0"), ("LBFGS_TEST_BACKEND", "mock"), ("LBFGS_BENCH_WORKER", "x")):
+        monkeypatch.setenv(k, v)
+        assert not bench.live_traffic_wanted(_args()), k
+        monkeypatch.delenv(k)

@@ -22,7 +22,7 @@ export LBFGS_HIP_BUILD_ID=$(python3 -c "import rust_lbfgs_amd as R; from rust_lb
 dim=${DIM:-100000000}
 hist=${HIST:-10}
 if [ "$dim" = 100000000 ] && [ "$hist" = 10 ]; then size=""; else size="--dim $dim --hist $hist --no-cpu-baseline"; fi
-python3 bench.py $size > "$out/bench.json" 2> "$out/bench.err"
+python3 bench.py $size --no-live-traffic > "$out/bench.json" 2> "$out/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py $size --steps ${STEPS:-400} --repeats 1 --warmup 12 --no-cpu-baseline --no-vector-free > "$out/stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- python3 bench.py $size --steps 4 --warmup 12 --no-cpu-baseline --no-prof --no-vector-free > "$out/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- python3 bench.py $size --steps 4 --warmup 12 --no-cpu-baseline --no-prof --no-vector-free > "$out/pmc_write.log" 2>&1
