@@ -68,6 +68,8 @@ and, so that an N > 1 line can be cross-checked and a scaling shortfall attribut
                 a profiler, rocprofv3 missing or failing: `traffic_live_error`) the committed figure is quoted, with
   roofline.traffic_build_id / traffic_is_current   which build the counter passes behind `traffic` were made
                 with, and whether it is the build measuring now.
+  roofline.rocprofv3_avg_ms   N = 1: the dominant kernel's duration as a `rocprofv3 --kernel-trace --stats` child run of this
+                command sees it (full-depth dispatches), beside the HIP-event `avg_ms` (`rocprofv3_over_hip_events`).
 """
 import argparse
 import json
@@ -464,6 +466,79 @@ def live_traffic_wanted(a):
     return not any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
 
 
+def rocprof_child(a, rocprof_args, outdir, steps, timeout_s):
+    """One run of this very command (same size, `steps` timed steps after the warm-up, nothing else) under rocprofv3 with
+    `rocprof_args`, output under `outdir`.  -> None, or what went wrong."""
+    import shutil
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return "rocprofv3 not found"
+    env = dict(os.environ, TMPDIR="/tmp", LBFGS_BENCH_LIVE_TRAFFIC="0")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--dim", str(a.n), "--hist", str(a.m), "--steps", str(steps), "--warmup",
+             str(max(a.warmup, a.m + 2)), "--repeats", "1", "--line-eval", str(a.line_eval), "--no-cpu-baseline", "--no-prof",
+             "--no-vector-free", "--no-live-traffic"]
+    if a.grid:
+        child += ["--grid", str(a.grid)]
+    cmd = [exe] + list(rocprof_args) + ["--output-format", "csv", "-d", outdir, "--"] + child
+    p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        _, err = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)  # (the group this call started: rocprofv3 and the program under it)
+        except OSError:
+            pass
+        p.communicate()
+        return f"did not finish within {timeout_s:.0f} s"
+    if p.returncode != 0:
+        return f"exited with {p.returncode}: {err[-300:]}"
+    return None
+
+
+def _summariser():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("summarize_profile", os.path.join(ROOT, "tools", "summarize_profile.py"))
+    sp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sp)
+    return sp
+
+
+def live_kernel_time(a, roof, steps=40, timeout_s=150.0):
+    """The dominant kernel's duration as rocprofv3 sees it (`--kernel-trace --stats`, a child run of this command: begin to end of
+    the dispatch), beside the HIP-event figure of the timed region (`roofline.avg_ms`: launch to completion on the stream, so it
+    also holds the dispatch gap in front of the kernel) -- the two must agree to a few per cent, and the record shows both."""
+    import shutil
+    import tempfile
+
+    work = tempfile.mkdtemp(prefix="lbfgs_bench_pmc_", dir="/tmp")
+    try:
+        print("[bench] roofline.rocprofv3_avg_ms: rocprofv3 --kernel-trace --stats pass of this command (a child run of a few seconds)",
+              file=sys.stderr)
+        err = rocprof_child(a, ["--kernel-trace", "--stats"], os.path.join(work, "stats"), steps, timeout_s)
+        if err:
+            return {"rocprofv3_avg_ms": None, "rocprofv3_error": "the --kernel-trace --stats pass " + err}
+        durs = _summariser().trace_durations(os.path.join(work, "stats"))
+        want = "two_loop_resident_kernel<" if "resident" in roof["kernel"] else "OpTwoLoopStep<false, false, 0"
+        keys = [k for k in durs if want in k and durs[k]]
+        if not keys:
+            return {"rocprofv3_avg_ms": None, "rocprofv3_error": f"no dispatches of {roof['kernel']} in the kernel trace"}
+        v = durs[keys[0]]
+        ref = sorted(v)[len(v) // 2]  # (most launches are full-depth: the median is one; see tools/summarize_profile.py)
+        full = [x for x in v if abs(x - ref) <= 0.05 * ref]
+        avg_ms = sum(full) / len(full) / 1e3
+        out = {"rocprofv3_avg_ms": avg_ms, "rocprofv3_launches": len(full), "rocprofv3_kernel": keys[0],
+               "rocprofv3_says": "average duration of the kernel's full-depth dispatches in a `rocprofv3 --kernel-trace --stats` child "
+                                 f"run of this command ({steps} steps after the warm-up)"}
+        if roof.get("avg_ms") and roof.get("bytes_per_launch"):
+            out["rocprofv3_over_hip_events"] = avg_ms / roof["avg_ms"]
+            out["frac_on_rocprofv3_time"] = roof["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        return out
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def live_traffic(a, roof, timeout_s=150.0):
     """roofline.traffic taken BY this run: two child runs of this very command under `rocprofv3 --pmc FETCH_SIZE` and
     `--pmc WRITE_SIZE` (separate passes, --kernel-trace only: /opt/skills/guides/MI355X_MICROARCH.md, HBM section), a few
@@ -471,41 +546,18 @@ def live_traffic(a, roof, timeout_s=150.0):
     FETCH_SIZE x2 (gfx950), KiB; averaged over the full-depth launches of the dominant kernel (tools/summarize_profile.py:
     the same arithmetic as the committed passes).  Counters cannot be read from inside the measuring process, and a profiled
     run is not a timed run -- hence children.  Any failure leaves the committed look-up in place and says why."""
-    import importlib.util
     import shutil
     import tempfile
 
-    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if exe is None:
-        return {"traffic_live": None, "traffic_live_error": "rocprofv3 not found"}
-    spec = importlib.util.spec_from_file_location("summarize_profile", os.path.join(ROOT, "tools", "summarize_profile.py"))
-    sp = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(sp)
+    sp = _summariser()
     work = tempfile.mkdtemp(prefix="lbfgs_bench_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp", LBFGS_BENCH_LIVE_TRAFFIC="0")
-    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--dim", str(a.n), "--hist", str(a.m), "--steps", "4", "--warmup",
-             str(max(a.warmup, a.m + 2)), "--repeats", "1", "--line-eval", str(a.line_eval), "--no-cpu-baseline", "--no-prof",
-             "--no-vector-free", "--no-live-traffic"]
-    if a.grid:
-        child += ["--grid", str(a.grid)]
     got, t0 = {}, time.monotonic()
     try:
         for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
             print(f"[bench] roofline.traffic: rocprofv3 --pmc {counter} pass of this command (a child run of a few seconds)", file=sys.stderr)
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(work, sub), "--"] + child
-            p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
-                                 start_new_session=True)
-            try:
-                _, err = p.communicate(timeout=timeout_s)
-            except subprocess.TimeoutExpired:
-                try:
-                    os.killpg(p.pid, signal.SIGKILL)  # (the group this call started: rocprofv3 and the program under it)
-                except OSError:
-                    pass
-                p.communicate()
-                return {"traffic_live": None, "traffic_live_error": f"the {counter} pass did not finish within {timeout_s:.0f} s"}
-            if p.returncode != 0:
-                return {"traffic_live": None, "traffic_live_error": f"the {counter} pass exited with {p.returncode}: {err[-300:]}"}
+            err = rocprof_child(a, ["--pmc", counter, "--kernel-trace"], os.path.join(work, sub), 4, timeout_s)
+            if err:
+                return {"traffic_live": None, "traffic_live_error": f"the {counter} pass " + err}
             per_kernel = sp.pmc(os.path.join(work, sub), counter)
             want = "two_loop_resident_kernel<" if "resident" in roof["kernel"] else "OpTwoLoopStep<false, false, 0"
             keys = [k for k in per_kernel if want in k]
@@ -927,6 +979,10 @@ def worker_main(a):
                 apply_live_traffic(results[0]["roofline"], live_traffic(a, results[0]["roofline"]))
             except Exception as e:  # noqa: BLE001  (the committed look-up stays)
                 results[0]["roofline"]["traffic_live_error"] = f"{type(e).__name__}: {e}"
+            try:
+                results[0]["roofline"].update(live_kernel_time(a, results[0]["roofline"]))
+            except Exception as e:  # noqa: BLE001
+                results[0]["roofline"]["rocprofv3_error"] = f"{type(e).__name__}: {e}"
 
     out = None
     rc = 0

@@ -219,7 +219,11 @@ FAKE_ROCPROF = r'''#!/usr/bin/env python3
 import os, shutil, sys, time
 argv = sys.argv[1:]
 mode = os.environ.get("FAKE_ROCPROF_MODE", "ok")
-assert argv[0] == "--pmc" and argv[1] in ("FETCH_SIZE", "WRITE_SIZE"), argv
+stats = "--stats" in argv
+if stats:
+    assert "--pmc" not in argv, argv            # counters and statistics never share a pass
+else:
+    assert argv[0] == "--pmc" and argv[1] in ("FETCH_SIZE", "WRITE_SIZE"), argv
 assert "--kernel-trace" in argv and "--sys-trace" not in argv and "--hip-trace" not in argv and "-s" not in argv, argv
 out = argv[argv.index("-d") + 1]
 prog = argv[argv.index("--") + 1:]
@@ -232,6 +236,18 @@ if mode == "fail":
 if mode == "hang":
     time.sleep(60)
 os.makedirs(os.path.join(out, "box"), exist_ok=True)
+if stats:
+    k = "void lh::two_loop_resident_kernel<60, true, true>(lh::ResArgs, lh::RedCtl)"
+    rows = ["Kernel_Name,Start_Timestamp,End_Timestamp"]
+    t = 1000
+    for i in range(40):   # the first m launches of a run are shallower (history not yet full): they must not count
+        d = 9_200_000 + 1000 * (i % 3) if i >= 10 else 850_000 * (i + 1)
+        rows.append(f'"{k}",{t},{t + d}')
+        t += d + 2_000_000
+    rows.append('"void lh::stream_kernel<lh::OpCopy<false>, 1, 256u, 2u, 0, 1>(lh::Args)",1,5001')
+    if mode != "empty":
+        open(os.path.join(out, "box", "123_kernel_trace.csv"), "w").write("\n".join(rows) + "\n")
+    sys.exit(0)
 src = os.environ["FAKE_ROCPROF_ROWS_" + argv[1]]
 if mode != "empty":
     shutil.copy(src, os.path.join(out, "box", "123_counter_collection.csv"))
@@ -298,3 +314,20 @@ def test_live_traffic_is_for_the_plain_single_gpu_run_only(monkeypatch):
         monkeypatch.setenv(k, v)
         assert not bench.live_traffic_wanted(_args()), k
         monkeypatch.delenv(k)
+
+
+def test_live_kernel_time_prices_the_full_depth_dispatches(tmp_path, monkeypatch):
+    """roofline.rocprofv3_avg_ms: a `--kernel-trace --stats` child run of the same command, the full-depth dispatches only (the
+    first m two-loops of a run are shallower), beside the HIP-event figure; no counters in that pass."""
+    _fake_rocprof(tmp_path, monkeypatch)
+    roof = {"kernel": "two_loop_resident_kernel<ER,NT>", "avg_ms": 9.3, "bytes_per_launch": 59972483072}
+    got = bench.live_kernel_time(_args(), roof, timeout_s=30.0)
+    assert got["rocprofv3_launches"] == 30 and got["rocprofv3_avg_ms"] == pytest.approx(9.201, abs=2e-3)
+    assert got["rocprofv3_over_hip_events"] == pytest.approx(9.201 / 9.3, abs=1e-3)
+    assert got["frac_on_rocprofv3_time"] == pytest.approx(59.972483072 / 9.201e-3 / 8000.0, rel=1e-3)
+    monkeypatch.setenv("FAKE_ROCPROF_MODE", "empty")
+    got = bench.live_kernel_time(_args(), roof, timeout_s=30.0)
+    assert got["rocprofv3_avg_ms"] is None and "no dispatches" in got["rocprofv3_error"]
+    monkeypatch.setenv("FAKE_ROCPROF_MODE", "fail")
+    got = bench.live_kernel_time(_args(), roof, timeout_s=30.0)
+    assert got["rocprofv3_avg_ms"] is None and "exited with 3" in got["rocprofv3_error"]
