@@ -14,7 +14,11 @@ the n-vector is sharded contiguously over the ranks (total work fixed => "strong
 reduction is closed by an all-reduce of its f64 scalars.
 
 Process structure.  N = 1 runs in this process (its CPU baseline runs BESIDE the GPU work, in a child pinned to one
-core).  N > 1 never measures in the process the user (or torch.distributed.run) started: that process is a SUPERVISOR
+core).  Its line EXISTS from the moment the timed measurement returns; everything that follows -- the vector-free extension,
+three rocprofv3 child runs (each <= --rocprof-timeout, 60 s; skipped when less than that is left), the wait for the baseline
+child -- runs inside ONE budget (--post-budget, 300 s, and never past --total-budget from the start of the process), and
+SIGTERM / SIGINT end the running child and print the line measured so far; `config.budget.cut`, `cpu_baseline.sample` and
+`roofline.traffic_live_error` / `rocprofv3_error` say what a line lacks and why.  N > 1 never measures in the process the user (or torch.distributed.run) started: that process is a SUPERVISOR
 that touches no GPU and runs fresh child jobs, each under a wall-clock timeout and all of them inside ONE total budget
 (--total-budget, default 520 s: the driver allows 600):
   * `python bench.py --gpus N` (no RANK in the environment): per job one
@@ -119,7 +123,15 @@ def parse(argv=None):
     ap.add_argument("--leg-timeout", type=float, default=150.0,
                     help="N>1: upper bound on one measurement job (s); the actual bound is its share of what is left of --total-budget")
     ap.add_argument("--total-budget", type=float, default=520.0,
-                    help="N>1: wall-clock budget of the whole run (s): probes and legs get their timeouts from what is left of it")
+                    help="wall-clock budget of the whole run (s; the driver allows 600).  N>1: probes and legs get their timeouts from "
+                         "what is left of it.  N=1: nothing that FOLLOWS the measurement (counter passes, waiting for the CPU baseline) "
+                         "may run past it")
+    ap.add_argument("--post-budget", type=float, default=300.0,
+                    help="N=1: wall-clock budget (s) of everything that follows the timed measurement -- the vector-free extension, the "
+                         "rocprofv3 child runs, the wait for the CPU baseline child: ONE budget; a pass is skipped when less than its "
+                         "timeout is left, and the line is printed when it is spent")
+    ap.add_argument("--rocprof-timeout", type=float, default=60.0,
+                    help="N=1: bound on ONE rocprofv3 child run (s; they take a few seconds)")
     ap.add_argument("--probe-timeout", type=float, default=30.0,
                     help="N>1: bound on one communicator probe (s); the first probe and rccl's get twice that (the box's cold start; RCCL's first communicator)")
     ap.add_argument("--no-vector-free", action="store_true",
@@ -251,11 +263,17 @@ def start_cpu_baseline(a):
     if a.no_cpu_full:
         args.append("--no-cpu-full")
     env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    if os.environ.get("LBFGS_BENCH_TEST_CPU_CHILD") == "hang":  # test hook: a baseline child that never returns
+        args = [sys.executable, "-c", "import time; time.sleep(100000)"]
     try:
         return subprocess.Popen(args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     except OSError as e:
         print(f"[bench] cpu baseline child not started: {e}", file=sys.stderr)
         return None
+
+
+def cpu_baseline_missing(why):
+    return {"value": None, "unit": "iters/sec", "cores": 1, "kind": "port", "sample": why}
 
 
 def collect_cpu_baseline(child, a, timeout=420.0):
@@ -266,10 +284,15 @@ def collect_cpu_baseline(child, a, timeout=420.0):
         j = last_json(out)
         if j is not None and "value" in j:
             return j
-        return {"value": None, "unit": "iters/sec", "cores": 1, "kind": "port", "sample": f"the baseline child printed no result (exit code {child.returncode})"}
+        return cpu_baseline_missing(f"the baseline child printed no result (exit code {child.returncode})")
     except subprocess.TimeoutExpired:
         child.kill()
-        return {"value": None, "unit": "iters/sec", "cores": 1, "kind": "port", "sample": f"the baseline child did not finish within {timeout:.0f} s"}
+        try:
+            child.communicate(timeout=5)
+        except Exception:  # noqa: BLE001
+            pass
+        return cpu_baseline_missing(f"cut: the baseline child (the oracle on one pinned core, ~60 s at the metric's size) had not finished "
+                                    f"when the run's budget ended (waited {timeout:.0f} s more after the GPU work)")
 
 
 # ======================================================================================== one rank
@@ -459,6 +482,8 @@ def live_traffic_wanted(a):
     """N = 1 only, not inside a profiler (tools/profile_round.sh runs this program under rocprofv3), not in a child of itself."""
     if a.no_live_traffic or a.no_prof or os.environ.get("LBFGS_BENCH_LIVE_TRAFFIC", "1") == "0":
         return False
+    if os.environ.get("LBFGS_BENCH_LIVE_TRAFFIC") == "force":  # (the CPU suite: the orchestration on the test double)
+        return True
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "RANK" in os.environ or a.gpus > 1:
         return False
     if os.environ.get("LBFGS_TEST_BACKEND") == "mock" or os.environ.get("LBFGS_BENCH_WORKER"):  # (the CPU test double)
@@ -482,6 +507,7 @@ def rocprof_child(a, rocprof_args, outdir, steps, timeout_s):
         child += ["--grid", str(a.grid)]
     cmd = [exe] + list(rocprof_args) + ["--output-format", "csv", "-d", outdir, "--"] + child
     p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    Job.proc = p  # (a signal handler ends it with its whole group)
     try:
         _, err = p.communicate(timeout=timeout_s)
     except subprocess.TimeoutExpired:
@@ -491,6 +517,8 @@ def rocprof_child(a, rocprof_args, outdir, steps, timeout_s):
             pass
         p.communicate()
         return f"did not finish within {timeout_s:.0f} s"
+    finally:
+        Job.proc = None
     if p.returncode != 0:
         return f"exited with {p.returncode}: {err[-300:]}"
     return None
@@ -505,13 +533,24 @@ def _summariser():
     return sp
 
 
-def live_kernel_time(a, roof, steps=40, timeout_s=150.0):
+def budget_says(left, timeout_s):
+    """-> None if a child run bounded by `timeout_s` still fits into what is left of the run's budget, else the sentence the record carries"""
+    if left is None or left() >= timeout_s:
+        return None
+    return (f"skipped: {max(left(), 0.0):.0f} s of the run's budget left, a pass is bounded by {timeout_s:.0f} s "
+            f"(--post-budget / --total-budget / --rocprof-timeout)")
+
+
+def live_kernel_time(a, roof, steps=40, timeout_s=60.0, left=None):
     """The dominant kernel's duration as rocprofv3 sees it (`--kernel-trace --stats`, a child run of this command: begin to end of
     the dispatch), beside the HIP-event figure of the timed region (`roofline.avg_ms`: launch to completion on the stream, so it
     also holds the dispatch gap in front of the kernel) -- the two must agree to a few per cent, and the record shows both."""
     import shutil
     import tempfile
 
+    cut = budget_says(left, timeout_s)
+    if cut:
+        return {"rocprofv3_avg_ms": None, "rocprofv3_error": "the --kernel-trace --stats pass " + cut}
     work = tempfile.mkdtemp(prefix="lbfgs_bench_pmc_", dir="/tmp")
     try:
         print("[bench] roofline.rocprofv3_avg_ms: rocprofv3 --kernel-trace --stats pass of this command (a child run of a few seconds)",
@@ -539,7 +578,7 @@ def live_kernel_time(a, roof, steps=40, timeout_s=150.0):
         shutil.rmtree(work, ignore_errors=True)
 
 
-def live_traffic(a, roof, timeout_s=150.0):
+def live_traffic(a, roof, timeout_s=60.0, left=None):
     """roofline.traffic taken BY this run: two child runs of this very command under `rocprofv3 --pmc FETCH_SIZE` and
     `--pmc WRITE_SIZE` (separate passes, --kernel-trace only: /opt/skills/guides/MI355X_MICROARCH.md, HBM section), a few
     iterations each with the history full, after the timed region and after this process has given its GPU memory back.
@@ -554,6 +593,9 @@ def live_traffic(a, roof, timeout_s=150.0):
     got, t0 = {}, time.monotonic()
     try:
         for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+            cut = budget_says(left, timeout_s)
+            if cut:
+                return {"traffic_live": None, "traffic_live_error": f"the {counter} pass " + cut}
             print(f"[bench] roofline.traffic: rocprofv3 --pmc {counter} pass of this command (a child run of a few seconds)", file=sys.stderr)
             err = rocprof_child(a, ["--pmc", counter, "--kernel-trace"], os.path.join(work, sub), 4, timeout_s)
             if err:
@@ -918,6 +960,7 @@ def worker_main(a):
     """One rank: measures ONE communicator (N = 1: none) and, on rank 0, prints the line.  --_probe: only the context and
     its start-up self-test (a supervisor's phase 1)."""
     # stdout carries exactly ONE JSON line: RCCL, gloo and friends print banners to fd 1, so park it on stderr
+    t_start = time.monotonic()
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
@@ -931,6 +974,58 @@ def worker_main(a):
     cpu_child = None
     if world_env <= 1 and not a.no_cpu_baseline and not a.probe and "RANK" not in os.environ:
         cpu_child = start_cpu_baseline(a)
+    # N = 1 is the only line a one-GPU box ever gives: it exists from the moment measure() returns (`hold["line"]`), everything
+    # after that only ADDS to it inside one budget, and a SIGTERM / SIGINT prints the best line so far (as the N > 1 supervisor does)
+    single = world_env <= 1 and "RANK" not in os.environ and not a.probe
+    hold = {"line": None, "cpu_child": cpu_child, "done": False, "t_post": None, "cuts": []}
+
+    def left():
+        """seconds left for what FOLLOWS the measurement: of --post-budget (from the end of the timed measurement) and of
+        --total-budget (from the start of the process), less a reserve for composing and printing the line"""
+        post = a.post_budget - (time.monotonic() - hold["t_post"]) if hold["t_post"] is not None else a.post_budget
+        return min(post, a.total_budget - (time.monotonic() - t_start)) - 3.0
+
+    def emit(line, signum=None):
+        if hold["done"] or line is None:
+            return False
+        hold["done"] = True
+        line["config"]["budget"] = {"post_s": a.post_budget, "total_s": a.total_budget, "used_s": round(time.monotonic() - t_start, 1),
+                                    "cut": list(hold["cuts"])}
+        if signum is not None:
+            line["config"]["interrupted_by_signal"] = int(signum)
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        return True
+
+    def on_signal(signum, _frame):
+        if hold["done"]:
+            return
+        if Job.proc is not None:  # a rocprofv3 child run: end it with its group
+            kill_group(Job.proc)
+        line = hold["line"]
+        print(f"[bench] signal {signum}: stopping; {'printing the line measured so far' if line else 'nothing measured yet'}", file=sys.stderr)
+        if line is not None and not a.no_cpu_baseline and line.get("cpu_baseline", {}).get("value") is None:
+            try:  # (only if it has finished: no time to wait now)
+                cb = collect_cpu_baseline(hold["cpu_child"], a, timeout=0.5) if hold["cpu_child"] is not None else None
+                hold["cpu_child"] = None
+                if cb is not None:
+                    if cb.get("value") is None:
+                        cb["sample"] = f"cut by signal {signum}: " + cb["sample"]
+                    line["cpu_baseline"] = cb
+            except Exception:  # noqa: BLE001  (e.g. the signal arrived inside the main flow's own communicate())
+                pass
+        hold["cuts"].append(f"signal {signum}")
+        ok = emit(line, signum)
+        if hold["cpu_child"] is not None:
+            try:
+                hold["cpu_child"].kill()
+            except OSError:
+                pass
+        os._exit(0 if ok else 1)
+
+    if single:
+        signal.signal(signal.SIGTERM, on_signal)
+        signal.signal(signal.SIGINT, on_signal)
+
     env = Env(a, comm)
     a.gpus = env.world
 
@@ -948,9 +1043,25 @@ def worker_main(a):
             os.write(real_stdout, (json.dumps({"probe": "ok", "comm": label, "mailboxes": placement,
                                                "seconds": round(time.perf_counter() - t_ctx, 2)}) + "\n").encode())
         return 0 if ctx is not None else 4
+
+    def recompose():
+        """the contract line from everything measured so far (rank 0)"""
+        if env.rank != 0 or not results:
+            return
+        out = compose(a, env.world, results, ext)
+        if results[0].get("mailboxes"):
+            out["config"]["p2p_mailboxes"] = results[0]["mailboxes"]
+        if env.world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = (hold["line"] or {}).get("cpu_baseline") or cpu_baseline_missing(
+                "not collected yet: the baseline child runs beside the GPU work and is collected last")
+        hold["line"] = out
+
     if ctx is not None:
         r = measure(env, ctx, label, repeats=a.repeats)
+        hold["t_post"] = time.monotonic()
         if r is not None:
+            results.append(r)
+            recompose()  # the line exists from here on
             if r["roofline"].get("achieved"):
                 try:  # both denominators: the spec peak (frac) and what a plain copy achieves on this box
                     cal = calibrate(ctx)
@@ -961,8 +1072,10 @@ def worker_main(a):
                     print(f"[bench] calibration skipped: {e}", file=sys.stderr)
             if getattr(ctx, "p2p_placement", None):
                 r["mailboxes"] = ctx.p2p_placement
-            results.append(r)
-            if not a.no_vector_free and a.m <= 10:
+            recompose()
+            if not a.no_vector_free and a.m <= 10 and single and left() < 90.0:
+                hold["cuts"].append("vector-free extension not measured: budget")
+            elif not a.no_vector_free and a.m <= 10:
                 # EXTENSION, reported beside the headline, never as `value`: the same iteration with the
                 # two-loop carried out in Gram-coefficient space (4m+3 passes, 2 all-reduces)
                 rv = measure(env, ctx, label + "+vector_free", vector_free=True, repeats=3 if a.repeats <= 0 else min(a.repeats, 3))
@@ -973,35 +1086,41 @@ def worker_main(a):
                                   "fallbacks_note": "iterations (warm-up included) whose coefficient-space direction failed its "
                                                     "run-time ||d||^2 check and was redone by the exact recursion",
                                   "two_loop_passes": 4 * a.m + 3, "repeats_iters_per_sec": rv["repeats"]}
+                    recompose()
         ctx.close()
         if results and results[0]["roofline"].get("achieved") and live_traffic_wanted(a):
+            roof = results[0]["roofline"]
             try:  # (after ctx.close(): the children get the whole GPU)
-                apply_live_traffic(results[0]["roofline"], live_traffic(a, results[0]["roofline"]))
+                apply_live_traffic(roof, live_traffic(a, roof, timeout_s=a.rocprof_timeout, left=left))
             except Exception as e:  # noqa: BLE001  (the committed look-up stays)
-                results[0]["roofline"]["traffic_live_error"] = f"{type(e).__name__}: {e}"
+                roof["traffic_live_error"] = f"{type(e).__name__}: {e}"
+            recompose()
             try:
-                results[0]["roofline"].update(live_kernel_time(a, results[0]["roofline"]))
+                roof.update(live_kernel_time(a, roof, timeout_s=a.rocprof_timeout, left=left))
             except Exception as e:  # noqa: BLE001
-                results[0]["roofline"]["rocprofv3_error"] = f"{type(e).__name__}: {e}"
+                roof["rocprofv3_error"] = f"{type(e).__name__}: {e}"
+            for k in ("traffic_live_error", "rocprofv3_error"):
+                if roof.get(k):
+                    hold["cuts"].append(f"{k}: {roof[k]}")
+            recompose()
 
-    out = None
     rc = 0
     if env.rank == 0:
         if not results:
             print("bench.py: the communicator produced no result", file=sys.stderr)
             rc = 3
-        else:
-            out = compose(a, env.world, results, ext)
-            if results[0].get("mailboxes"):
-                out["config"]["p2p_mailboxes"] = results[0]["mailboxes"]
-            if env.world == 1 and not a.no_cpu_baseline:
-                out["cpu_baseline"] = collect_cpu_baseline(cpu_child, a)
-                cpu_child = None
-    if cpu_child is not None:
-        cpu_child.kill()
+        elif env.world == 1 and not a.no_cpu_baseline:
+            # (the Popen stays in `hold` while communicate() waits: a signal that arrives meanwhile must still find the child)
+            cb = collect_cpu_baseline(hold["cpu_child"], a, timeout=max(0.5, left()) if single else 420.0)
+            hold["cpu_child"] = None
+            if cb.get("value") is None:
+                hold["cuts"].append("cpu_baseline: " + cb["sample"])
+            hold["line"]["cpu_baseline"] = cb
+    if hold["cpu_child"] is not None:
+        hold["cpu_child"].kill()
+        hold["cpu_child"] = None
     env.finish()
-    if out is not None:
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    emit(hold["line"])
     return rc
 
 

@@ -331,3 +331,107 @@ def test_live_kernel_time_prices_the_full_depth_dispatches(tmp_path, monkeypatch
     monkeypatch.setenv("FAKE_ROCPROF_MODE", "fail")
     got = bench.live_kernel_time(_args(), roof, timeout_s=30.0)
     assert got["rocprofv3_avg_ms"] is None and "exited with 3" in got["rocprofv3_error"]
+
+
+# ---------------------------------------------------------------------------------------------
+# N = 1: the line exists as soon as the measurement returns; what follows runs inside ONE budget; a signal prints the line so far
+# (round-5 verdict, weak #4: the only JSON line used to be written after up to 3 x 150 s of rocprofv3 child runs and a 420 s wait)
+# ---------------------------------------------------------------------------------------------
+def _n1_on_the_test_double(tmp_path, mode, extra_env=None, extra_args=()):
+    exe = tmp_path / "bin" / "rocprofv3"
+    exe.parent.mkdir(exist_ok=True)
+    exe.write_text(FAKE_ROCPROF)
+    exe.chmod(0o755)
+    env = dict(os.environ, OMP_NUM_THREADS="1", LBFGS_BENCH_LIVE_TRAFFIC="force", FAKE_ROCPROF_MODE=mode, LBFGS_MOCK_FAKE_KERNEL_TIMES="1",
+               PATH=str(exe.parent) + os.pathsep + os.environ["PATH"],
+               FAKE_ROCPROF_ROWS_FETCH_SIZE=os.path.join(ROOT, "profiles", "r05_pmc_fetch_counter_collection.csv"),
+               FAKE_ROCPROF_ROWS_WRITE_SIZE=os.path.join(ROOT, "profiles", "r05_pmc_write_counter_collection.csv"))
+    for k in list(env):
+        if k.startswith(("ROCPROF", "ROCP_")) or k in ("RANK", "WORLD_SIZE"):
+            del env[k]
+    env.update(extra_env or {})
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "support", "bench_on_mock.py"), "--steps", "4", "--warmup", "12", "--dim", "3000",
+           "--hist", "5", "--repeats", "2", "--cpu-n", "3000", "--no-vector-free"] + list(extra_args)
+    return subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def _one_line(out):
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_n1_line_appears_within_budget_when_every_rocprofv3_child_hangs(tmp_path):
+    """Three stand-in rocprofv3 runs that never return, each bounded by --rocprof-timeout, all of them inside --post-budget: the
+    third is not even started once less than its timeout is left, and the line says what was cut."""
+    t0 = time.monotonic()
+    p = _n1_on_the_test_double(tmp_path, "hang", extra_args=["--post-budget", "9", "--rocprof-timeout", "3"])
+    out, err = p.communicate(timeout=120)
+    took = time.monotonic() - t0
+    assert p.returncode == 0, err[-3000:]
+    j = _one_line(out)
+    assert j["value"] > 0 and j["cpu_baseline"]["value"] > 0
+    roof = j["roofline"]
+    assert "did not finish within 3 s" in roof["traffic_live_error"] and roof.get("traffic_live") is None
+    assert "did not finish within 3 s" in roof["rocprofv3_error"] or "skipped" in roof["rocprofv3_error"]
+    cut = j["config"]["budget"]["cut"]
+    assert any(c.startswith("traffic_live_error") for c in cut) and any(c.startswith("rocprofv3_error") for c in cut)
+    assert j["config"]["budget"]["used_s"] < 9 + 10 and took < 60
+
+
+def test_n1_a_pass_is_skipped_when_less_than_its_timeout_is_left(tmp_path):
+    p = _n1_on_the_test_double(tmp_path, "ok", extra_args=["--post-budget", "5", "--rocprof-timeout", "30"])
+    out, err = p.communicate(timeout=120)
+    assert p.returncode == 0, err[-3000:]
+    roof = _one_line(out)["roofline"]
+    assert roof["traffic_live_error"].startswith("the FETCH_SIZE pass skipped:") and "--post-budget" in roof["traffic_live_error"]
+    assert roof["rocprofv3_error"].startswith("the --kernel-trace --stats pass skipped:")
+
+
+def test_n1_line_appears_within_budget_when_the_baseline_child_never_returns(tmp_path):
+    t0 = time.monotonic()
+    p = _n1_on_the_test_double(tmp_path, "ok", extra_env={"LBFGS_BENCH_TEST_CPU_CHILD": "hang"}, extra_args=["--post-budget", "8"])
+    out, err = p.communicate(timeout=120)
+    took = time.monotonic() - t0
+    assert p.returncode == 0, err[-3000:]
+    j = _one_line(out)
+    assert j["value"] > 0 and j["cpu_baseline"]["value"] is None and j["cpu_baseline"]["sample"].startswith("cut:")
+    assert j["cpu_baseline"]["cores"] == 1 and j["cpu_baseline"]["kind"] == "port"
+    assert any(c.startswith("cpu_baseline: cut") for c in j["config"]["budget"]["cut"])
+    assert took < 60
+    # ... and the child is gone (it would hold ~22 GB of host memory at the metric's size)
+    left_over = subprocess.run(["pgrep", "-f", "time.sleep(100000)"], capture_output=True, text=True).stdout.split()
+    assert not left_over, left_over
+
+
+@pytest.mark.parametrize("sig", ["SIGTERM", "SIGINT"])
+def test_n1_a_signal_prints_the_line_measured_so_far(tmp_path, sig):
+    """The driver's kill while a rocprofv3 child hangs and the baseline child never returns: the measured line is printed at
+    once, says what it lacks, and neither child survives."""
+    import signal as _signal
+
+    p = _n1_on_the_test_double(tmp_path, "hang", extra_env={"LBFGS_BENCH_TEST_CPU_CHILD": "hang"},
+                               extra_args=["--post-budget", "200", "--rocprof-timeout", "60"])
+    # the stand-in rocprofv3 announces itself on stderr through bench.py's own progress line
+    deadline = time.monotonic() + 90
+    seen = ""
+    os.set_blocking(p.stderr.fileno(), False)
+    while time.monotonic() < deadline and "rocprofv3 --pmc FETCH_SIZE pass" not in seen:
+        try:
+            seen += p.stderr.read() or ""
+        except (BlockingIOError, TypeError):
+            pass
+        time.sleep(0.2)
+    assert "rocprofv3 --pmc FETCH_SIZE pass" in seen, seen[-2000:]
+    time.sleep(0.5)
+    t0 = time.monotonic()
+    p.send_signal(getattr(_signal, sig))
+    out, _ = p.communicate(timeout=60)
+    assert time.monotonic() - t0 < 20 and p.returncode == 0
+    j = _one_line(out)
+    assert j["value"] > 0 and j["config"]["interrupted_by_signal"] == int(getattr(_signal, sig))
+    assert j["cpu_baseline"]["value"] is None and "signal" in j["cpu_baseline"]["sample"]
+    assert j["roofline"].get("traffic_live") is None
+    time.sleep(0.5)
+    left_over = subprocess.run(["pgrep", "-f", "time.sleep(100000)"], capture_output=True, text=True).stdout.split()
+    assert not left_over, left_over
