@@ -734,6 +734,11 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int device, uint64_t n, const lbfg
     if (const char* e = getenv("LBFGS_HIP_NT_STORE_THRESHOLD_MB")) ctx->nt_store_threshold_bytes = (size_t)atoll(e) << 20;
     if (const char* e = getenv("LBFGS_HIP_HANDOFF")) ctx->handoff_ticket = strcmp(e, "ticket") == 0;
     if (const char* e = getenv("LBFGS_HIP_GRID")) ctx->grid_override = std::min(MAX_GRID, std::max(0, atoi(e)));
+    for (int k = 0; k < LBFGS_HIP_K_CLASSES; ++k) {  // tuning experiments: the launch grid of one kernel class
+        char name[40];
+        snprintf(name, sizeof(name), "LBFGS_HIP_GRID_X32_K%d", k);
+        if (const char* e = getenv(name)) ctx->grid_x32_class[k] = std::min(512, std::max(0, atoi(e)));
+    }
     CTX_TRY(hipMalloc(&ctx->board, (LBFGS_HIP_BOARD_SLOTS + 2) * sizeof(double)));
     CTX_TRY(hipMemsetAsync(ctx->board, 0, (LBFGS_HIP_BOARD_SLOTS + 2) * sizeof(double), ctx->stream));
     CTX_TRY(hipMalloc(&ctx->partials, (size_t)MAX_RED * MAX_GRID * sizeof(double)));

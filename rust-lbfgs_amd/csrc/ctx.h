@@ -158,6 +158,7 @@ struct lbfgs_hip_ctx {
     int grid_default = 0;
     int cu_count = 0;
     int grid_override = 0;
+    int grid_x32_class[LBFGS_HIP_K_CLASSES] = {0};  // LBFGS_HIP_GRID_X32_K<class>=<workgroups per 32 CUs>: experiments (0 = the operator's own)
     int gram_grid = 0;  // workgroups of the Gram rows kernel (0 = same as the others)
     size_t nt_threshold_bytes = (size_t)128 << 20;  // measured crossover: 95 MiB vectors prefer plain, 190 MiB prefer nt
     size_t nt_store_threshold_bytes = (size_t)64 << 20;  // from here up to nt_threshold_bytes: `nt` on the STORES only

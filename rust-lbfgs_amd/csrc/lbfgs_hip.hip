@@ -38,7 +38,8 @@ int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out,
     }
     const uint64_t n = ctx->shard.n_local;
     constexpr int MAP = tuning<Op>::MAP, UNR = tuning<Op>::UNR;
-    const int grid = grid_for(ctx, tuning<Op>::GRID_X32);
+    const int x32_k = (kclass >= 0 && kclass < LBFGS_HIP_K_CLASSES) ? ctx->grid_x32_class[kclass] : 0;
+    const int grid = grid_for(ctx, x32_k > 0 ? x32_k : tuning<Op>::GRID_X32);
     if (grid_out) *grid_out = (unsigned int)grid;
     // Cache hints by vector size (profiles/r02_shard_cache_hints.log):
     //   >= 128 MiB  `nt` (streaming) on loads and stores: nothing can stay in the 256 MiB Infinity Cache anyway;

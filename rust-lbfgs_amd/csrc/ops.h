@@ -333,34 +333,106 @@ struct OpConstrainDir {
 // The synthetic workloads of BASELINE.json configs 2-4.  Data comes from a counter-based hash of
 // the GLOBAL index, built from + and * only, so every rank and the CPU oracle (an independent C
 // restatement in oracle/objectives.c) generate bit-identical a_i, b_i, t_i with nothing stored.
-__device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t i) {
-    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
+// splitmix64 of (seed, i): z = seed + (i + 1) * golden, two xor-shift-multiply rounds.  `hp` = (i + 1) * IDX_GOLDEN, the index
+// product, comes from the skeleton (stream.h wants_index_product), which forms it once per thread and trip.
+__device__ __forceinline__ uint64_t mix64_h(uint64_t seed, uint64_t hp) {
+    uint64_t z = seed + hp;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
-__device__ __forceinline__ double hash_u01(uint64_t seed, uint64_t i) {
-    return (double)(mix64(seed, i) >> 11) * (1.0 / 9007199254740992.0);
+static_assert(IDX_GOLDEN == 0x9E3779B97F4A7C15ULL, "the index multiplier of splitmix64 (oracle/objectives.c)");
+// the top 53 bits of a hash as a double: v = m >> 11 < 2^53 converts EXACTLY as (2^84 + hi * 2^32) - (2^84 + 2^52) + (2^52 + lo)
+// -- two words OR-ed under two exponents, two exact additions -- instead of two integer conversions, a scaling and an
+// addition.  -> v itself (the caller folds the 2^-53 into its own multiplier: a power of two, so the rounding is the same)
+__device__ __forceinline__ double hash_top53(uint64_t m) {
+    const uint64_t v = m >> 11;
+    const double hi = __longlong_as_double((long long)(0x4530000000000000ULL | (v >> 32)));
+    const double lo = __longlong_as_double((long long)(0x4330000000000000ULL | (v & 0xffffffffULL)));
+    return (hi - 0x1.00000001p+84) + lo;
 }
+constexpr double TWO_M53 = 1.0 / 9007199254740992.0;
 
 struct ObjQuadratic {  // f_i = x*(0.5*a*x - b), g_i = a*x - b ; a = 1 + 999*u^2, b = 2*u' - 1
     uint64_t seed_a, seed_b;
-    __device__ void eval(double x, uint64_t gi, double& f, double& g) const {
-        const double ua = hash_u01(seed_a, gi), ub = hash_u01(seed_b, gi);
+    __device__ void eval(double x, uint64_t hp, double& f, double& g) const {
+        const double ua = hash_top53(mix64_h(seed_a, hp)) * TWO_M53;
         const double a = 1.0 + 999.0 * (ua * ua);
-        const double b = 2.0 * ub - 1.0;
+        const double b = (2.0 * TWO_M53) * hash_top53(mix64_h(seed_b, hp)) - 1.0;   // = 2 u - 1: scaling by 2 is exact
         const double t = a * x;
         g = t - b;
         f = x * (0.5 * t - b);
     }
 };
 
+// softplus(-z) = log(1 + exp(-z)) and sigma(-z) = 1 / (1 + exp(z)) in f64, branch-free, from ONE range reduction -- the
+// benchmark objective of BASELINE config 3 (the CALLER's closure kept on the device, not the reference's path; the oracle's
+// restatement, oracle/objectives.c, calls glibc).  ocml's exp + log1p + an IEEE division cost ~170 issue slots per element and
+// made every kernel that evaluates this objective ALU-bound at 2.4 TB/s (profiles/r05_probe_alu_check.log); this form takes
+// ~55: within 6e-16 of the exact value (softplus) / 4.8e-16 (sigma) over |z| <= 745, mean 5e-17 / 7e-17 -- glibc's own
+// sequence: 2.2e-16 / 3.3e-16 (tools/logistic_math_check.c emulates it bit for bit on the host; tests hold the device to it).
+//   e = exp(-|z|):      k = rint(t log2 e), r = t - k ln2 (two-part ln2: k ln2_hi exact), e = 2^k (1 + r + r^2 P9(r))
+//   u = 1 + e in (1,2]: u > sqrt 2 ? (N, D, kk) = (e - 1, e + 3, 1) : (e, e + 2, 0), so that s = N / D = (m-1)/(m+1) with
+//                       m = u / 2^kk in (0.707, 1.414]: log u = kk ln2 + 2 atanh s = kk ln2 + 2 s + s^3 Q6(s^2), |s| <= 0.1716
+//   ONE reciprocal:     w = 1 / (u D) (v_rcp_f64 + one third-order step); 1/u = D w; s = N u w
+// NaN propagates through every step; z = +-inf, +-0 and |z| > 745 (e denormal or 0) give the oracle's values exactly.
+struct LogisticMath {
+    __device__ static __forceinline__ void eval(const double z, double& softplus, double& sigma) {
+        double t = -__builtin_fabs(z);
+        t = (t < -800.0) ? -800.0 : t;                        // exp underflows to 0 beyond -745.2 (a compare, not fmax: NaN stays)
+        const double kf = __builtin_rint(t * 0x1.71547652b82fep+0);
+        double r = __builtin_fma(-kf, 0x1.62e42fefa3000p-1, t);
+        r = __builtin_fma(-kf, 0x1.3de6af278ece6p-42, r);     // |r| <= ln2 / 2
+        double p = 0x1.af38a9b0ec855p-26;
+        p = __builtin_fma(p, r, 0x1.289185613a3d6p-22);
+        p = __builtin_fma(p, r, 0x1.71de0dae63bb3p-19);
+        p = __builtin_fma(p, r, 0x1.a019b90d2ae7ap-16);
+        p = __builtin_fma(p, r, 0x1.a01a01a7c41d5p-13);
+        p = __builtin_fma(p, r, 0x1.6c16c1788bd90p-10);
+        p = __builtin_fma(p, r, 0x1.11111111109b3p-7);
+        p = __builtin_fma(p, r, 0x1.5555555553d63p-5);
+        p = __builtin_fma(p, r, 0x1.5555555555556p-3);
+        p = __builtin_fma(p, r, 0x1.0000000000001p-1);
+        const double q = __builtin_fma(r * r, p, r);
+        const double e = __builtin_amdgcn_ldexp(1.0 + q, (int)kf);
+        const double u = 1.0 + e;
+        const bool big = e > 0x1.a827999fcef32p-2;             // u > sqrt 2
+        const double kk = big ? 1.0 : 0.0;
+        const double N = e - kk;
+        const double D = e + (big ? 3.0 : 2.0);
+        const double pd = u * D;
+        double w = __builtin_amdgcn_rcp(pd);                    // ~2^-23 (measured: tests/test_gpu_parity.py holds the result to 2e-15)
+        const double e0 = __builtin_fma(-pd, w, 1.0);
+        w = __builtin_fma(w, __builtin_fma(e0, e0, e0), w);     // one third-order step: w (1 + e0 + e0^2), error e0^3
+        const double inv_u = D * w;
+        const double s = (N * u) * w;
+        const double s2 = s * s;
+        double l = 0x1.2b5f68a50d903p-3;
+        l = __builtin_fma(l, s2, 0x1.39fdcceb4bb45p-3);
+        l = __builtin_fma(l, s2, 0x1.7462b91b8df65p-3);
+        l = __builtin_fma(l, s2, 0x1.c71c62d5e53e0p-3);
+        l = __builtin_fma(l, s2, 0x1.2492492dfd86cp-2);
+        l = __builtin_fma(l, s2, 0x1.9999999995273p-2);
+        l = __builtin_fma(l, s2, 0x1.5555555555558p-1);
+        double lg = __builtin_fma(kk, 0x1.abc9e3b39803fp-56, (s * s2) * l);
+        lg = __builtin_fma(2.0, s, lg);
+        lg = __builtin_fma(kk, 0x1.62e42fefa39efp-1, lg);
+        softplus = lg + __builtin_fmax(-z, 0.0);                // z < 0: log(1 + e^-z) = -z + log(1 + e^z)
+        sigma = ((z >= 0.0) ? e : 1.0) * inv_u;
+    }
+};
+
 struct ObjLogistic {  // f_i = log(1+exp(-w*x)), w = +-(0.5 + 1.5*u)
     uint64_t seed_a, seed_b;
-    __device__ void eval(double x, uint64_t gi, double& f, double& g) const {
-        const double a = 0.5 + 1.5 * hash_u01(seed_a, gi);
-        const double w = (mix64(seed_b, gi) >> 63) ? a : -a;
+    static constexpr int GRID_X32 = 96;  // ~140 issue slots per element: 3 workgroups per CU hide them behind the loads
+    __device__ void eval(double x, uint64_t hp, double& f, double& g) const {
+        // a = 0.5 + 1.5 u with u = v 2^-53: (1.5 * 2^-53) v rounds like 1.5 (v 2^-53) -- the power of two is exact
+        const double a = 0.5 + (1.5 * TWO_M53) * hash_top53(mix64_h(seed_a, hp));
+        // w = bit 63 of the second hash ? a : -a: its complement goes straight into a's sign bit (a > 0)
+        const unsigned int sgn = ~(unsigned int)(mix64_h(seed_b, hp) >> 32) & 0x80000000u;
+        const double w = __hiloint2double(__double2hiint(a) | (int)sgn, __double2loint(a));
         const double z = w * x;
+#if defined(LH_LOGISTIC_OCML)  // the libm form (A/B builds: tools/build_variants.sh "ocml=-DLH_LOGISTIC_OCML=1")
         const double e = exp(-fabs(z));
         double fi = log1p(e);
         double sig;
@@ -370,22 +442,40 @@ struct ObjLogistic {  // f_i = log(1+exp(-w*x)), w = +-(0.5 + 1.5*u)
             sig = 1.0 / (1.0 + e);
             fi -= z;
         }
+#else
+        double fi, sig;
+        LogisticMath::eval(z, fi, sig);
+#endif
         g = -w * sig;
         f = fi;
     }
 };
 
+// workgroups per 32 CUs for an operator that evaluates Obj per element: an objective with real arithmetic names its own
+// (Obj::GRID_X32), the others take the operator's default
+template <class Obj, int DEFAULT>
+struct obj_grid {
+    template <class T> static constexpr int get(decltype(T::GRID_X32)*) { return T::GRID_X32; }
+    template <class T> static constexpr int get(...) { return DEFAULT; }
+    static constexpr int value = get<Obj>(nullptr);
+};
+
 template <class Obj>
 struct OpObjEval {  // core.rs:119-121 with the closure resident on the device.  1r 1w.
     static constexpr int NIN = 1, NOUT = 1, NRED = 1;
+    static constexpr int TUNE_GRID_X32 = obj_grid<Obj, 27>::value;
     const double* in[1];  // x
     double* out[1];       // g
     Obj obj;
     typedef NoCoef Coef;
     __device__ Coef setup() const { return {}; }
-    __device__ void elem(const Coef&, const double* v, double* w, double* acc, uint64_t gi) const {
+    static constexpr bool INDEX_PRODUCT = true;  // hp = (gi + 1) * IDX_GOLDEN from the skeleton (stream.h)
+    __device__ void elem(const Coef& cf, const double* v, double* w, double* acc, uint64_t gi) const {
+        elem(cf, v, w, acc, gi, (gi + 1) * IDX_GOLDEN);
+    }
+    __device__ void elem(const Coef&, const double* v, double* w, double* acc, uint64_t gi, uint64_t hp) const {
         double f, g;
-        obj.eval(v[0], gi, f, g);
+        obj.eval(v[0], hp, f, g);
         w[0] = g;
         acc[0] += f;
     }
@@ -394,16 +484,21 @@ struct OpObjEval {  // core.rs:119-121 with the closure resident on the device. 
 template <class Obj>
 struct OpObjLineEval {  // take_line_step + evaluate + dg_unchecked (core.rs:155-158,119-121,114-116).  2r 2w.
     static constexpr int NIN = 2, NOUT = 2, NRED = 2;
+    static constexpr int TUNE_GRID_X32 = obj_grid<Obj, 27>::value;
     const double* in[2];  // xp, d
     double* out[2];       // x, g
     double step;
     Obj obj;
     typedef NoCoef Coef;
     __device__ Coef setup() const { return {}; }
-    __device__ void elem(const Coef&, const double* v, double* w, double* acc, uint64_t gi) const {
+    static constexpr bool INDEX_PRODUCT = true;  // hp = (gi + 1) * IDX_GOLDEN from the skeleton (stream.h)
+    __device__ void elem(const Coef& cf, const double* v, double* w, double* acc, uint64_t gi) const {
+        elem(cf, v, w, acc, gi, (gi + 1) * IDX_GOLDEN);
+    }
+    __device__ void elem(const Coef&, const double* v, double* w, double* acc, uint64_t gi, uint64_t hp) const {
         const double x = v[0] + step * v[1];
         double f, g;
-        obj.eval(x, gi, f, g);
+        obj.eval(x, hp, f, g);
         w[0] = x;
         w[1] = g;
         acc[0] += f;
@@ -425,10 +520,14 @@ struct OpObjLineProbe {
     Obj obj;
     typedef NoCoef Coef;
     __device__ Coef setup() const { return {}; }
-    __device__ void elem(const Coef&, const double* v, double*, double* acc, uint64_t gi) const {
+    static constexpr bool INDEX_PRODUCT = true;  // hp = (gi + 1) * IDX_GOLDEN from the skeleton (stream.h)
+    __device__ void elem(const Coef& cf, const double* v, double* w, double* acc, uint64_t gi) const {
+        elem(cf, v, w, acc, gi, (gi + 1) * IDX_GOLDEN);
+    }
+    __device__ void elem(const Coef&, const double* v, double*, double* acc, uint64_t gi, uint64_t hp) const {
         const double x = v[0] + step * v[1];
         double f, g;
-        obj.eval(x, gi, f, g);
+        obj.eval(x, hp, f, g);
         acc[0] += f;
         acc[1] += g * v[1];
     }
@@ -442,7 +541,7 @@ struct OpHistUpdateFromStep {
     static constexpr int NIN = 3, NOUT = 4, NRED = 7;
     // default map / unroll, 2 workgroups per CU.  (The stand-alone sweep profiles/r01_tune_objective_kernels.log prefers
     // map 1 / unroll 2 / 1 per CU; inside bench.py that setting measured 1082 us against 925 us: not taken.)
-    static constexpr int TUNE_GRID_X32 = 64;
+    static constexpr int TUNE_GRID_X32 = obj_grid<Obj, 64>::value;
     const double* in[3];  // xp, d, gp
     double* out[4];       // x, g, s, y
     double t;             // the accepted trial step
@@ -450,10 +549,14 @@ struct OpHistUpdateFromStep {
     Obj obj;
     typedef NoCoef Coef;
     __device__ Coef setup() const { return {}; }
-    __device__ void elem(const Coef&, const double* v, double* w, double* acc, uint64_t gi) const {
+    static constexpr bool INDEX_PRODUCT = true;  // hp = (gi + 1) * IDX_GOLDEN from the skeleton (stream.h)
+    __device__ void elem(const Coef& cf, const double* v, double* w, double* acc, uint64_t gi) const {
+        elem(cf, v, w, acc, gi, (gi + 1) * IDX_GOLDEN);
+    }
+    __device__ void elem(const Coef&, const double* v, double* w, double* acc, uint64_t gi, uint64_t hp) const {
         const double x = v[0] + t * v[1];
         double f, g;
-        obj.eval(x, gi, f, g);
+        obj.eval(x, hp, f, g);
         const double s = x - v[0];
         const double y = g - v[2];
         w[0] = x; w[1] = g; w[2] = s; w[3] = y;
@@ -477,6 +580,7 @@ struct OpHistUpdateFromStep {
 template <class Obj, bool FIRST = false>
 struct OpObjOwlLineEval {
     static constexpr int NIN = 3, NOUT = FIRST ? 4 : 3, NRED = 5;
+    static constexpr int TUNE_GRID_X32 = obj_grid<Obj, 27>::value;
     const double* in[3];  // xp, d, wp (FIRST: the previous pg)
     double* out[4];       // x, g, pg (FIRST: + wp)
     double step, c;
@@ -484,7 +588,11 @@ struct OpObjOwlLineEval {
     Obj obj;
     typedef NoCoef Coef;
     __device__ Coef setup() const { return {}; }
-    __device__ void elem(const Coef&, const double* v, double* w, double* acc, uint64_t gi) const {
+    static constexpr bool INDEX_PRODUCT = true;  // hp = (gi + 1) * IDX_GOLDEN from the skeleton (stream.h)
+    __device__ void elem(const Coef& cf, const double* v, double* w, double* acc, uint64_t gi) const {
+        elem(cf, v, w, acc, gi, (gi + 1) * IDX_GOLDEN);
+    }
+    __device__ void elem(const Coef&, const double* v, double* w, double* acc, uint64_t gi, uint64_t hp) const {
         double x = v[0] + step * v[1];
         const bool reg = gi >= start && gi < end;
         double orthant = v[2];
@@ -494,7 +602,7 @@ struct OpObjOwlLineEval {
         }
         if (reg && signum0(x) != signum0(orthant)) x = 0.0;       // orthantwise.rs:165-171
         double f, g;
-        obj.eval(x, gi, f, g);
+        obj.eval(x, hp, f, g);
         double pg = g;
         if (reg) {                                             // orthantwise.rs:70-112
             acc[2] += c * fabs(x);

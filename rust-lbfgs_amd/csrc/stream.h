@@ -553,11 +553,35 @@ struct tuning {
     static constexpr int GRID_X32 = gx32<Op>(nullptr);
 };
 
+// Operators that hash the GLOBAL index (the synthetic objectives of ops.h: data from splitmix64 of the index, nothing stored)
+// declare `static constexpr bool INDEX_PRODUCT = true` and take, next to the index, its product (gidx + 1) * IDX_GOLDEN mod 2^64
+// -- the first step of that hash -- from the skeleton: `elem(cf, v, w, acc, gidx, hp)`.  A 64-bit multiply is three
+// quarter-rate integer multiplies on gfx950; the skeleton knows that the index products of a trip differ by constants, forms
+// ONE per thread and trip (8 elements) and adds (bit-identical: arithmetic mod 2^64).  Worth 8 % on the trial probe of the
+// hashed quadratic, whose ALU work sits close behind its two reads.
+constexpr uint64_t IDX_GOLDEN = 0x9E3779B97F4A7C15ULL;
+template <class Op>
+struct wants_index_product {
+    template <class T> static constexpr bool test(decltype(T::INDEX_PRODUCT)*) { return T::INDEX_PRODUCT; }
+    template <class T> static constexpr bool test(...) { return false; }
+    static constexpr bool value = test<Op>(nullptr);
+};
+
+// hp0: (gidx0 + 1) * IDX_GOLDEN for operators that want it (anything otherwise)
 template <class Op>
 __device__ __forceinline__ void do_pair(const Op& op, const typename Op::Coef& cf, const d2* v, d2* w, double* acc,
-                                        uint64_t gidx0) {
+                                        uint64_t gidx0, uint64_t hp0) {
     if constexpr (is_pairwise<Op>::value) {
         op.pair(cf, v, w, acc, gidx0);
+    } else if constexpr (wants_index_product<Op>::value) {
+        double a[Op::NIN ? Op::NIN : 1], b[Op::NIN ? Op::NIN : 1];
+        double wa[Op::NOUT ? Op::NOUT : 1], wb[Op::NOUT ? Op::NOUT : 1];
+#pragma unroll
+        for (int s = 0; s < Op::NIN; ++s) { a[s] = v[s].x; b[s] = v[s].y; }
+        op.elem(cf, a, wa, acc, gidx0, hp0);
+        op.elem(cf, b, wb, acc, gidx0 + 1, hp0 + IDX_GOLDEN);
+#pragma unroll
+        for (int s = 0; s < Op::NOUT; ++s) { w[s].x = wa[s]; w[s].y = wb[s]; }
     } else {
         double a[Op::NIN ? Op::NIN : 1], b[Op::NIN ? Op::NIN : 1];
         double wa[Op::NOUT ? Op::NOUT : 1], wb[Op::NOUT ? Op::NOUT : 1];
@@ -623,11 +647,15 @@ __device__ __forceinline__ void stream_sweep(const Op& op, CoefFn coef, const ui
         }
     };
     auto work_trip = [&](const typename Op::Coef& cf, uint64_t t, d2 (&v)[UNROLL][NIN ? NIN : 1]) {
+        // (index products: the chunks of a trip are a fixed stride apart -- 1, or G under MAP 1 -- so one multiply serves the trip)
+        uint64_t hp_trip = 0;
+        if constexpr (wants_index_product<Op>::value) hp_trip = (gofs + 2 * (chunk_of(t, 0) * BLOCK + tid) + 1) * IDX_GOLDEN;
+        const uint64_t hp_chunk = (MAP == 1 ? G : 1) * (2ull * BLOCK) * IDX_GOLDEN;
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const uint64_t p = chunk_of(t, u) * BLOCK + tid;
             d2 w[NOUT ? NOUT : 1];
-            do_pair<Op>(op, cf, v[u], w, acc, gofs + 2 * p);
+            do_pair<Op>(op, cf, v[u], w, acc, gofs + 2 * p, hp_trip + (uint64_t)u * hp_chunk);
 #pragma unroll
             for (int s = 0; s < NOUT; ++s) st_masked<NTO>(op.out[s], p, w[s], s);
         }
@@ -640,7 +668,7 @@ __device__ __forceinline__ void stream_sweep(const Op& op, CoefFn coef, const ui
                 d2 v[NIN ? NIN : 1], w[NOUT ? NOUT : 1];
 #pragma unroll
                 for (int s = 0; s < NIN; ++s) v[s] = ld_masked<NTI>(op.in[s], p, s);
-                do_pair<Op>(op, cf, v, w, acc, gofs + 2 * p);
+                do_pair<Op>(op, cf, v, w, acc, gofs + 2 * p, (gofs + 2 * p + 1) * IDX_GOLDEN);
 #pragma unroll
                 for (int s = 0; s < NOUT; ++s) st_masked<NTO>(op.out[s], p, w[s], s);
             }

@@ -418,6 +418,47 @@ def test_builtin_objectives(n):
             v.free()
 
 
+def test_logistic_softplus_and_sigmoid_over_the_whole_range():
+    """The hashed logistic objective (BASELINE config 3) evaluates log(1 + exp(-z)) and 1 / (1 + exp(z)) with a hand-written
+    f64 form (ops.h LogisticMath: one range reduction, one reciprocal, two short polynomials) where the oracle calls glibc's
+    exp / log1p and divides.  Bar: 2e-15 relative PER ELEMENT over the whole range of z, the special values exactly --
+    the parity bar on f and ||g|| (1e-10) is five orders of magnitude above that."""
+    rng = np.random.default_rng(7)
+    # g, element by element: z = w x with |w| in [0.5, 2], so x in +-400 covers exp's whole range (e denormal from |z| > 708)
+    n = 400_000
+    xh = np.concatenate([rng.uniform(-3, 3, n // 4), rng.uniform(-40, 40, n // 4), rng.uniform(-400, 400, n // 4),
+                         rng.uniform(-1e-3, 1e-3, n // 4 - 16),
+                         [0.0, -0.0, 5e-324, -5e-324, 1e-320, 1e300, -1e300, np.inf, -np.inf, np.nan, 1.7e308, -1.7e308, 354.0, -354.0, 372.5, -372.5]])
+    with R.Context(n) as ctx:
+        xp, g = DeviceVec(ctx, xh), DeviceVec(ctx)
+        H.objective_eval(objectives.Logistic(), xp, g, 0)
+        gd = g.to_numpy()
+        _, go = O.eval_builtin(O.logistic(), xh)
+        xp.free(); g.free()
+    assert np.array_equal(np.isnan(gd), np.isnan(go)) and np.isnan(gd).sum() == 1
+    ok = ~np.isnan(go)
+    normal = ok & (np.abs(go) > 1e-300)
+    assert np.max(np.abs(gd[normal] - go[normal]) / np.abs(go[normal])) <= 2e-15
+    assert np.all(np.abs(gd[ok & ~normal] - go[ok & ~normal]) <= 5e-324 + 1e-15 * np.abs(go[ok & ~normal]))   # (denormal sigmoids: an ulp)
+    assert np.array_equal(np.signbit(gd[ok]), np.signbit(go[ok]))
+    # f, element by element: a one-element problem per value (the hashed weight of index 0 throughout)
+    vals = np.concatenate([[0.0, -0.0, 5e-324, -1e-320, 1e-17, -1e-17, 1e-9, -1e-9, 0.3, -0.3, 0.44, -0.44, 0.8813735870195429,
+                            -0.8813735870195429, 1.0, -1.0, 18.0, -18.0, 37.0, -37.0, 354.0, -354.0, 372.4, -372.4, 700.0, -700.0,
+                            1e300, -1e300, np.inf, -np.inf, np.nan], rng.uniform(-4, 4, 100), rng.uniform(-800, 800, 60)])
+    with R.Context(1) as ctx:
+        xp, g = DeviceVec(ctx), DeviceVec(ctx)
+        for v in vals:
+            xp.upload(np.array([v]))
+            H.objective_eval(objectives.Logistic(), xp, g, 0)
+            f = ctx.scalars(0)[0]
+            fo, _ = O.eval_builtin(O.logistic(), np.array([v]))
+            if np.isnan(fo) or np.isinf(fo) or fo == 0.0:
+                assert (np.isnan(f) and np.isnan(fo)) or f == fo, (v, f, fo)
+            else:
+                assert abs(f - fo) <= 2e-15 * abs(fo) + 5e-324, (v, f, fo)
+        xp.free(); g.free()
+
+
 # ---------------------------------------------------------------------------------------------
 # the reference's integration tests, through the drop-in closure API (tests/simple.rs, tests/owlqn.rs)
 # ---------------------------------------------------------------------------------------------
