@@ -1370,6 +1370,8 @@ def supervisor_main(a):
         leg_env = dict(base_env)
         if leg == "p2p-per-step":  # the p2p communicator with one kernel per two-loop step (no persistent kernel)
             leg_env["LBFGS_HIP_RESIDENT"] = "0"
+        if leg == "rccl":  # OPT IN to the gated exchange (the library's default is a kernel per step until the gated form has run with
+            leg_env["LBFGS_HIP_RCCL_RESIDENT"] = "1"  # peers): this job is a child with a timeout, and ran_as() files what really ran
         if leg == "rccl-per-step":  # RCCL with one kernel per two-loop step (no gated exchange under the persistent kernel)
             leg_env["LBFGS_HIP_RCCL_RESIDENT"] = "0"
         if hook:

@@ -12,6 +12,7 @@
 
 #include <cerrno>
 #include <chrono>
+#include <thread>
 
 #include "ctx.h"
 
@@ -27,6 +28,7 @@ struct Rccl {
     int (*CommCount)(const nccl_comm_t, int*) = nullptr;     // what RCCL itself says the communicator spans ...
     int (*CommUserRank)(const nccl_comm_t, int*) = nullptr;  // ... and who this process is in it
     int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*CommAbort)(void*) = nullptr;  // optional
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -62,6 +64,7 @@ bool rccl_load(std::string* err) {
     LH_SYM(GroupEnd, "ncclGroupEnd")
     LH_SYM(GetErrorString, "ncclGetErrorString")
 #undef LH_SYM
+    *(void**)(&g_rccl.CommAbort) = dlsym(g_rccl.handle, "ncclCommAbort");  // (absent: a communicator that cannot drain is left alone)
     g_rccl.ok = true;
     return true;
 }
@@ -321,28 +324,44 @@ __global__ __launch_bounds__(64) void ext_selftest_set_kernel(unsigned long long
     if (threadIdx.x == 0) __hip_atomic_store(flags + 3, magic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// *bad (0 / 1: this rank's outcome) -> the number of ranks that reported 1.  Slot 0 of the ring is the buffer.
+// *bad (0 / 1: this rank's outcome) -> the number of ranks that reported 1.  The buffer is the board's first private slot (the
+// two-loop's ping-pong dots: idle while a context is being created) -- NOT the uncached block, which a rank that failed to
+// allocate it does not have and must still vote.
 static int ext_agree(lbfgs_hip_ctx* ctx, int* bad) {
-    double* const slot0 = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->ext_block) + EXT_BUF_OFFSET);
+    double* const buf = ctx->board + LBFGS_HIP_BOARD_SLOTS;
     double v = *bad ? 1.0 : 0.0;
-    HIP_TRY(ctx, hipMemcpy(slot0, &v, sizeof(v), hipMemcpyHostToDevice));
-    const int rc = rccl_allreduce_on(ctx, slot0, 1, ctx->stream);
+    HIP_TRY(ctx, hipMemcpy(buf, &v, sizeof(v), hipMemcpyHostToDevice));
+    const int rc = rccl_allreduce_on(ctx, buf, 1, ctx->stream);
     if (rc != LBFGS_HIP_OK) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(&v, slot0, sizeof(v), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(&v, buf, sizeof(v), hipMemcpyDeviceToHost));
     *bad = (int)v;
     v = 0.0;
-    HIP_TRY(ctx, hipMemcpy(slot0, &v, sizeof(v), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(buf, &v, sizeof(v), hipMemcpyHostToDevice));
     return LBFGS_HIP_OK;
 }
+// rank-local steps of ext_prepare: a failure is RECORDED (ctx->err keeps the message) and the rank goes on to every collective
+// below with a "bad" vote -- returning here would leave its peers inside ncclAllReduce + hipStreamSynchronize for ever (the host
+// side has no timeout) -- and hands the error back after the last one (round-5 advice).
+#define EXT_LOCAL(call)                                                                                             \
+    do {                                                                                                            \
+        if (local_rc == LBFGS_HIP_OK) {                                                                             \
+            hipError_t e_ = (call);                                                                                 \
+            if (e_ != hipSuccess) local_rc = fail(ctx, LBFGS_HIP_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+        }                                                                                                           \
+    } while (0)
+// -> LBFGS_HIP_OK: the gated exchange is usable on EVERY rank; 1: not (every rank takes the kernel-per-step form); < 0: error.
+// COLLECTIVE over the context's communicator: every rank makes the same sequence of all-reduces whatever happens to it locally.
 int ext_prepare(lbfgs_hip_ctx* ctx) {
-    const bool first_use = !ctx->xstream || !ctx->ext_block;
+    int local_rc = LBFGS_HIP_OK;
     if (!ctx->xstream) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // (numerically lowest = highest priority)
-        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->xstream, hipStreamNonBlocking, hi));
+        EXT_LOCAL(hipStreamCreateWithPriority(&ctx->xstream, hipStreamNonBlocking, hi));
+        if (ctx->resident_fault == -2) local_rc = fail(ctx, LBFGS_HIP_ERR_HIP, "injected: the second stream could not be created (tests)");
     }
-    if (!ctx->ext_block) {
+    if (!ctx->ext_ev) EXT_LOCAL(hipEventCreateWithFlags(&ctx->ext_ev, hipEventDisableTiming));
+    if (!ctx->ext_block && local_rc == LBFGS_HIP_OK) {
         void* p = nullptr;
         {
             std::lock_guard<std::mutex> lk(g_uc_pool_mu);  // (uncached blocks are pooled per process, never freed: see lbfgs_hip_ctx_create)
@@ -353,71 +372,117 @@ int ext_prepare(lbfgs_hip_ctx* ctx) {
             }
         }
         const size_t bytes = P2P_MBOX_WORDS * sizeof(unsigned long long);
-        if (!p) HIP_TRY(ctx, hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached));
-        ctx->ext_block = static_cast<unsigned long long*>(p);
-        HIP_TRY(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (!p) EXT_LOCAL(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached));
+        if (local_rc == LBFGS_HIP_OK) {
+            ctx->ext_block = static_cast<unsigned long long*>(p);
+            EXT_LOCAL(hipMemsetAsync(p, 0, bytes, ctx->stream));
+            EXT_LOCAL(hipStreamSynchronize(ctx->stream));
+        }
     }
-    if (first_use) {
-        // handshake: a kernel on the compute stream waits (<= 20 ms) for a word that a kernel on the second stream sets
+    // stage 1 -- handshake: a kernel on the compute stream waits (<= 20 ms) for a word that a kernel on the second stream sets;
+    // and this rank's shard and device must be able to take the persistent kernel at all (an empty shard, a shard beyond the
+    // kernel's limits, a CU-masked queue cannot: lbfgs_hip.hip resident_shard_eligible)
+    unsigned long long verdict = 0;
+    if (local_rc == LBFGS_HIP_OK) {
         const unsigned long long magic = 0x6761746564ull;
         hipLaunchKernelGGL(ext_selftest_wait_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->ext_block, magic, 2000000ull);
         hipLaunchKernelGGL(ext_selftest_set_kernel, dim3(1), dim3(64), 0, ctx->xstream, ctx->ext_block, magic);
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->xstream));
-        unsigned long long verdict = 0;
-        HIP_TRY(ctx, hipMemcpy(&verdict, ctx->ext_block + 4, sizeof(verdict), hipMemcpyDeviceToHost));
-        // Every rank must take the same form -- a rank with a kernel per step and a rank with the gated chain would pair their
-        // all-reduces wrongly -- so the ranks AGREE on each outcome: a sum of 0 / 1 over the communicator, on the compute
-        // stream (which works whatever the second stream does).
-        int bad = verdict == 1ull ? 0 : 1, stage = 1;
-        if (ctx->nccl) {
-            const int rc_a = ext_agree(ctx, &bad);
-            if (rc_a != LBFGS_HIP_OK) return rc_a;
+        EXT_LOCAL(hipGetLastError());
+        EXT_LOCAL(hipStreamSynchronize(ctx->stream));
+        EXT_LOCAL(hipStreamSynchronize(ctx->xstream));
+        EXT_LOCAL(hipMemcpy(&verdict, ctx->ext_block + 4, sizeof(verdict), hipMemcpyDeviceToHost));
+    }
+    const bool shard_ok = resident_shard_eligible(ctx);
+    // Every rank must take the same form -- a rank with a kernel per step and a rank with the gated chain would pair their
+    // all-reduces wrongly -- so the ranks AGREE on each outcome: a sum of 0 / 1 over the communicator, on the compute
+    // stream (which works whatever the second stream does).
+    int bad = (local_rc == LBFGS_HIP_OK && verdict == 1ull && shard_ok) ? 0 : 1, stage = shard_ok || local_rc != LBFGS_HIP_OK ? 1 : 0;
+    if (ctx->nccl) {
+        const int rc_a = ext_agree(ctx, &bad);
+        if (rc_a != LBFGS_HIP_OK) return rc_a;  // (the communicator itself failed: nothing collective can follow)
+    }
+    if (bad == 0 && ctx->nccl) {
+        // RCCL's first collective on a stream may set things up (channels, buffers) and wait for the device: let it do so
+        // NOW, not with a persistent kernel waiting for it.  Collective: every rank comes here (bad == 0 is the agreed value).
+        double* const slot0 = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->ext_block) + EXT_BUF_OFFSET);
+        const int rc_w = rccl_allreduce_on(ctx, slot0, 1, ctx->xstream);
+        if (rc_w != LBFGS_HIP_OK) return rc_w;
+        EXT_LOCAL(hipStreamSynchronize(ctx->xstream));
+        EXT_LOCAL(hipMemsetAsync(slot0, 0, EXT_SLOT_DOUBLES * sizeof(double), ctx->stream));
+        EXT_LOCAL(hipStreamSynchronize(ctx->stream));
+        // ... and then the exchange itself, once, under a kernel that fills the chip the way the two-loop will.  Every rank's
+        // peers wait inside RCCL for its all-reduce of this trial: a rank that failed locally, or whose trial failed before it
+        // got that far, still hands ONE all-reduce to the communicator (on the compute stream, ungated: the sum is then wrong
+        // and every rank sees the trial fail) -- nobody is left inside RCCL.
+        bool ok = false, enqueued = false;
+        if (local_rc == LBFGS_HIP_OK && ctx->resident_fault != -3) {
+            const int rc_s = ext_selftest_resident(ctx, &ok, &enqueued);
+            if (rc_s != LBFGS_HIP_OK) local_rc = rc_s;
+        } else if (ctx->resident_fault == -3) {
+            local_rc = fail(ctx, LBFGS_HIP_ERR_HIP, "injected: this rank failed before the gated exchange's trial (tests)");
         }
-        if (bad == 0 && ctx->nccl) {
-            // RCCL's first collective on a stream may set things up (channels, buffers) and wait for the device: let it do so
-            // NOW, not with a persistent kernel waiting for it.  Collective: every rank of the communicator comes here from
-            // lbfgs_hip_ctx_create under the same settings (LBFGS_HIP_RCCL_RESIDENT, exclusive_device).
-            double* const slot0 = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->ext_block) + EXT_BUF_OFFSET);
-            const int rc_w = rccl_allreduce_on(ctx, slot0, 1, ctx->xstream);
-            if (rc_w != LBFGS_HIP_OK) return rc_w;
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->xstream));
-            HIP_TRY(ctx, hipMemsetAsync(slot0, 0, EXT_SLOT_DOUBLES * sizeof(double), ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            // ... and then the exchange itself, once, under a kernel that fills the chip the way the two-loop will
-            bool ok = false;
-            const int rc_s = ext_selftest_resident(ctx, &ok);
-            if (rc_s != LBFGS_HIP_OK) return rc_s;
-            if (ctx->resident_fault == -1) ok = false;  // (tests)
-            bad = ok ? 0 : 1;
-            stage = 2;
-            const int rc_b = ext_agree(ctx, &bad);
-            if (rc_b != LBFGS_HIP_OK) return rc_b;
+        if (!enqueued) {
+            const int rc_e = rccl_allreduce_on(ctx, ctx->board + LBFGS_HIP_BOARD_SLOTS, 1, ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream);
+            if (rc_e != LBFGS_HIP_OK) return rc_e;
         }
-        if (bad != 0) {
-            ctx->rccl_resident = 0;
-            if (stage == 1)
-                fprintf(stderr, "[lbfgs_hip] warning: the compute stream and the second stream of the gated RCCL exchange are not served "
-                                "concurrently on %d of %d ranks (they share a hardware queue: GPU_MAX_HW_QUEUES); the two-loop runs with a "
-                                "kernel per step under RCCL\n", bad, ctx->shard.world);
-            else
-                fprintf(stderr, "[lbfgs_hip] warning: the gated RCCL exchange's self-test (an all-reduce enqueued on the second stream, "
-                                "awaited by a kernel that fills the chip) did not come back right within 1 s on %d of %d ranks; the "
-                                "two-loop runs with a kernel per step under RCCL\n", bad, ctx->shard.world);
-            return 1;  // (not an error: the caller takes the kernel-per-step form)
-        }
+        if (ctx->resident_fault == -1) ok = false;  // (tests)
+        bad = (ok && local_rc == LBFGS_HIP_OK) ? 0 : 1;
+        stage = 2;
+        const int rc_b = ext_agree(ctx, &bad);
+        if (rc_b != LBFGS_HIP_OK) return rc_b;
+    }
+    if (local_rc != LBFGS_HIP_OK) return local_rc;  // (after the last collective)
+    if (bad != 0) {
+        ctx->rccl_resident = 0;
+        if (stage == 0)
+            fprintf(stderr, "[lbfgs_hip] note: the shard or the device of %d of %d ranks cannot take the persistent two-loop kernel (an empty "
+                            "shard, a shard beyond its limits, a CU-masked queue); every rank runs the two-loop with a kernel per step "
+                            "under RCCL\n", bad, ctx->shard.world);
+        else if (stage == 1)
+            fprintf(stderr, "[lbfgs_hip] warning: the gated RCCL exchange is not available on %d of %d ranks (the compute stream and the "
+                            "second stream are not served concurrently -- they share a hardware queue: GPU_MAX_HW_QUEUES --, or a "
+                            "shard / device cannot take the persistent kernel); the two-loop runs with a kernel per step under RCCL\n",
+                    bad, ctx->shard.world);
+        else
+            fprintf(stderr, "[lbfgs_hip] warning: the gated RCCL exchange's self-test (an all-reduce enqueued on the second stream, "
+                            "awaited by a kernel that fills the chip) did not come back right within 1 s on %d of %d ranks; the "
+                            "two-loop runs with a kernel per step under RCCL\n", bad, ctx->shard.world);
+        return 1;  // (not an error: the caller takes the kernel-per-step form)
     }
     return LBFGS_HIP_OK;
 }
+#undef EXT_LOCAL
 // Give the chain of the latest gated launch up: its gates leave at once (abort word >= their launch id), the all-reduces behind
 // them reduce whatever the slots hold -- on every rank alike, nobody reads it -- and the second stream runs empty.
 void ext_abort(lbfgs_hip_ctx* ctx) {
     if (!ctx->xstream || !ctx->ext_block) return;
     const unsigned long long id = ctx->ext_launches;
     (void)hipMemcpy(ctx->ext_block + 2, &id, sizeof(id), hipMemcpyHostToDevice);
-    (void)hipStreamSynchronize(ctx->xstream);
+    // The drain is BOUNDED: an all-reduce of the chain that a peer never enqueues (the peer died, or took another path after an
+    // error of its own) does not complete, and a hipStreamSynchronize here would hold lbfgs_hip_ctx_destroy and every error
+    // return for ever.  Poll; past the deadline abort the communicator (ncclCommAbort ends its kernels), poll once more.
+    auto drained = [&](double seconds) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(ctx->xstream);
+            if (q != hipErrorNotReady) {
+                (void)hipGetLastError();
+                return true;
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    };
+    const double wait_s = std::max(2.0, 2.0 * (double)(ctx->p2p_timeout_ticks + ctx->handoff_timeout_ticks) * 1e-8);
+    if (drained(wait_s)) return;
+    fprintf(stderr, "[lbfgs_hip] warning: the gated RCCL chain did not drain within %.0f s (a peer never enqueued its all-reduce?)%s\n",
+            wait_s, (ctx->nccl && g_rccl.CommAbort) ? ": aborting the communicator" : "");
+    if (ctx->nccl && g_rccl.CommAbort) {
+        (void)g_rccl.CommAbort(ctx->nccl);
+        ctx->nccl = nullptr;  // (aborted communicators are freed by the abort)
+        (void)drained(2.0);
+    }
 }
 int rccl_allreduce_on(lbfgs_hip_ctx* ctx, double* buf, int count, hipStream_t stream) {
     const int rc = g_rccl.AllReduce(buf, buf, (size_t)count, kNcclDouble, kNcclSum, ctx->nccl, stream);
@@ -973,6 +1038,7 @@ void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* ctx) {
     ext_abort(ctx);  // (a gated chain that is still waiting for a kernel that will never come)
     if (ctx->nccl && g_rccl.ok) g_rccl.CommDestroy(ctx->nccl);
     if (ctx->xstream) (void)hipStreamDestroy(ctx->xstream);
+    if (ctx->ext_ev) (void)hipEventDestroy(ctx->ext_ev);
     if (ctx->ext_block) uc_mbox_retire(ctx->device, ctx->ext_block);
     for (int r = 0; r < P2P_MAX_WORLD; ++r) {
         if (!ctx->p2p_mbox[r]) continue;

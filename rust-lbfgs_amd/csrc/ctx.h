@@ -110,8 +110,13 @@ struct lbfgs_hip_ctx {
     bool gran_pooled = false;             // ... in an uncached block of the process-wide pool (returned there, never freed)
     bool p2p_exclusive = false;           // lbfgs_hip_comm.exclusive_device: no other rank shares this GPU
     // GATED exchange (RCCL under the persistent two-loop kernel; stream.h ext_exchange, lbfgs_hip.hip enqueue_gated_chain)
-    int rccl_resident = 1;                // LBFGS_HIP_RCCL_RESIDENT=0: under RCCL the two-loop always runs with a kernel per step
+    int rccl_resident = 0;                // LBFGS_HIP_RCCL_RESIDENT=1 OPTS IN to the gated exchange under RCCL (the persistent two-loop kernel
+                                          // served by ncclAllReduce on a second stream).  Off by default: it has never run with more than
+                                          // one rank (a single GPU hosts a 1-rank communicator only); bench.py's "rccl" leg opts in inside a
+                                          // child job with a timeout.  Off: under RCCL the two-loop runs with a kernel per step
     hipStream_t xstream = nullptr;        // the second stream: gate -> ncclAllReduce -> post, one triple per exchange
+    hipEvent_t ext_ev = nullptr;          // recorded on the compute stream just before a gated persistent kernel; the chain's first gate
+                                          // waits for it, so its timeout does not run while the kernel is still queued behind earlier work
     unsigned long long* ext_block = nullptr;  // one uncached block: flags A, B, abort at words 0..2, the ring of exchange slots at byte 256
     unsigned long long ext_launches = 0;  // gated launches so far (the abort word names the launch that is given up)
     unsigned long long resident_attr_mask = 0;  // which resident kernels have had their dynamic-LDS limit raised on this device
@@ -143,7 +148,9 @@ struct lbfgs_hip_ctx {
     } last_res;
     unsigned long long resident_fallbacks = 0;  // how often that happened
     int resident_fault = 0;               // LBFGS_HIP_RESIDENT_FAULT=k (tests): the k-th resident launch of this context loses its last workgroup;
-                                          // -1: this rank reports the gated exchange's self-test as failed (context.hip ext_prepare)
+                                          // -1: this rank reports the gated exchange's self-test as failed (context.hip ext_prepare);
+                                          // -2 / -3: this rank fails LOCALLY before the handshake / before the trial (it must still
+                                          // take part in every collective of ext_prepare and hand the error back afterwards)
     bool defer_inner_sums = true;         // LBFGS_HIP_DEFER_SUMS=0: the two-loop's inner dots are reduced by their own kernels (A/B)
     double* dot_parts = nullptr;          // 2 x MAX_GRID: workgroup partials of the two-loop's inner dot products (ping-pong)
     DevCounters* dev_ctr = nullptr;       // device-resident sequence numbers (stream.h); the three fields below shadow them
@@ -205,7 +212,8 @@ LH_INTERNAL int ext_prepare(lbfgs_hip_ctx* ctx);
 LH_INTERNAL void ext_abort(lbfgs_hip_ctx* ctx);
 LH_INTERNAL int rccl_allreduce_on(lbfgs_hip_ctx* ctx, double* buf, int count, hipStream_t stream);
 // (lbfgs_hip.hip) one exchange of the gated form under a chip-wide kernel, on the context's own communicator; collective
-LH_INTERNAL int ext_selftest_resident(lbfgs_hip_ctx* ctx, bool* ok);
+LH_INTERNAL int ext_selftest_resident(lbfgs_hip_ctx* ctx, bool* ok, bool* enqueued);
+LH_INTERNAL bool resident_shard_eligible(lbfgs_hip_ctx* ctx);  // this rank's shard and device can take the persistent kernel under the gated exchange
 
 // ---- profiling: one event pair per launch of a timed class --------------------------------
 struct ProfScope {

@@ -21,6 +21,12 @@ namespace {
 // ---- launch one operator ---------------------------------------------------------------------
 // partials_only (Op::NRED == 1, single rank): the kernel leaves its workgroups' partial sums in red_out[0][0 .. grid) and
 // nobody reduces them -- the consumer does (stream.h RedCtl::tagged == 2); *grid_out receives the number of partials.
+// ALIASING CONTRACT: an output stream may BE an input stream (y += c x; OpObjOwlLineEval<Obj, true> reads the previous
+// pseudo-gradient through in[2] and writes the new one through out[2], the same buffer).  That is sound because the skeleton
+// (stream.h stream_sweep) loads ALL inputs of an element -- of a whole trip -- before it stores any output of that element, every
+// element is touched by exactly one thread, and neither in[] nor out[] is declared __restrict__; the `nt` hint is a cache
+// policy, not a promise of no aliasing.  An operator must not read, for element i, an input that aliases an output at another
+// index j != i.  Held by test_fused_owlqn_kernels_equal_their_unfused_sequences (bitwise, odd n, every cache-hint regime).
 template <class Op>
 int launch(lbfgs_hip_ctx* ctx, int kclass, const Op& op, double* const* red_out, double* dup_ptr = nullptr,
            int dup_k = 0, bool partials_only = false, unsigned int* grid_out = nullptr) {
@@ -263,9 +269,9 @@ int gram_combine_resident(lbfgs_hip_ctx* ctx, const double* const* cols, int nb,
     for (int j = 0; j < nb; ++j) a.in[j] = cols[j];
     a.d = d; a.delta = delta; a.n = n; a.nb = nb;
     a.pred = pred;
-    // the rank that owns global element 0 carries the prediction into the third and fourth sums: exactly ONE rank (an empty
-    // rank 0 and its successor both have offset 0: the all-reduced prediction would double and every direction fail its check)
-    a.lead = (ctx->shard.offset == 0 && n > 0) ? 1 : 0;
+    // the rank that owns global element 0 carries the prediction into the third and fourth sums (this kernel only runs on
+    // shards of at least two elements; an EMPTY rank 0 takes the streaming combine, which keys on the element index itself)
+    a.lead = ctx->shard.offset == 0 ? 1 : 0;
     a.total_rounds = (uint32_t)total;
     a.tile_rounds = (uint32_t)tile;
     RedCtl red{};
@@ -809,6 +815,9 @@ int enqueue_gated_chain(lbfgs_hip_ctx* ctx, unsigned long long first_exchange, i
     ga.abort_id = ctx->ext_launches;
     ga.timeout_ticks = ctx->p2p_timeout_ticks + ctx->handoff_timeout_ticks;  // (the kernel may itself be waiting for its workgroups)
     ga.post_epoch = 0;
+    // the first gate starts its clock when the persistent kernel is about to start, not while that kernel is still queued behind
+    // earlier work of the compute stream (which may be the caller's own stream): two_loop_resident recorded ext_ev just before it
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->xstream, ctx->ext_ev, 0));
     for (int i = 0; i < handoffs; ++i) {
         const unsigned long long e = epoch_of(first_exchange + (unsigned long long)i);
         ga.gate_epoch = e;
@@ -860,8 +869,9 @@ __global__ __launch_bounds__(BLOCK) void ext_selftest_resident_kernel(const P2PC
 }
 
 }  // namespace
-int ext_selftest_resident(lbfgs_hip_ctx* ctx, bool* ok) {
+int ext_selftest_resident(lbfgs_hip_ctx* ctx, bool* ok, bool* enqueued) {
     *ok = false;
+    *enqueued = false;  // (has this rank's all-reduce of the trial been handed to RCCL?  Its peers wait for it: ext_prepare)
     constexpr unsigned long long EPOCH = 0x7E57ull;         // (any non-zero epoch: the words are cleared again below)
     constexpr unsigned long long TICKS = 100000000ull;      // 1 s of the 100 MHz wall clock
     unsigned long long* const w = ctx->ext_block;           // words: 0 A, 1 B, 2 abort, (3, 4: the stream handshake), 5 done, 6 sum, 7 err
@@ -889,6 +899,7 @@ int ext_selftest_resident(lbfgs_hip_ctx* ctx, bool* ok) {
     ga.gate_epoch = EPOCH;
     hipLaunchKernelGGL(ext_post_gate_kernel, dim3(1), dim3(64), 0, ctx->xstream, ga);
     const int rc = rccl_allreduce_on(ctx, slot, 1, ctx->xstream);
+    *enqueued = true;
     ga.post_epoch = EPOCH;
     ga.gate_epoch = 0;
     hipLaunchKernelGGL(ext_post_gate_kernel, dim3(1), dim3(64), 0, ctx->xstream, ga);  // (also after a failed enqueue: the kernel is let go)
@@ -911,31 +922,25 @@ int ext_selftest_resident(lbfgs_hip_ctx* ctx, bool* ok) {
 }
 namespace {
 
-// -> 1 if the recursion was launched as the resident kernel, 0 if this case is not eligible (caller falls back), < 0 error
-int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
-                      int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end, bool owl,
-                      uint64_t owl_start, uint64_t owl_end) {
-    lbfgs_hip_ctx* ctx = h->ctx;
-    const int m = h->m;
-    const int bound = (int)std::min<uint64_t>((uint64_t)m, k);
-    // One rank -- or several that each have their GPU to themselves: a kernel that fills the chip and waits for its peers
-    // inside would starve ranks sharing the GPU (lbfgs_hip_comm.exclusive_device).
-    // Under RCCL the exchange is GATED (stream.h ext_exchange): ncclAllReduce only exists as a host-enqueued kernel, so the host
-    // enqueues one per hand-off on a second stream, each behind a gate kernel that waits for this kernel's flag -- q stays on the chip.
-    const bool gated = ctx->comm_kind == LBFGS_HIP_COMM_RCCL && ctx->rccl_resident && ctx->p2p_exclusive && ctx->xstream && ctx->ext_block;
-    const bool comm_ok = ctx->comm_kind == LBFGS_HIP_COMM_NONE || (ctx->comm_kind == LBFGS_HIP_COMM_P2P && ctx->p2p_exclusive) || gated;
-    if (!ctx->resident_on || !comm_ok || ctx->handoff_ticket || bound < 1 || ctx->grid_override > 0 ||
-        2 * bound > RES_MAX_STEPS)
-        return 0;
-    // (gated: lbfgs_hip_ctx_create made the second stream and the uncached block, proved that both streams are served concurrently
-    // -- else rccl_resident is off -- and let RCCL run its first collective on that stream)
+// What two_loop_resident decides from the SHARD and the DEVICE alone (nothing of the call: bound and the tag wrap are the same
+// on every rank).  Under the gated RCCL exchange every rank must take the same launch form -- a rank with a kernel per step
+// next to ranks with gated chains would pair its all-reduces wrongly -- so lbfgs_hip_ctx_create evaluates exactly this on every
+// rank and the ranks agree on it (resident_shard_eligible, context.hip ext_prepare).
+constexpr int RES_ER_MAX = 60;
+struct ResPlan {
+    int grid, er;            // workgroups; register rounds of the instantiation
+    uint64_t per_round, E;   // 16-byte pairs per round of the grid; rounds (pairs per thread)
+    bool hybrid;             // the shard does not fit the chip: rounds beyond er + el stay in HBM
+    uint32_t eh, el;         // rounds whose q stays in HBM; rounds in LDS
+};
+bool resident_plan(const lbfgs_hip_ctx* ctx, bool gated, ResPlan* pl) {
     // one workgroup per CU: all of them resident at once (fewer on request -- tests run two ranks on one GPU -- and for
     // vectors of a few MB, where a hand-off among fewer workgroups is worth more than the idle CUs' bandwidth: >= 8 pairs per
     // thread, at least 64 workgroups; measured at n = 1e5 / 3e5 / 1e6, profiles/r02_resident_small_n.log)
     const uint64_t n = ctx->shard.n_local;
     // ... and 27/32 of the CUs, the streaming kernels' grid, once less than a fifth of a shard fits the chip and
     // the kernel is a streaming kernel above all (n = 1e8: 9.73 ms against 9.83 with 256; at 2.5e7 256 wins by 4 %)
-    const bool mostly_streaming = (n >> 1) > 5ull * (uint64_t)(60 + RES_LDS_PAIRS_MAX) * (uint64_t)ctx->cu_count * BLOCK;
+    const bool mostly_streaming = (n >> 1) > 5ull * (uint64_t)(RES_ER_MAX + RES_LDS_PAIRS_MAX) * (uint64_t)ctx->cu_count * BLOCK;
     const int grid_auto = mostly_streaming ? std::max(1, ctx->cu_count * 27 / 32)
         : (int)std::min<uint64_t>((uint64_t)ctx->cu_count, std::max<uint64_t>(64, ((n >> 1) + BLOCK * 8 - 1) / (BLOCK * 8)));
     // (gated: RCCL's kernel and the gates need CUs of their own while this kernel waits -- one per XCD is left free, workgroups
@@ -944,22 +949,26 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     // all on the chip was measured and is no better: 783 us against 755 us for the hybrid launch on 248, profiles/r05_rccl_one_rank.log)
     const int grid_cap = gated ? std::max(1, ctx->cu_count - 8) : ctx->cu_count;
     const int grid = std::min(ctx->resident_grid > 0 ? std::min(ctx->resident_grid, ctx->cu_count) : grid_auto, grid_cap);
-    if (grid < 1 || grid > BLOCK || grid > MAX_GRID) return 0;  // (every thread polls one workgroup's granules)
+    if (grid < 1 || grid > BLOCK || grid > MAX_GRID) return false;  // (every thread polls one workgroup's granules)
     const uint64_t per_round = (uint64_t)grid * BLOCK;
     const uint64_t E = ((n >> 1) + per_round - 1) / per_round;  // 16-byte pairs per thread
-    constexpr int ER_MAX = 60;
     // Larger shards: HYBRID -- the first 60 + 36 rounds of every thread stay on the chip, the rest of q lives in `d` and is
     // streamed by every step as on the kernel-per-step path (resident.h).
-    const bool hybrid = E > (uint64_t)(ER_MAX + RES_LDS_PAIRS_MAX);
-    if (hybrid && !ctx->resident_hybrid) return 0;
-    if (E == 0 || (n >> 1) + per_round * 4 >= (1ull << 28)) return 0;
-    if (ctx->red_count % 0xFFFFFFFFull + 2ull * (uint64_t)bound + 4ull >= 0xFFFFFFFFull) return 0;  // tag wrap: eager path
+    const bool hybrid = E > (uint64_t)(RES_ER_MAX + RES_LDS_PAIRS_MAX);
+    if (hybrid && !ctx->resident_hybrid) return false;
+    if (E == 0 || (n >> 1) + per_round * 4 >= (1ull << 28)) return false;
     // Rounds 0 .. E-2 are full for every thread, round E-1 is the ragged one.  The register rounds carry no bounds checks,
     // so ER <= E-1; the rest (the ragged round included) lives in LDS -- everything, for the smallest vectors (ER = 0).
-    const int er = E - 1 >= ER_MAX ? ER_MAX : E - 1 >= 40 ? 40 : E - 1 >= 24 ? 24 : E - 1 >= 8 ? 8 : 0;
-    const uint32_t eh = hybrid ? (uint32_t)(E - ER_MAX - RES_LDS_PAIRS_MAX) : 0u;  // rounds whose q stays in HBM
+    const int er = E - 1 >= RES_ER_MAX ? RES_ER_MAX : E - 1 >= 40 ? 40 : E - 1 >= 24 ? 24 : E - 1 >= 8 ? 8 : 0;
+    const uint32_t eh = hybrid ? (uint32_t)(E - RES_ER_MAX - RES_LDS_PAIRS_MAX) : 0u;  // rounds whose q stays in HBM
     const uint32_t el = hybrid ? (uint32_t)RES_LDS_PAIRS_MAX : (uint32_t)((E - er + RES_UNROLL - 1) / RES_UNROLL * RES_UNROLL);
-    if (el > (uint32_t)RES_LDS_PAIRS_MAX) return 0;
+    if (el > (uint32_t)RES_LDS_PAIRS_MAX) return false;
+    *pl = ResPlan{grid, er, per_round, E, hybrid, eh, el};
+    return true;
+}
+// once per context: can this device hold one such workgroup per CU, and does this queue reach every CU?
+bool resident_device_ok(lbfgs_hip_ctx* ctx) {
+    constexpr int ER_MAX = RES_ER_MAX;
     if (ctx->resident_ok < 0) {  // once: can this device hold one such workgroup per CU?
         int nb = 0;
         const size_t lds_max = (size_t)RES_LDS_PAIRS_MAX * BLOCK * sizeof(d2);
@@ -995,7 +1004,45 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
             fprintf(stderr, "[lbfgs_hip] resident two-loop kernel: %s (%s, %d workgroup(s) per CU with %zu bytes of LDS)\n",
                     ctx->resident_ok ? "usable" : "not usable", hipGetErrorString(e), nb, lds_max);
     }
-    if (ctx->resident_ok != 1) return 0;
+    return ctx->resident_ok == 1;
+}
+}  // namespace
+// (context.hip ext_prepare: this rank's vote on the gated form)
+bool resident_shard_eligible(lbfgs_hip_ctx* ctx) {
+    ResPlan pl{};
+    return ctx->resident_on && !ctx->handoff_ticket && ctx->grid_override == 0 && resident_plan(ctx, true, &pl) && resident_device_ok(ctx);
+}
+namespace {
+
+// -> 1 if the recursion was launched as the resident kernel, 0 if this case is not eligible (caller falls back), < 0 error
+int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_vec* g, uint64_t k, int end,
+                      int gamma_num_slot, int gamma_den_slot, int dnorm_slot, int first_dot_slot, int* new_end, bool owl,
+                      uint64_t owl_start, uint64_t owl_end) {
+    lbfgs_hip_ctx* ctx = h->ctx;
+    const int m = h->m;
+    const int bound = (int)std::min<uint64_t>((uint64_t)m, k);
+    // One rank -- or several that each have their GPU to themselves: a kernel that fills the chip and waits for its peers
+    // inside would starve ranks sharing the GPU (lbfgs_hip_comm.exclusive_device).
+    // Under RCCL the exchange is GATED (stream.h ext_exchange): ncclAllReduce only exists as a host-enqueued kernel, so the host
+    // enqueues one per hand-off on a second stream, each behind a gate kernel that waits for this kernel's flag -- q stays on the chip.
+    const bool gated = ctx->comm_kind == LBFGS_HIP_COMM_RCCL && ctx->rccl_resident && ctx->p2p_exclusive && ctx->xstream && ctx->ext_block && ctx->ext_ev;
+    const bool comm_ok = ctx->comm_kind == LBFGS_HIP_COMM_NONE || (ctx->comm_kind == LBFGS_HIP_COMM_P2P && ctx->p2p_exclusive) || gated;
+    if (!ctx->resident_on || !comm_ok || ctx->handoff_ticket || bound < 1 || ctx->grid_override > 0 ||
+        2 * bound > RES_MAX_STEPS)
+        return 0;
+    // (gated: lbfgs_hip_ctx_create made the second stream and the uncached block, proved that both streams are served concurrently
+    // -- else rccl_resident is off --, let RCCL run its first collective on that stream, and the ranks have AGREED that every
+    // shard and every device can take this form: resident_shard_eligible below, context.hip ext_prepare)
+    ResPlan pl{};
+    if (!resident_plan(ctx, gated, &pl)) return 0;
+    if (ctx->red_count % 0xFFFFFFFFull + 2ull * (uint64_t)bound + 4ull >= 0xFFFFFFFFull) return 0;  // tag wrap: eager path
+    if (!resident_device_ok(ctx)) return 0;
+    const uint64_t n = ctx->shard.n_local;
+    const int grid = pl.grid, er = pl.er;
+    const uint64_t per_round = pl.per_round, E = pl.E;
+    const bool hybrid = pl.hybrid;
+    const uint32_t eh = pl.eh, el = pl.el;
+    constexpr int ER_MAX = RES_ER_MAX;
 
     ProfScope whole(ctx, LBFGS_HIP_K_TWOLOOP_ALL);
     const int e1 = (end + 1) % m;                                   // lbfgs.rs:577
@@ -1102,6 +1149,7 @@ int two_loop_resident(lbfgs_hip_history* h, lbfgs_hip_vec* d, const lbfgs_hip_ve
     const bool nt = n * sizeof(double) >= ctx->resident_nt_bytes;
     const size_t lds_bytes = (size_t)el * BLOCK * sizeof(d2);
     int rc;
+    if (gated) HIP_TRY(ctx, hipEventRecord(ctx->ext_ev, ctx->stream));  // (enqueue_gated_chain: the chain's first gate waits for it)
     {
         ProfScope ps(ctx, LBFGS_HIP_K_TWOLOOP_RESIDENT);
         switch (er) {

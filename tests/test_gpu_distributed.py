@@ -550,3 +550,47 @@ def test_rccl_gated_exchange_is_proven_at_context_creation_or_not_used(monkeypat
         for u, v in zip(a[2:], b[2:]):
             assert abs(u - v) <= 1e-11 * max(abs(u), 1e-6), (a, b)
     assert np.max(np.abs(xf - xg)) <= 1e-11 * np.max(np.abs(xg))
+
+
+def test_rccl_gated_exchange_is_opt_in_and_a_local_failure_is_returned_after_the_collectives(monkeypatch):
+    """Round-5 advice.  (1) The gated exchange has never run with more than one rank, so the library's default under RCCL is
+    the kernel-per-step form: LBFGS_HIP_RCCL_RESIDENT=1 opts in (bench.py's "rccl" leg does, inside a child job with a timeout).
+    (2) lbfgs_hip_ctx_create's preparation of the gated exchange is COLLECTIVE -- agree, warm-up all-reduce, trial, agree -- and a
+    rank that fails locally between those steps (stream creation, allocation, the trial's launch) must not return before the last
+    of them: its peers would wait inside ncclAllReduce for ever.  Injected here on the only rank a single GPU can host: the
+    context is refused with the local error, after every collective has been made (it does not hang, and the next context on
+    the same device works)."""
+    if os.environ.get("LBFGS_TEST_BACKEND") == "mock":
+        pytest.skip("needs RCCL and the GPU")
+    from rust_lbfgs_amd import objectives
+    from rust_lbfgs_amd.dist import CommSpec
+
+    L = _ffi.load()
+    _ffi.torch_before_rccl()
+    n, m, iters = 1_300_003, 6, 8
+
+    def make():
+        buf = (C.c_char * 128)()
+        assert L.lbfgs_hip_rccl_unique_id(buf) == 0, L.lbfgs_hip_last_error(None)
+        spec = CommSpec(_ffi.COMM_RCCL, unique_id=buf)
+        spec.c.exclusive_device = 1
+        return R.Context(n, shard=_ffi.Shard(0, 1, n, 0, n), comm=spec)
+
+    def run():
+        with make() as ctx:
+            x = np.zeros(n)
+            R.lbfgs().with_m(m).with_epsilon(0.0).with_max_iterations(iters).minimize(x, objectives.Quadratic(), lambda p: False, ctx=ctx)
+            return ctx.resident_two_loops()
+
+    monkeypatch.delenv("LBFGS_HIP_RCCL_RESIDENT", raising=False)
+    monkeypatch.delenv("LBFGS_HIP_RESIDENT_FAULT", raising=False)
+    assert run() == 0                                   # default: a kernel per step
+    monkeypatch.setenv("LBFGS_HIP_RCCL_RESIDENT", "1")
+    assert run() == iters - 1                           # opted in: every two-loop with history ran as the persistent kernel
+    for fault, says in (("-2", "second stream"), ("-3", "before the gated exchange's trial")):
+        monkeypatch.setenv("LBFGS_HIP_RESIDENT_FAULT", fault)
+        with pytest.raises(R.LbfgsError) as ei:
+            make()
+        assert "injected" in str(ei.value) and says in str(ei.value), str(ei.value)
+    monkeypatch.delenv("LBFGS_HIP_RESIDENT_FAULT")
+    assert run() == iters - 1

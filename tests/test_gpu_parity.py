@@ -948,10 +948,13 @@ def test_random_sweep_compared_what_it_claims():
     assert cov["loosest_tol"] <= 2.1e-8, cov   # (FACTOR x CHAOS x the vector-free slack = 4 x 1e-9 x 5)
 
 
-@pytest.mark.parametrize("n", [7, 1001, 70001])
+@pytest.mark.parametrize("n", [7, 1001, 70001, 8_500_003, 17_000_001])
 def test_fused_owlqn_kernels_equal_their_unfused_sequences(n):
     """objective_owlqn_line_eval == line_step(project) + objective_eval + owlqn_post_eval + dot, and
-    two_loop_owlqn == two_loop + constrain_direction: vectors bit for bit, sums to rounding."""
+    two_loop_owlqn == two_loop + constrain_direction: vectors bit for bit, sums to rounding.
+    (The first-trial kernel reads the previous pseudo-gradient and writes the new one through the SAME buffer -- the aliasing
+    contract stated at lbfgs_hip.hip launch().  Sizes: odd n, not a multiple of the 16-byte vector width; 8.5e6 = the regime with
+    `nt` stores (>= 64 MiB vectors), 1.7e7 = the streaming regime (`nt` loads and stores, another instantiation of the skeleton).)"""
     r = np.random.default_rng(n)
     xp_h, d_h = 0.3 * rnd(n, 41), rnd(n, 42)
     xp_h[r.random(n) < 0.3] = 0.0
