@@ -296,6 +296,19 @@ def collect_cpu_baseline(child, a, timeout=420.0):
 
 
 # ======================================================================================== one rank
+def pick_device(local_rank, forced, visible):
+    """The device index of this rank.  One process per GPU: LOCAL_RANK -- unless the launcher has masked the devices per rank
+    (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = one GPU each), when every rank sees fewer devices than there are local ranks
+    and its own is among the ones it sees: LOCAL_RANK modulo that count (0 with one device each).  Such ranks cannot map each
+    other's device memory: the "p2p" probe then fails with the IPC error and the run goes on with host-placed mailboxes and RCCL.
+    `forced` (--device, tests: several ranks on one card) wins."""
+    if forced >= 0:
+        return forced
+    if visible > 0 and local_rank >= visible:
+        return local_rank % visible
+    return local_rank
+
+
 class Env:
     """rank / world / torch.distributed plumbing (only rendezvous, barriers and a max over ranks)."""
 
@@ -314,6 +327,15 @@ class Env:
             import torch.distributed as dist
 
             self.torch, self.dist = torch, dist
+            try:  # (counting devices does not initialise the GPU)
+                visible = int(torch.cuda.device_count())
+            except Exception:  # noqa: BLE001
+                visible = 0
+            dev = pick_device(self.local_rank, a.device, visible)
+            if dev != self.dev:
+                print(f"[bench] rank {self.rank}: LOCAL_RANK {self.local_rank} but {visible} visible device(s): the launcher masks "
+                      f"devices per rank; taking device {dev}", file=sys.stderr)
+                self.dev = dev
             torch.cuda.set_device(self.dev)
             if self.backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.dev))
@@ -640,12 +662,17 @@ COMM_CLASSED = ("timed_exchanges", "exchange_us", "local_wait_us")
 
 def comm_counters_add(acc, before, after):
     """acc += (after - before) over the counters of Context.comm_info()"""
-    acc = acc or {**{k: 0 for k in COMM_COUNTERS}, **{k: {"other": 0, "two_loop": 0} for k in COMM_CLASSED}}
+    acc = acc or {**{k: 0 for k in COMM_COUNTERS}, **{k: {"other": 0, "two_loop": 0} for k in COMM_CLASSED}, "exchange_hist": None}
     for k in COMM_COUNTERS:
         acc[k] += after[k] - before[k]
     for k in COMM_CLASSED:
         for c in ("other", "two_loop"):
             acc[k][c] += after[k][c] - before[k][c]
+    if after.get("exchange_hist"):  # (ABI 5: exchanges by duration; the test double has none)
+        h = acc["exchange_hist"] or {c: [0] * len(after["exchange_hist"][c]) for c in ("other", "two_loop")}
+        for c in ("other", "two_loop"):
+            h[c] = [x + (y - z) for x, y, z in zip(h[c], after["exchange_hist"][c], before["exchange_hist"][c])]
+        acc["exchange_hist"] = h
     return acc
 
 
@@ -680,6 +707,21 @@ def exchange_figures(ctx, ci_sum, roof):
         comm["exchange_timing"] = "HIP events around the grouped ncclAllReduce launches on the compute stream (all of them, not only the two-loop's)"
     else:
         comm["exchange_us_mean"] = comm["local_wait_us_mean"] = None
+    # the DISTRIBUTION of the exchanges inside two-loops over the timed regions (device histogram, lbfgs_hip_comm_info ABI 5):
+    # one real multi-GPU run then places the leg on profiles/r05_scaling_model.md's latency axis -- its columns are per-exchange
+    # latencies L, and a mean hides whether 1 exchange in 100 waited for a straggler
+    hist = (z.get("exchange_hist") or {}).get("two_loop")
+    if hist and sum(hist) > 0:
+        from rust_lbfgs_amd.api import exchange_quantile
+
+        comm["exchange_us_p50"] = exchange_quantile(hist, 0.50)
+        comm["exchange_us_p99"] = exchange_quantile(hist, 0.99)
+        comm["exchange_hist_counted"] = sum(hist)
+    else:
+        comm["exchange_us_p50"] = comm["exchange_us_p99"] = None
+    # (maxima cannot be differenced: since the context was created, warm-up and start-up self-tests included)
+    comm["exchange_us_max_since_start"] = (ci.get("exchange_us_max") or {}).get("two_loop")
+    comm["local_wait_us_max_since_start"] = (ci.get("local_wait_us_max") or {}).get("two_loop")
     other = dd("timed_exchanges", "other")
     comm["exchange_us_mean_outside_two_loop"] = (dd("exchange_us", "other") / other) if other else None
     roof["exchange_us_mean"] = comm["exchange_us_mean"]
@@ -1462,7 +1504,9 @@ def supervisor_main(a):
             ci = j["config"].get("comm_info") or {}
             report[leg].update(ranks_seen=ci.get("ranks_seen"), mailboxes_mapped=(ci.get("peers_device"), ci.get("peers_host")),
                                mailbox_placement=ci.get("mailbox_placement"), exchange_us_mean=ci.get("exchange_us_mean"),
-                               local_wait_us_mean=ci.get("local_wait_us_mean"),
+                               exchange_us_p50=ci.get("exchange_us_p50"), exchange_us_p99=ci.get("exchange_us_p99"),
+                               exchange_us_max=ci.get("exchange_us_max_since_start"),
+                               local_wait_us_mean=ci.get("local_wait_us_mean"), local_wait_us_max=ci.get("local_wait_us_max_since_start"),
                                exchanges_per_two_loop=ci.get("exchanges_per_two_loop"),
                                two_loop_ms=((j.get("roofline") or {}).get("two_loop") or {}).get("ms"))
         if j:

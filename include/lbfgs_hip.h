@@ -39,7 +39,9 @@
 extern "C" {
 #endif
 
-/* 4: lbfgs_evaluator (lbfgs_solver.h) grew device_probe / device_accept: deferred trial points for device closures;
+/* 5: lbfgs_hip_comm_info grew the DISTRIBUTION of the cross-rank exchanges (exchange_us_max, local_wait_us_max,
+ *    exchange_hist): one multi-GPU run is then enough to place a leg on the scaling model's latency axis (round 6).
+ * 4: lbfgs_evaluator (lbfgs_solver.h) grew device_probe / device_accept: deferred trial points for device closures;
  *    lbfgs_hip_objective_owlqn_first_trial (round 5).
  * 3: lbfgs_hip_ctx_comm_info / lbfgs_hip_comm_info (round 4); lbfgs_hip_sync, lbfgs_hip_vec_download and
  *    lbfgs_hip_history_scalars_read report device errors (and recover from a timed-out resident two-loop) like
@@ -47,7 +49,7 @@ extern "C" {
  * 2: lbfgs_hip_objective.skin, lbfgs_hip_comm.exclusive_device, LBFGS_HIP_K_TWOLOOP_RESIDENT (all round 2, unversioned then),
  *    mailbox placements, lbfgs_hip_build_id.  A caller compares lbfgs_hip_abi_version() with the constant it was built
  *    against before anything else (rust-lbfgs_amd/_ffi.py, integration/rust-shim, tests/support/c_caller.c do). */
-#define LBFGS_HIP_ABI_VERSION 4
+#define LBFGS_HIP_ABI_VERSION 5
 #define LBFGS_HIP_BOARD_SLOTS 256
 
 /* status codes */
@@ -144,6 +146,7 @@ int lbfgs_hip_get_shard(const lbfgs_hip_ctx* ctx, lbfgs_hip_shard* out);
 /* What the communicator of this context really spans, and what its exchanges cost -- so that a multi-GPU measurement can be
  * cross-checked ("did RCCL see N ranks?") and a scaling shortfall attributed ("how long does one exchange take?").
  * Synchronises the stream. */
+#define LBFGS_HIP_XCHG_BINS 48
 typedef struct lbfgs_hip_comm_info {
     int32_t kind;               /* LBFGS_HIP_COMM_* */
     int32_t world, rank;        /* the shard this context was created with */
@@ -166,6 +169,12 @@ typedef struct lbfgs_hip_comm_info {
     double exchange_us[2];       /* total time inside the exchange proper: stores to every peer's mailbox + wait for every
                                     peer's values (includes waiting for a peer that arrives later) */
     double local_wait_us[2];     /* total time that workgroup waited for this GPU's other workgroups before it */
+    /* ... and their distribution (ABI 5), same classes: */
+    double exchange_us_max[2];   /* the longest single exchange */
+    double local_wait_us_max[2]; /* the longest single wait for this GPU's own workgroups */
+    uint32_t exchange_hist[2][LBFGS_HIP_XCHG_BINS]; /* exchanges by duration: bin b < 32 covers [b/4, (b+1)/4) us; bin 32 + k covers
+                                    [8 * 2^k, 8 * 2^(k+1)) us, the last one everything beyond (quantiles: rust-lbfgs_amd/api.py
+                                    exchange_quantile; bench.py reports p50 / p99 per leg) */
 } lbfgs_hip_comm_info;
 int lbfgs_hip_ctx_comm_info(lbfgs_hip_ctx* ctx, lbfgs_hip_comm_info* out);
 /* launch geometry override for tuning (0 = default): blocks, i.e. workgroups per launch */

@@ -10,7 +10,7 @@ use std::os::raw::{c_char, c_int, c_void};
 
 /// `LBFGS_HIP_ABI_VERSION` of the `include/lbfgs_hip.h` these declarations mirror; `Context::new` refuses a library
 /// that reports another one (struct layouts are shared by value).
-pub const LBFGS_HIP_ABI_VERSION: i32 = 4;
+pub const LBFGS_HIP_ABI_VERSION: i32 = 5;
 pub const LBFGS_HIP_OK: c_int = 0;
 pub const LBFGS_ERR_EVALUATE: c_int = -1;
 pub const LBFGS_PANIC_OWLQN_RANGE: c_int = -20;
@@ -159,8 +159,9 @@ pub struct lbfgs_report {
 }
 
 /// `lbfgs_hip_comm_info` (include/lbfgs_hip.h): what the communicator spans and what its exchanges cost.
+pub const LBFGS_HIP_XCHG_BINS: usize = 48;
 #[repr(C)]
-#[derive(Clone, Copy, Default)]
+#[derive(Clone, Copy)]
 pub struct lbfgs_hip_comm_info {
     pub kind: i32,
     pub world: i32,
@@ -180,6 +181,10 @@ pub struct lbfgs_hip_comm_info {
     pub timed_exchanges: [u64; 2],
     pub exchange_us: [f64; 2],
     pub local_wait_us: [f64; 2],
+    // ABI 5: the distribution behind those totals (bins: include/lbfgs_hip.h)
+    pub exchange_us_max: [f64; 2],
+    pub local_wait_us_max: [f64; 2],
+    pub exchange_hist: [[u32; LBFGS_HIP_XCHG_BINS]; 2],
 }
 
 extern "C" {

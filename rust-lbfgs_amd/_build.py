@@ -28,7 +28,7 @@ RESOURCES = os.path.join(HERE, "liblbfgs_hip.resources.txt")  # per-kernel regis
 # the library's translation units (compiled one by one, in parallel, then linked) ...
 HIP_UNITS = [os.path.join(CSRC, f) for f in ("context.hip", "lbfgs_hip.hip", "lj.hip")]
 # ... and everything the build id covers: the units, the headers they share, the public header
-HIP_SRCS = HIP_UNITS + [os.path.join(CSRC, f) for f in ("ctx.h", "ops.h", "stream.h", "gram.h", "lj.h", "resident.h", "gram_combine.h")] + [
+HIP_SRCS = HIP_UNITS + [os.path.join(CSRC, f) for f in ("ctx.h", "ops.h", "stream.h", "gram.h", "lj.h", "resident.h", "gram_combine.h", "ext_protocol.h")] + [
     os.path.join(ROOT, "include", "lbfgs_hip.h")
 ]
 SOLVER_SRCS = [os.path.join(CSRC, "host", "solver.cpp"), os.path.join(ROOT, "include", "lbfgs_solver.h"),

@@ -24,7 +24,7 @@ LS_MORETHUENTE, LS_BT_ARMIJO, LS_BT_STRONGWOLFE, LS_BT_WOLFE = 0, 1, 2, 3
 EVAL_HOST, EVAL_DEVICE, EVAL_BUILTIN = 0, 1, 2
 COMM_NONE, COMM_RCCL, COMM_CALLBACK, COMM_P2P = 0, 1, 2, 3
 MAILBOX_AUTO, MAILBOX_DEVICE, MAILBOX_HOST = -1, 0, 1
-ABI_VERSION = 4  # LBFGS_HIP_ABI_VERSION of the include/lbfgs_hip.h these declarations were written against
+ABI_VERSION = 5  # LBFGS_HIP_ABI_VERSION of the include/lbfgs_hip.h these declarations were written against
 OBJ_QUADRATIC, OBJ_LOGISTIC, OBJ_ROSENBROCK, OBJ_LJ_ALLPAIRS, OBJ_LJ_NEIGHBORS, OBJ_LJ_CELLS = 1, 2, 3, 4, 5, 6
 (K_TWOLOOP_STEP, K_TWOLOOP_EDGE, K_UPDATE, K_LINE, K_EVAL, K_OWLQN, K_BLAS1, K_COMM, K_TWOLOOP_ALL,
  K_TWOLOOP_RESIDENT) = range(10)
@@ -46,6 +46,9 @@ class Comm(C.Structure):
                 ("p2p_mailbox", C.c_void_p), ("p2p_handles", C.c_void_p), ("p2p_timeout_s", C.c_double)]
 
 
+XCHG_BINS = 48  # LBFGS_HIP_XCHG_BINS
+
+
 class CommInfo(C.Structure):
     """lbfgs_hip_comm_info: what the communicator really spans and what its exchanges cost (lbfgs_hip_ctx_comm_info)."""
     _fields_ = [("kind", C.c_int32), ("world", C.c_int32), ("rank", C.c_int32), ("ranks_seen", C.c_int32),
@@ -53,7 +56,8 @@ class CommInfo(C.Structure):
                 ("peers_host", C.c_int32), ("exclusive_device", C.c_int32), ("_pad", C.c_int32),
                 ("two_loops", C.c_uint64), ("two_loop_exchanges", C.c_uint64), ("allreduce_launches", C.c_uint64),
                 ("p2p_exchanges", C.c_uint64), ("resident_fallbacks", C.c_uint64),
-                ("timed_exchanges", C.c_uint64 * 2), ("exchange_us", C.c_double * 2), ("local_wait_us", C.c_double * 2)]
+                ("timed_exchanges", C.c_uint64 * 2), ("exchange_us", C.c_double * 2), ("local_wait_us", C.c_double * 2),
+                ("exchange_us_max", C.c_double * 2), ("local_wait_us_max", C.c_double * 2), ("exchange_hist", (C.c_uint32 * XCHG_BINS) * 2)]
 
 
 class Objective(C.Structure):

@@ -48,6 +48,30 @@ def _dp(a):
 
 
 # ------------------------------------------------------------------------------------ context
+def exchange_bin_edges_us():
+    """[lo, hi) in microseconds of the bins of lbfgs_hip_comm_info.exchange_hist: quarter-microsecond bins up to 8 us, then
+    octaves; the last bin is open (include/lbfgs_hip.h)."""
+    edges = [(b / 4.0, (b + 1) / 4.0) for b in range(32)]
+    edges += [(8.0 * 2 ** k, 8.0 * 2 ** (k + 1)) for k in range(_ffi.XCHG_BINS - 32)]
+    edges[-1] = (edges[-1][0], float("inf"))
+    return edges
+
+
+def exchange_quantile(hist, q):
+    """The q-quantile (0 < q <= 1) of the cross-rank exchange times from a histogram of lbfgs_hip_comm_info.exchange_hist
+    (or a difference of two): linear inside the bin it falls into; the open last bin answers with its lower edge.
+    -> microseconds, or None for an empty histogram."""
+    total = sum(hist)
+    if total <= 0:
+        return None
+    want, seen = q * total, 0
+    for (lo, hi), c in zip(exchange_bin_edges_us(), hist):
+        if c > 0 and seen + c >= want:
+            return lo if hi == float("inf") else lo + (hi - lo) * (want - seen) / c
+        seen += c
+    return exchange_bin_edges_us()[-1][0]
+
+
 class Context:
     """Device, stream, scalar board and communicator (lbfgs_hip_ctx)."""
 
@@ -135,13 +159,15 @@ class Context:
         ci = _ffi.CommInfo()
         self.check(self._L.lbfgs_hip_ctx_comm_info(self._h, C.byref(ci)))
         out = {k: getattr(ci, k) for k, _ in _ffi.CommInfo._fields_ if not k.startswith("_") and k not in (
-            "timed_exchanges", "exchange_us", "local_wait_us")}
+            "timed_exchanges", "exchange_us", "local_wait_us", "exchange_us_max", "local_wait_us_max", "exchange_hist")}
         out["kind"] = {_ffi.COMM_NONE: "none", _ffi.COMM_RCCL: "rccl", _ffi.COMM_CALLBACK: "callback", _ffi.COMM_P2P: "p2p"}.get(ci.kind, ci.kind)
         out["mailbox_placement"] = {_ffi.MAILBOX_DEVICE: "device", _ffi.MAILBOX_HOST: "host"}.get(ci.mailbox_placement)
         if ci.kind == _ffi.COMM_CALLBACK:
             out["ranks_seen"] = None  # (the all-reduce is the caller's: the library sees no peer itself)
-        for k in ("timed_exchanges", "exchange_us", "local_wait_us"):
+        for k in ("timed_exchanges", "exchange_us", "local_wait_us", "exchange_us_max", "local_wait_us_max"):
             out[k] = {"other": getattr(ci, k)[0], "two_loop": getattr(ci, k)[1]}
+        # the distribution behind exchange_us (ABI 5): counts per duration bin, see exchange_quantile below
+        out["exchange_hist"] = {"other": list(ci.exchange_hist[0]), "two_loop": list(ci.exchange_hist[1])}
         return out
 
     def set_grid(self, blocks):

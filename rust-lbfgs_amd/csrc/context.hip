@@ -15,6 +15,7 @@
 #include <thread>
 
 #include "ctx.h"
+#include "ext_protocol.h"
 
 // ------------------------------------------------------------------------------------ RCCL (lazy)
 // RCCL is only needed when world > 1, so it is dlopen'ed on first use; a single-GPU process
@@ -340,119 +341,108 @@ static int ext_agree(lbfgs_hip_ctx* ctx, int* bad) {
     HIP_TRY(ctx, hipMemcpy(buf, &v, sizeof(v), hipMemcpyHostToDevice));
     return LBFGS_HIP_OK;
 }
-// rank-local steps of ext_prepare: a failure is RECORDED (ctx->err keeps the message) and the rank goes on to every collective
-// below with a "bad" vote -- returning here would leave its peers inside ncclAllReduce + hipStreamSynchronize for ever (the host
-// side has no timeout) -- and hands the error back after the last one (round-5 advice).
-#define EXT_LOCAL(call)                                                                                             \
-    do {                                                                                                            \
-        if (local_rc == LBFGS_HIP_OK) {                                                                             \
-            hipError_t e_ = (call);                                                                                 \
-            if (e_ != hipSuccess) local_rc = fail(ctx, LBFGS_HIP_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
-        }                                                                                                           \
+// The steps of ext_prepare as the collective skeleton sees them (ext_protocol.h: every rank makes the same sequence of
+// collectives whatever happens to it locally -- a failure is RECORDED, ctx->err keeps the message, and handed back after the last
+// one: round-5 advice).
+#define EXT_LOCAL(call)                                                                                    \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess) return fail(ctx, LBFGS_HIP_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
-// -> LBFGS_HIP_OK: the gated exchange is usable on EVERY rank; 1: not (every rank takes the kernel-per-step form); < 0: error.
-// COLLECTIVE over the context's communicator: every rank makes the same sequence of all-reduces whatever happens to it locally.
-int ext_prepare(lbfgs_hip_ctx* ctx) {
-    int local_rc = LBFGS_HIP_OK;
-    if (!ctx->xstream) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // (numerically lowest = highest priority)
-        EXT_LOCAL(hipStreamCreateWithPriority(&ctx->xstream, hipStreamNonBlocking, hi));
-        if (ctx->resident_fault == -2) local_rc = fail(ctx, LBFGS_HIP_ERR_HIP, "injected: the second stream could not be created (tests)");
-    }
-    if (!ctx->ext_ev) EXT_LOCAL(hipEventCreateWithFlags(&ctx->ext_ev, hipEventDisableTiming));
-    if (!ctx->ext_block && local_rc == LBFGS_HIP_OK) {
-        void* p = nullptr;
-        {
-            std::lock_guard<std::mutex> lk(g_uc_pool_mu);  // (uncached blocks are pooled per process, never freed: see lbfgs_hip_ctx_create)
-            auto& pool = g_uc_mbox_pool[ctx->device];
-            if (!pool.empty()) {
-                p = pool.back();
-                pool.pop_back();
-            }
+namespace {
+struct ExtOps {
+    lbfgs_hip_ctx* ctx;
+    bool has_comm() const { return ctx->nccl != nullptr; }
+    int setup() {
+        if (!ctx->xstream) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // (numerically lowest = highest priority)
+            EXT_LOCAL(hipStreamCreateWithPriority(&ctx->xstream, hipStreamNonBlocking, hi));
+            if (ctx->resident_fault == -2) return fail(ctx, LBFGS_HIP_ERR_HIP, "injected: the second stream could not be created (tests)");
         }
-        const size_t bytes = P2P_MBOX_WORDS * sizeof(unsigned long long);
-        if (!p) EXT_LOCAL(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached));
-        if (local_rc == LBFGS_HIP_OK) {
+        if (!ctx->ext_ev) EXT_LOCAL(hipEventCreateWithFlags(&ctx->ext_ev, hipEventDisableTiming));
+        if (!ctx->ext_block) {
+            void* p = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(g_uc_pool_mu);  // (uncached blocks are pooled per process, never freed: see lbfgs_hip_ctx_create)
+                auto& pool = g_uc_mbox_pool[ctx->device];
+                if (!pool.empty()) {
+                    p = pool.back();
+                    pool.pop_back();
+                }
+            }
+            const size_t bytes = P2P_MBOX_WORDS * sizeof(unsigned long long);
+            if (!p) EXT_LOCAL(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached));
             ctx->ext_block = static_cast<unsigned long long*>(p);
             EXT_LOCAL(hipMemsetAsync(p, 0, bytes, ctx->stream));
             EXT_LOCAL(hipStreamSynchronize(ctx->stream));
         }
+        return LBFGS_HIP_OK;
     }
-    // stage 1 -- handshake: a kernel on the compute stream waits (<= 20 ms) for a word that a kernel on the second stream sets;
-    // and this rank's shard and device must be able to take the persistent kernel at all (an empty shard, a shard beyond the
-    // kernel's limits, a CU-masked queue cannot: lbfgs_hip.hip resident_shard_eligible)
-    unsigned long long verdict = 0;
-    if (local_rc == LBFGS_HIP_OK) {
+    // a kernel on the compute stream waits (<= 20 ms) for a word that a kernel on the second stream sets
+    int handshake(bool* passed) {
         const unsigned long long magic = 0x6761746564ull;
         hipLaunchKernelGGL(ext_selftest_wait_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->ext_block, magic, 2000000ull);
         hipLaunchKernelGGL(ext_selftest_set_kernel, dim3(1), dim3(64), 0, ctx->xstream, ctx->ext_block, magic);
         EXT_LOCAL(hipGetLastError());
         EXT_LOCAL(hipStreamSynchronize(ctx->stream));
         EXT_LOCAL(hipStreamSynchronize(ctx->xstream));
+        unsigned long long verdict = 0;
         EXT_LOCAL(hipMemcpy(&verdict, ctx->ext_block + 4, sizeof(verdict), hipMemcpyDeviceToHost));
+        *passed = verdict == 1ull;
+        return LBFGS_HIP_OK;
     }
-    const bool shard_ok = resident_shard_eligible(ctx);
-    // Every rank must take the same form -- a rank with a kernel per step and a rank with the gated chain would pair their
-    // all-reduces wrongly -- so the ranks AGREE on each outcome: a sum of 0 / 1 over the communicator, on the compute
-    // stream (which works whatever the second stream does).
-    int bad = (local_rc == LBFGS_HIP_OK && verdict == 1ull && shard_ok) ? 0 : 1, stage = shard_ok || local_rc != LBFGS_HIP_OK ? 1 : 0;
-    if (ctx->nccl) {
-        const int rc_a = ext_agree(ctx, &bad);
-        if (rc_a != LBFGS_HIP_OK) return rc_a;  // (the communicator itself failed: nothing collective can follow)
-    }
-    if (bad == 0 && ctx->nccl) {
-        // RCCL's first collective on a stream may set things up (channels, buffers) and wait for the device: let it do so
-        // NOW, not with a persistent kernel waiting for it.  Collective: every rank comes here (bad == 0 is the agreed value).
-        double* const slot0 = reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->ext_block) + EXT_BUF_OFFSET);
-        const int rc_w = rccl_allreduce_on(ctx, slot0, 1, ctx->xstream);
-        if (rc_w != LBFGS_HIP_OK) return rc_w;
+    // an empty shard, a shard beyond the kernel's limits, a CU-masked queue cannot take the persistent kernel (lbfgs_hip.hip)
+    bool shard_ok() { return resident_shard_eligible(ctx); }
+    int agree(int* bad) { return ext_agree(ctx, bad); }
+    // RCCL's first collective on a stream may set things up (channels, buffers) and wait for the device: let it do so NOW, not
+    // with a persistent kernel waiting for it
+    int warmup() { return rccl_allreduce_on(ctx, slot0(), 1, ctx->xstream); }
+    int after_warmup() {
         EXT_LOCAL(hipStreamSynchronize(ctx->xstream));
-        EXT_LOCAL(hipMemsetAsync(slot0, 0, EXT_SLOT_DOUBLES * sizeof(double), ctx->stream));
+        EXT_LOCAL(hipMemsetAsync(slot0(), 0, EXT_SLOT_DOUBLES * sizeof(double), ctx->stream));
         EXT_LOCAL(hipStreamSynchronize(ctx->stream));
-        // ... and then the exchange itself, once, under a kernel that fills the chip the way the two-loop will.  Every rank's
-        // peers wait inside RCCL for its all-reduce of this trial: a rank that failed locally, or whose trial failed before it
-        // got that far, still hands ONE all-reduce to the communicator (on the compute stream, ungated: the sum is then wrong
-        // and every rank sees the trial fail) -- nobody is left inside RCCL.
-        bool ok = false, enqueued = false;
-        if (local_rc == LBFGS_HIP_OK && ctx->resident_fault != -3) {
-            const int rc_s = ext_selftest_resident(ctx, &ok, &enqueued);
-            if (rc_s != LBFGS_HIP_OK) local_rc = rc_s;
-        } else if (ctx->resident_fault == -3) {
-            local_rc = fail(ctx, LBFGS_HIP_ERR_HIP, "injected: this rank failed before the gated exchange's trial (tests)");
-        }
-        if (!enqueued) {
-            const int rc_e = rccl_allreduce_on(ctx, ctx->board + LBFGS_HIP_BOARD_SLOTS, 1, ctx->stream);
-            (void)hipStreamSynchronize(ctx->stream);
-            if (rc_e != LBFGS_HIP_OK) return rc_e;
-        }
-        if (ctx->resident_fault == -1) ok = false;  // (tests)
-        bad = (ok && local_rc == LBFGS_HIP_OK) ? 0 : 1;
-        stage = 2;
-        const int rc_b = ext_agree(ctx, &bad);
-        if (rc_b != LBFGS_HIP_OK) return rc_b;
+        return LBFGS_HIP_OK;
     }
-    if (local_rc != LBFGS_HIP_OK) return local_rc;  // (after the last collective)
-    if (bad != 0) {
-        ctx->rccl_resident = 0;
-        if (stage == 0)
-            fprintf(stderr, "[lbfgs_hip] note: the shard or the device of %d of %d ranks cannot take the persistent two-loop kernel (an empty "
-                            "shard, a shard beyond its limits, a CU-masked queue); every rank runs the two-loop with a kernel per step "
-                            "under RCCL\n", bad, ctx->shard.world);
-        else if (stage == 1)
-            fprintf(stderr, "[lbfgs_hip] warning: the gated RCCL exchange is not available on %d of %d ranks (the compute stream and the "
-                            "second stream are not served concurrently -- they share a hardware queue: GPU_MAX_HW_QUEUES --, or a "
-                            "shard / device cannot take the persistent kernel); the two-loop runs with a kernel per step under RCCL\n",
-                    bad, ctx->shard.world);
-        else
-            fprintf(stderr, "[lbfgs_hip] warning: the gated RCCL exchange's self-test (an all-reduce enqueued on the second stream, "
-                            "awaited by a kernel that fills the chip) did not come back right within 1 s on %d of %d ranks; the "
-                            "two-loop runs with a kernel per step under RCCL\n", bad, ctx->shard.world);
-        return 1;  // (not an error: the caller takes the kernel-per-step form)
+    // the exchange itself, once, under a kernel that fills the chip the way the two-loop will
+    int trial(bool* ok, bool* enqueued) {
+        if (ctx->resident_fault == -3) return fail(ctx, LBFGS_HIP_ERR_HIP, "injected: this rank failed before the gated exchange's trial (tests)");
+        const int rc = ext_selftest_resident(ctx, ok, enqueued);
+        if (ctx->resident_fault == -1) *ok = false;  // (tests)
+        return rc;
     }
-    return LBFGS_HIP_OK;
-}
+    int bare_allreduce() {  // (on the compute stream, ungated)
+        const int rc = rccl_allreduce_on(ctx, ctx->board + LBFGS_HIP_BOARD_SLOTS, 1, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
+    double* slot0() const { return reinterpret_cast<double*>(reinterpret_cast<char*>(ctx->ext_block) + EXT_BUF_OFFSET); }
+};
+}  // namespace
 #undef EXT_LOCAL
+// -> LBFGS_HIP_OK: the gated exchange is usable on EVERY rank; 1: not (every rank takes the kernel-per-step form); < 0: error.
+// COLLECTIVE over the context's communicator.
+int ext_prepare(lbfgs_hip_ctx* ctx) {
+    ExtOps ops{ctx};
+    ExtOutcome res;
+    const int rc = ext_prepare_protocol(ops, &res);
+    if (rc != 1) return rc;
+    ctx->rccl_resident = 0;
+    if (res.stage == 0)
+        fprintf(stderr, "[lbfgs_hip] note: the shard or the device of %d of %d ranks cannot take the persistent two-loop kernel (an empty "
+                        "shard, a shard beyond its limits, a CU-masked queue); every rank runs the two-loop with a kernel per step "
+                        "under RCCL\n", res.bad, ctx->shard.world);
+    else if (res.stage == 1)
+        fprintf(stderr, "[lbfgs_hip] warning: the gated RCCL exchange is not available on %d of %d ranks (the compute stream and the "
+                        "second stream are not served concurrently -- they share a hardware queue: GPU_MAX_HW_QUEUES --, or a "
+                        "shard / device cannot take the persistent kernel); the two-loop runs with a kernel per step under RCCL\n",
+                res.bad, ctx->shard.world);
+    else
+        fprintf(stderr, "[lbfgs_hip] warning: the gated RCCL exchange's self-test (an all-reduce enqueued on the second stream, "
+                        "awaited by a kernel that fills the chip) did not come back right within 1 s on %d of %d ranks; the "
+                        "two-loop runs with a kernel per step under RCCL\n", res.bad, ctx->shard.world);
+    return 1;  // (not an error: the caller takes the kernel-per-step form)
+}
 // Give the chain of the latest gated launch up: its gates leave at once (abort word >= their launch id), the all-reduces behind
 // them reduce whatever the slots hold -- on every rank alike, nobody reads it -- and the second stream runs empty.
 void ext_abort(lbfgs_hip_ctx* ctx) {
@@ -1156,6 +1146,14 @@ int lbfgs_hip_ctx_comm_info(lbfgs_hip_ctx* ctx, lbfgs_hip_comm_info* out) {
         out->timed_exchanges[c] = x[c].count;
         out->exchange_us[c] = (double)x[c].p2p_ticks * 0.01;   // wall_clock64 ticks of 10 ns
         out->local_wait_us[c] = (double)x[c].local_ticks * 0.01;
+    }
+    static_assert(XCHG_BINS == LBFGS_HIP_XCHG_BINS, "stream.h DevXchgDist and lbfgs_hip_comm_info::exchange_hist");
+    DevXchgDist dist[2];
+    HIP_TRY(ctx, hipMemcpy(dist, reinterpret_cast<const char*>(ctx->dev_ctr) + DEV_XCHG_DIST_OFFSET, sizeof(dist), hipMemcpyDeviceToHost));
+    for (int c = 0; c < 2; ++c) {
+        out->exchange_us_max[c] = (double)dist[c].p2p_max * 0.01;
+        out->local_wait_us_max[c] = (double)dist[c].local_max * 0.01;
+        for (int b = 0; b < XCHG_BINS; ++b) out->exchange_hist[c][b] = dist[c].hist[b];
     }
     return LBFGS_HIP_OK;
 }

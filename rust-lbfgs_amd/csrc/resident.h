@@ -57,6 +57,9 @@ constexpr int RES_UNROLL = 4;          // pairs whose loads are issued together 
 #ifndef LH_RES_TOUCH
 #define LH_RES_TOUCH 16  // the deepest touch compiled in (rounds, a multiple of 4): a touching thread holds LH_RES_TOUCH / 2 words
 #endif
+#ifndef LH_RES_D_NT
+#define LH_RES_D_NT 1  // the direction's write-out pass uses `nt` stores where the history loads use `nt`
+#endif
 #ifndef LH_RES_TRACE
 #define LH_RES_TRACE 0  // 1: every workgroup logs wall-clock stamps of every hand-off into RedCtl::partials (tools/handoff_trace.sh)
 #endif
@@ -305,9 +308,11 @@ __device__ __forceinline__ void res_exchange(double (&acc)[NS], const RedCtl& re
             const long long t1 = wall_clock64();
             if (red.p2p.ext_buf) ext_exchange(red.p2p, p2p_tag, s_tot, NS);  // (gated: ncclAllReduce on the second stream)
             else p2p_exchange(red.p2p, p2p_tag, s_tot, NS, s_bits);
-            xacc.p2p_ticks += (unsigned long long)(wall_clock64() - t1);
-            xacc.local_ticks += (unsigned long long)(t1 - t0);
+            const unsigned long long dt_x = (unsigned long long)(wall_clock64() - t1), dt_l = (unsigned long long)(t1 - t0);
+            xacc.p2p_ticks += dt_x;
+            xacc.local_ticks += dt_l;
             xacc.count += 1ull;
+            if (threadIdx.x == 0) xchg_dist_note(red.ctr, 1u, dt_x, dt_l);  // (fire-and-forget atomics: the distribution behind the totals)
             if (threadIdx.x == 0) {
 #pragma unroll
                 for (int k = 0; k < NS; ++k) {
@@ -997,10 +1002,13 @@ void two_loop_resident_kernel(const ResArgs a, const RedCtl red) {
         acc[1] = t4[2];
         acc[2] = t4[3];
     } else {
-        ResGroups<0, NG, NT, 0>::store(b_first, b_stride, a.d);
+        // (LH_RES_D_NT=0, A/B builds: d written with the default cache policy -- the line search reads it next and a shard's d fits
+        // the Infinity Cache; measured twice, rounds 4 and 6: what the trials gain the two-loop kernel loses, EXPERIMENTS.md)
+        constexpr bool DNT = NT && (LH_RES_D_NT != 0);
+        ResGroups<0, NG, DNT, 0>::store(b_first, b_stride, a.d);
         for (uint32_t e = 0; e < EL; ++e) {
             const uint32_t p = p_first + (ER + e) * p_stride;
-            if (p < n2) st16<NT>(a.d, p, q_lds[(size_t)e * BLOCK + tid]);
+            if (p < n2) st16<DNT>(a.d, p, q_lds[(size_t)e * BLOCK + tid]);
         }
         if (tail_owner) a.d[a.n - 1] = q_tail;
     }

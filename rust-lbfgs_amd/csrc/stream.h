@@ -110,6 +110,33 @@ struct DevXchg {
     unsigned long long _pad;
 };
 constexpr int DEV_XCHG_OFFSET = 64;  // bytes from the start of the counters' page
+// ... and the DISTRIBUTION of those exchanges, per class, 128 bytes in: how long the longest one took, the longest wait for this
+// GPU's own workgroups, and a histogram of the exchange times (lbfgs_hip_comm_info::exchange_hist: quarter-microsecond bins up
+// to 8 us, octaves beyond).  Updated by fire-and-forget atomics of the exchanging thread -- no value comes back, so nothing
+// waits on them: the record above is loaded BEFORE an exchange for the same reason.
+constexpr int XCHG_BINS = 48;
+struct DevXchgDist {
+    unsigned long long p2p_max, local_max;
+    unsigned int hist[XCHG_BINS];
+};
+constexpr int DEV_XCHG_DIST_OFFSET = 128;
+static_assert(DEV_XCHG_OFFSET + 2 * sizeof(DevXchg) <= DEV_XCHG_DIST_OFFSET && DEV_XCHG_DIST_OFFSET + 2 * sizeof(DevXchgDist) <= 4096,
+              "the counters' page");
+__device__ __forceinline__ void xchg_dist_note(DevCounters* ctr, const unsigned int cls, const unsigned long long p2p_ticks,
+                                               const unsigned long long local_ticks) {
+    DevXchgDist* const d = reinterpret_cast<DevXchgDist*>(reinterpret_cast<char*>(ctr) + DEV_XCHG_DIST_OFFSET) + (cls & 1u);
+    unsigned int b;
+    if (p2p_ticks < 800ull) {
+        b = (unsigned int)p2p_ticks / 25u;  // 100 MHz ticks: 25 = 0.25 us
+    } else {
+        const unsigned long long oct = p2p_ticks / 800ull;  // >= 1
+        b = 32u + (unsigned int)(63 - __clzll((long long)oct));
+        if (b > (unsigned int)XCHG_BINS - 1u) b = (unsigned int)XCHG_BINS - 1u;
+    }
+    (void)__hip_atomic_fetch_add(&d->hist[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_max(&d->p2p_max, p2p_ticks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_max(&d->local_max, local_ticks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ DevXchg* dev_xchg(DevCounters* ctr, const unsigned int cls) {
     return reinterpret_cast<DevXchg*>(reinterpret_cast<char*>(ctr) + DEV_XCHG_OFFSET) + (cls & 1u);
 }
@@ -436,10 +463,12 @@ __device__ __forceinline__ void grid_reduce(double (&acc)[NRED], const RedCtl& r
 #pragma unroll
             for (int k = 0; k < NRED; ++k) tot[k] = s_vals[k];
             red.ctr->p2p_epoch = next_epoch(c0.p2p_epoch);
-            x.p2p_ticks += (unsigned long long)(wall_clock64() - t1);
-            if (tagged) x.local_ticks += (unsigned long long)(t1 - t0);
+            const unsigned long long dt_x = (unsigned long long)(wall_clock64() - t1), dt_l = tagged ? (unsigned long long)(t1 - t0) : 0ull;
+            x.p2p_ticks += dt_x;
+            x.local_ticks += dt_l;
             x.count += 1ull;
             *xs = x;
+            xchg_dist_note(red.ctr, red.xchg_class, dt_x, dt_l);
         }
     }
     if (threadIdx.x == 0) {

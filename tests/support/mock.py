@@ -20,7 +20,7 @@ SRCS = [
 ]
 C_SRCS = [os.path.join(ROOT, "oracle", "lbfgs_oracle.c"), os.path.join(ROOT, "oracle", "objectives.c")]
 HDRS = [os.path.join(ROOT, "include", "lbfgs_hip.h"), os.path.join(ROOT, "include", "lbfgs_solver.h"),
-        os.path.join(ROOT, "oracle", "lbfgs_oracle.h")]
+        os.path.join(ROOT, "oracle", "lbfgs_oracle.h"), os.path.join(ROOT, "rust-lbfgs_amd", "csrc", "ext_protocol.h")]
 
 
 def _build_id(flags):
@@ -62,7 +62,7 @@ def build(force=False):
         o = os.path.join(HERE, os.path.basename(s) + (".asan.o" if SANITIZE else ".o"))
         subprocess.run(["gcc", "-std=c11", *flags, "-c", s, "-o", o], check=True, capture_output=True)
         objs.append(o)
-    r = subprocess.run(["g++", "-std=c++17", *flags, "-shared", *SRCS, *objs, "-o", LIB, "-lm", "-Wl,-Bsymbolic"],
+    r = subprocess.run(["g++", "-std=c++17", *flags, "-shared", *SRCS, *objs, "-o", LIB, "-lm", "-lrt", "-Wl,-Bsymbolic"],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stderr)

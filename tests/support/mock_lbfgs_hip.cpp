@@ -11,7 +11,20 @@
 // reference's unfused order with sequential sums, so with world == 1 the solver on
 // this mock must reproduce the oracle -- and the reference's 17-digit known answers
 // -- bit for bit.  With world > 1 each rank holds a contiguous shard and scalars are
-// closed through the callback communicator (torch.distributed / gloo in the tests).
+// closed through the callback communicator (torch.distributed / gloo in the tests) -- or, round 6, through STAND-INS of the
+// P2P and RCCL communicators over POSIX shared memory ("bus" below): several rank PROCESSES, which no single GPU can host,
+// then run bench.py's legs, dist.py's collective fall-back from device- to host-placed mailboxes, and -- through the product's own
+// collective skeleton, rust-lbfgs_amd/csrc/ext_protocol.h -- the preparation of the gated RCCL exchange with failures injected
+// on ONE rank.  Hooks (environment): LBFGS_MOCK_RCCL=1 (there is an "RCCL"), LBFGS_MOCK_NO_DEVICE_IPC=1 (a peer's device-placed
+// mailbox cannot be mapped: each rank sees only its own GPU), LBFGS_MOCK_FAULT_RANK=r (LBFGS_HIP_RESIDENT_FAULT applies to
+// rank r only), LBFGS_MOCK_HANDSHAKE_FAIL_RANK=r, LBFGS_MOCK_PROTOCOL_LOG=<path prefix> (every rank logs its collectives).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +34,23 @@
 
 #include "../../include/lbfgs_hip.h"
 #include "../../oracle/lbfgs_oracle.h"
+#include "../../rust-lbfgs_amd/csrc/ext_protocol.h"
+
+// ---- the bus: a ring of slots [BUS_RING][world], one per (epoch mod ring, writing rank), in shared memory -------------------
+constexpr int BUS_RING = 8, BUS_COUNT = 8, BUS_WORLD = 8;
+struct BusSlot {
+    std::atomic<uint64_t> epoch;  // written last (release); 0 = never
+    uint64_t tag;                 // what the writer thinks this collective is (count and kind): a mismatch is a protocol error
+    double v[BUS_COUNT];
+};
+struct BusSeg {
+    BusSlot* slots = nullptr;  // [BUS_RING][BUS_WORLD]
+    std::string name;
+    bool owner = false;
+    int placement = -1;        // P2P mailboxes: LBFGS_HIP_MAILBOX_DEVICE / _HOST as ASKED for (it is shared memory either way)
+};
+constexpr size_t BUS_BYTES = sizeof(BusSlot) * BUS_RING * BUS_WORLD;
+constexpr char BUS_MAGIC[8] = {'L', 'M', 'O', 'C', 'K', 'B', 'U', 'S'};
 
 struct lbfgs_hip_ctx {
     lbfgs_hip_shard shard{};
@@ -32,6 +62,14 @@ struct lbfgs_hip_ctx {
     uint64_t n_allreduce = 0, n_two_loop = 0, n_two_loop_allreduce = 0;
     bool in_two_loop = false;
     uint64_t n_gram = 0;
+    // bus communicators (P2P / RCCL stand-ins)
+    std::vector<BusSeg*> targets;   // where this rank's contribution goes: every rank's mailbox (P2P) or the one shared segment (RCCL)
+    BusSeg* inbox = nullptr;        // where it reads every rank's contribution
+    uint64_t bus_epoch = 0;
+    double bus_timeout_s = 20.0;
+    bool exclusive = false, gated = false;
+    int peers_device = 0, peers_host = 0;
+    FILE* plog = nullptr;           // LBFGS_MOCK_PROTOCOL_LOG
 };
 struct lbfgs_hip_vec {
     lbfgs_hip_ctx* ctx;
@@ -53,13 +91,101 @@ int fail(lbfgs_hip_ctx* c, int code, const char* msg) {
 bool slot_ok(int first, int count) { return first >= 0 && count >= 0 && first + count <= LBFGS_HIP_BOARD_SLOTS; }
 size_t nl(const lbfgs_hip_ctx* c) { return (size_t)c->shard.n_local; }
 
+BusSeg* bus_map(const char* name, bool create, std::string* err) {
+    int fd = shm_open(name, create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDWR, 0600);
+    if (fd < 0) { *err = std::string("shm_open(") + name + "): " + strerror(errno); return nullptr; }
+    if (create && ftruncate(fd, (off_t)BUS_BYTES) != 0) { *err = "ftruncate failed"; close(fd); shm_unlink(name); return nullptr; }
+    void* p = mmap(nullptr, BUS_BYTES, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { *err = "mmap failed"; if (create) shm_unlink(name); return nullptr; }
+    auto* sgm = new BusSeg();
+    sgm->slots = static_cast<BusSlot*>(p);   // (a fresh segment is zero-filled: every epoch 0)
+    sgm->name = name;
+    sgm->owner = create;
+    return sgm;
+}
+void bus_unmap(BusSeg* sgm) {
+    if (!sgm) return;
+    munmap(sgm->slots, BUS_BYTES);
+    if (sgm->owner) shm_unlink(sgm->name.c_str());
+    delete sgm;
+}
+std::string bus_fresh_name(const char* what) {
+    static std::atomic<unsigned> ctr{0};
+    char b[56];
+    snprintf(b, sizeof(b), "/lbfgs_mock_%s_%d_%u", what, (int)getpid(), ctr.fetch_add(1));
+    return b;
+}
+// in-place sum all-reduce over the bus, in rank order (the same bits on every rank); `tag` names the collective
+int bus_allreduce(lbfgs_hip_ctx* c, double* v, int count, uint64_t tag) {
+    if (count > BUS_COUNT) return fail(c, LBFGS_HIP_ERR_ARG, "mock bus: too many values in one all-reduce");
+    const int W = c->shard.world, me = c->shard.rank;
+    const uint64_t e = ++c->bus_epoch;
+    tag = (tag << 8) | (uint64_t)count;
+    if (c->plog) { fprintf(c->plog, "%llu %llx\n", (unsigned long long)e, (unsigned long long)tag); fflush(c->plog); }
+    for (BusSeg* t : c->targets) {
+        BusSlot& sl = t->slots[(e % BUS_RING) * BUS_WORLD + me];
+        for (int i = 0; i < count; ++i) sl.v[i] = v[i];
+        sl.tag = tag;
+        sl.epoch.store(e, std::memory_order_release);
+    }
+    double sum[BUS_COUNT] = {0};
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < W; ++r) {
+        BusSlot& sl = c->inbox->slots[(e % BUS_RING) * BUS_WORLD + r];
+        while (sl.epoch.load(std::memory_order_acquire) != e) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->bus_timeout_s)
+                return fail(c, LBFGS_HIP_ERR_COMM, "mock bus: all-reduce timed out waiting for a peer");
+            usleep(50);
+        }
+        if (sl.tag != tag) return fail(c, LBFGS_HIP_ERR_COMM, "mock bus: the ranks disagree about which collective this is (sequence mismatch)");
+        for (int i = 0; i < count; ++i) sum[i] += sl.v[i];
+    }
+    for (int i = 0; i < count; ++i) v[i] = sum[i];
+    return LBFGS_HIP_OK;
+}
+
 int allreduce(lbfgs_hip_ctx* c, double* v, int count) {
     if (c->comm_kind == LBFGS_HIP_COMM_NONE) return LBFGS_HIP_OK;
     c->n_allreduce += 1;
     if (c->in_two_loop) c->n_two_loop_allreduce += 1;
+    if (c->comm_kind == LBFGS_HIP_COMM_P2P || c->comm_kind == LBFGS_HIP_COMM_RCCL) return bus_allreduce(c, v, count, 0xA11);
     if (c->cb(c->cb_user, v, count) != 0) return fail(c, LBFGS_HIP_ERR_COMM, "all-reduce callback failed");
     return LBFGS_HIP_OK;
 }
+
+// the steps of the gated exchange's preparation as the product's collective skeleton sees them (ext_protocol.h), with the
+// failures of context.hip's LBFGS_HIP_RESIDENT_FAULT injected on ONE rank (LBFGS_MOCK_FAULT_RANK)
+struct MockExtOps {
+    lbfgs_hip_ctx* c;
+    int fault = 0;
+    bool has_comm() const { return true; }
+    int setup() { return fault == -2 ? fail(c, LBFGS_HIP_ERR_HIP, "injected: the second stream could not be created (tests)") : 0; }
+    int handshake(bool* passed) {
+        const char* e = getenv("LBFGS_MOCK_HANDSHAKE_FAIL_RANK");
+        *passed = !(e && atoi(e) == c->shard.rank);
+        return 0;
+    }
+    bool shard_ok() { return c->shard.n_local > 0; }  // (an empty shard cannot take the persistent kernel: lbfgs_hip.hip resident_plan)
+    int agree(int* bad) {
+        double v = *bad ? 1.0 : 0.0;
+        const int rc = bus_allreduce(c, &v, 1, 0xA62EE);
+        *bad = (int)v;
+        return rc;
+    }
+    int warmup() { double v = 0.0; return bus_allreduce(c, &v, 1, 0x3A63); }
+    int after_warmup() { return 0; }
+    int trial(bool* ok, bool* enqueued) {
+        if (fault == -3) return fail(c, LBFGS_HIP_ERR_HIP, "injected: this rank failed before the gated exchange's trial (tests)");
+        double v = (double)(c->shard.rank + 1);
+        *enqueued = true;
+        const int rc = bus_allreduce(c, &v, 1, 0x721A1);
+        const double W = (double)c->shard.world;
+        *ok = rc == 0 && v == 0.5 * W * (W + 1.0) && fault != -1;
+        return rc;
+    }
+    int bare_allreduce() { double v = 0.0; return bus_allreduce(c, &v, 1, 0x721A1); }
+};
 int gdot(lbfgs_hip_ctx* c, const double* a, const double* b, double* out) {
     *out = oracle_vecdot(a, b, nl(c));
     return allreduce(c, out, 1);
@@ -78,13 +204,44 @@ extern "C" {
 
 int lbfgs_hip_abi_version(void) { return LBFGS_HIP_ABI_VERSION; }
 int lbfgs_hip_device_count(int* count) { *count = 0; return LBFGS_HIP_OK; }
-int lbfgs_hip_rccl_unique_id(void*) { return fail(nullptr, LBFGS_HIP_ERR_COMM, "mock: no RCCL"); }
-int lbfgs_hip_p2p_mailbox_create(int, void**, void*) { return fail(nullptr, LBFGS_HIP_ERR_COMM, "mock: no P2P"); }
-int lbfgs_hip_p2p_mailbox_create2(int, int, void**, void*) { return fail(nullptr, LBFGS_HIP_ERR_COMM, "mock: no P2P"); }
-void lbfgs_hip_p2p_mailbox_destroy(int, void*) {}
+// "RCCL": rank 0 creates the shared segment and its name is the unique id (LBFGS_MOCK_RCCL=1; otherwise the double has none)
+int lbfgs_hip_rccl_unique_id(void* id128) {
+    if (!getenv("LBFGS_MOCK_RCCL")) return fail(nullptr, LBFGS_HIP_ERR_COMM, "mock: no RCCL");
+    const std::string name = bus_fresh_name("rccl");
+    std::string err;
+    BusSeg* sgm = bus_map(name.c_str(), true, &err);
+    if (!sgm) return fail(nullptr, LBFGS_HIP_ERR_COMM, err.c_str());
+    sgm->owner = false;  // (the contexts unlink it: the last one to go finds the name gone already, which is fine)
+    munmap(sgm->slots, BUS_BYTES);
+    delete sgm;
+    memset(id128, 0, 128);
+    memcpy(id128, BUS_MAGIC, sizeof(BUS_MAGIC));
+    snprintf(static_cast<char*>(id128) + 8, 120, "%s", name.c_str());
+    return LBFGS_HIP_OK;
+}
+// "P2P": a mailbox is a segment of this rank's own; the 64-byte handle carries the placement that was ASKED for and the name
+int lbfgs_hip_p2p_mailbox_create2(int, int placement, void** mbox, void* handle64) {
+    if (getenv("LBFGS_MOCK_NO_P2P")) return fail(nullptr, LBFGS_HIP_ERR_COMM, "mock: no P2P");
+    if (placement == LBFGS_HIP_MAILBOX_AUTO) {
+        const char* e = getenv("LBFGS_HIP_P2P_MAILBOX");
+        placement = (e && strcmp(e, "host") == 0) ? LBFGS_HIP_MAILBOX_HOST : LBFGS_HIP_MAILBOX_DEVICE;
+    }
+    std::string err;
+    BusSeg* sgm = bus_map(bus_fresh_name("mbox").c_str(), true, &err);
+    if (!sgm) return fail(nullptr, LBFGS_HIP_ERR_COMM, err.c_str());
+    sgm->placement = placement;
+    memset(handle64, 0, 64);
+    memcpy(handle64, BUS_MAGIC, sizeof(BUS_MAGIC));
+    static_cast<char*>(handle64)[8] = (char)placement;
+    snprintf(static_cast<char*>(handle64) + 9, 55, "%s", sgm->name.c_str());
+    *mbox = sgm;
+    return LBFGS_HIP_OK;
+}
+int lbfgs_hip_p2p_mailbox_create(int dev, void** mbox, void* handle64) { return lbfgs_hip_p2p_mailbox_create2(dev, LBFGS_HIP_MAILBOX_AUTO, mbox, handle64); }
+void lbfgs_hip_p2p_mailbox_destroy(int, void* mbox) { bus_unmap(static_cast<BusSeg*>(mbox)); }
 int lbfgs_hip_ctx_p2p_seal(lbfgs_hip_ctx* ctx, int* placement_out) {
     if (!ctx) return LBFGS_HIP_ERR_ARG;
-    if (placement_out) *placement_out = -1;
+    if (placement_out) *placement_out = (ctx->comm_kind == LBFGS_HIP_COMM_P2P && ctx->inbox) ? ctx->inbox->placement : -1;
     return LBFGS_HIP_OK;
 }
 #ifndef LBFGS_MOCK_BUILD_ID
@@ -99,13 +256,82 @@ int lbfgs_hip_ctx_create(lbfgs_hip_ctx** out, int, uint64_t n, const lbfgs_hip_s
     if (shard) c->shard = *shard;
     else c->shard = {0, 1, n, 0, n};
     int kind = comm ? comm->kind : LBFGS_HIP_COMM_NONE;
-    if (kind == LBFGS_HIP_COMM_RCCL) { delete c; return fail(nullptr, LBFGS_HIP_ERR_COMM, "mock: no RCCL"); }
-    if (c->shard.world > 1 && kind != LBFGS_HIP_COMM_CALLBACK) { delete c; return fail(nullptr, LBFGS_HIP_ERR_ARG, "world > 1 needs a communicator"); }
+    if (c->shard.world > 1 && kind == LBFGS_HIP_COMM_NONE) { delete c; return fail(nullptr, LBFGS_HIP_ERR_ARG, "world > 1 needs a communicator"); }
+    if (c->shard.world > BUS_WORLD && (kind == LBFGS_HIP_COMM_RCCL || kind == LBFGS_HIP_COMM_P2P)) { delete c; return fail(nullptr, LBFGS_HIP_ERR_ARG, "mock bus: world too large"); }
     if (kind == LBFGS_HIP_COMM_CALLBACK) { c->comm_kind = kind; c->cb = comm->callback; c->cb_user = comm->callback_user; }
+    if (const char* e = getenv("LBFGS_MOCK_PROTOCOL_LOG")) {
+        const std::string path = std::string(e) + ".rank" + std::to_string(c->shard.rank);
+        c->plog = fopen(path.c_str(), "a");
+    }
+    if (kind == LBFGS_HIP_COMM_P2P) {
+        // (the product takes ownership of the mailbox whether creation succeeds or not)
+        BusSeg* own = static_cast<BusSeg*>(comm->p2p_mailbox);
+        if (!own || !comm->p2p_handles) { bus_unmap(own); lbfgs_hip_ctx_destroy(c); return fail(nullptr, LBFGS_HIP_ERR_ARG, "P2P communicator needs a mailbox and handles"); }
+        c->comm_kind = kind;
+        c->inbox = own;
+        c->exclusive = comm->exclusive_device != 0;
+        if (comm->p2p_timeout_s > 0) c->bus_timeout_s = comm->p2p_timeout_s;
+        c->targets.assign((size_t)c->shard.world, nullptr);
+        c->targets[(size_t)c->shard.rank] = own;
+        for (int r = 0; r < c->shard.world; ++r) {
+            if (r == c->shard.rank) continue;
+            const char* h = static_cast<const char*>(comm->p2p_handles) + 64 * r;
+            const int placement = (int)h[8];
+            std::string err;
+            BusSeg* peer = nullptr;
+            if (memcmp(h, BUS_MAGIC, sizeof(BUS_MAGIC)) != 0) err = "not a mailbox handle";
+            else if (placement == LBFGS_HIP_MAILBOX_DEVICE && getenv("LBFGS_MOCK_NO_DEVICE_IPC"))
+                err = "hipIpcOpenMemHandle: invalid argument (mock: this rank sees only its own device)";
+            else peer = bus_map(h + 9, false, &err);
+            if (!peer) {
+                const std::string msg = "mailbox of rank " + std::to_string(r) + ": " + err;
+                lbfgs_hip_ctx_destroy(c);
+                return fail(nullptr, LBFGS_HIP_ERR_COMM, msg.c_str());
+            }
+            peer->placement = placement;
+            (placement == LBFGS_HIP_MAILBOX_HOST ? c->peers_host : c->peers_device) += 1;
+            c->targets[(size_t)r] = peer;
+        }
+    }
+    if (kind == LBFGS_HIP_COMM_RCCL) {
+        const char* id = static_cast<const char*>(comm->rccl_unique_id);
+        std::string err;
+        BusSeg* shared = (id && memcmp(id, BUS_MAGIC, sizeof(BUS_MAGIC)) == 0) ? bus_map(id + 8, false, &err) : nullptr;
+        if (!shared) { lbfgs_hip_ctx_destroy(c); return fail(nullptr, LBFGS_HIP_ERR_COMM, ("mock RCCL: " + (err.empty() ? std::string("no unique id") : err)).c_str()); }
+        shared->owner = true;  // (every rank tries to unlink the name when it goes)
+        c->comm_kind = kind;
+        c->inbox = shared;
+        c->targets.assign(1, shared);
+        c->exclusive = comm->exclusive_device != 0;
+        // the gated exchange: opt-in, exclusive devices only, prepared COLLECTIVELY by the product's own skeleton
+        const char* opt = getenv("LBFGS_HIP_RCCL_RESIDENT");
+        if (c->exclusive && opt && atoi(opt) != 0) {
+            MockExtOps ops{c};
+            const char* f = getenv("LBFGS_HIP_RESIDENT_FAULT");
+            const char* fr = getenv("LBFGS_MOCK_FAULT_RANK");
+            if (f && (!fr || atoi(fr) == c->shard.rank)) ops.fault = atoi(f);
+            lh::ExtOutcome res;
+            const int rc = lh::ext_prepare_protocol(ops, &res);
+            if (rc < 0) {
+                const std::string msg = c->err;
+                lbfgs_hip_ctx_destroy(c);
+                return fail(nullptr, rc, msg.c_str());
+            }
+            c->gated = rc == 0;
+            if (rc == 1) fprintf(stderr, "[mock lbfgs_hip] the gated RCCL exchange is not used: stage %d, %d of %d ranks against; kernel per step\n",
+                                 res.stage, res.bad, c->shard.world);
+        }
+    }
     *out = c;
     return LBFGS_HIP_OK;
 }
-void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* c) { delete c; }
+void lbfgs_hip_ctx_destroy(lbfgs_hip_ctx* c) {
+    if (!c) return;
+    if (c->comm_kind == LBFGS_HIP_COMM_P2P) for (BusSeg* t : c->targets) bus_unmap(t);
+    else if (c->inbox) bus_unmap(c->inbox);
+    if (c->plog) fclose(c->plog);
+    delete c;
+}
 const char* lbfgs_hip_last_error(const lbfgs_hip_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
 int lbfgs_hip_sync(lbfgs_hip_ctx*) { return LBFGS_HIP_OK; }
 void* lbfgs_hip_stream(lbfgs_hip_ctx*) { return nullptr; }
@@ -387,6 +613,15 @@ int lbfgs_hip_ctx_comm_info(lbfgs_hip_ctx* c, lbfgs_hip_comm_info* out) {
     out->ranks_seen = c->comm_kind == LBFGS_HIP_COMM_NONE ? 1 : 0;  // (callback: the library sees no peer itself)
     out->rank_seen = c->shard.rank;
     out->mailbox_placement = -1;
+    out->exclusive_device = c->exclusive ? 1 : 0;
+    if (c->comm_kind == LBFGS_HIP_COMM_RCCL) out->ranks_seen = c->shard.world;
+    if (c->comm_kind == LBFGS_HIP_COMM_P2P) {
+        out->ranks_seen = 1 + c->peers_device + c->peers_host;
+        out->mailbox_placement = c->inbox->placement;
+        out->peers_device = c->peers_device;
+        out->peers_host = c->peers_host;
+        out->p2p_exchanges = c->n_allreduce;
+    }
     out->two_loops = c->n_two_loop;
     out->two_loop_exchanges = c->n_two_loop_allreduce;
     out->allreduce_launches = c->n_allreduce;
@@ -481,6 +716,15 @@ int lbfgs_hip_prof_read(lbfgs_hip_ctx* c, int k, uint64_t* launches, double* ms)
     // the orchestration that follows its measurement (counter passes, budget, signals) runs on the test double
     static const bool fake = getenv("LBFGS_MOCK_FAKE_KERNEL_TIMES") != nullptr;
     if (fake && (k == LBFGS_HIP_K_TWOLOOP_STEP || k == LBFGS_HIP_K_TWOLOOP_ALL)) {
+        if (launches) *launches = 1;
+        if (ms) *ms = 1.0;
+    }
+    // ... and the launch FORM the product would have taken: the persistent kernel for one rank, for P2P ranks that own their GPU
+    // and under RCCL only with the gated exchange agreed on by every rank; LBFGS_HIP_RESIDENT=0 turns it off (bench.ran_as)
+    const char* res = getenv("LBFGS_HIP_RESIDENT");
+    const bool resident = !(res && atoi(res) == 0) && (c->comm_kind == LBFGS_HIP_COMM_NONE || (c->comm_kind == LBFGS_HIP_COMM_P2P && c->exclusive) ||
+                                                        (c->comm_kind == LBFGS_HIP_COMM_RCCL && c->gated));
+    if (fake && k == LBFGS_HIP_K_TWOLOOP_RESIDENT && resident) {
         if (launches) *launches = 1;
         if (ms) *ms = 1.0;
     }

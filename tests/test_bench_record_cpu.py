@@ -435,3 +435,88 @@ def test_n1_a_signal_prints_the_line_measured_so_far(tmp_path, sig):
     time.sleep(0.5)
     left_over = subprocess.run(["pgrep", "-f", "time.sleep(100000)"], capture_output=True, text=True).stdout.split()
     assert not left_over, left_over
+
+
+# ---------------------------------------------------------------------------------------------
+# Round 6: first contact with several ranks, blind (round-5 verdict, next #3).  The rank processes run on the test double, whose
+# P2P and RCCL stand-ins live in POSIX shared memory (tests/support/mock_lbfgs_hip.cpp): the legs really exchange.
+# ---------------------------------------------------------------------------------------------
+def test_a_rank_that_sees_only_its_own_device_takes_it():
+    assert bench.pick_device(5, -1, 8) == 5          # one process per GPU, all devices visible: LOCAL_RANK
+    assert bench.pick_device(5, -1, 1) == 0          # masked per rank: the one device this rank sees
+    assert bench.pick_device(5, -1, 2) == 1 and bench.pick_device(5, 3, 1) == 3 and bench.pick_device(2, -1, 0) == 2
+
+
+def _supervised(args, env_extra, timeout=600):
+    env = dict(os.environ, LBFGS_BENCH_WORKER=os.path.join(ROOT, "tests", "support", "bench_on_mock.py"), OMP_NUM_THREADS="1",
+               LBFGS_MOCK_FAKE_KERNEL_TIMES="1")
+    env.update(env_extra)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0]), p.stderr
+
+
+def test_world_8_with_devices_masked_per_rank_ends_on_host_placed_mailboxes():
+    """`bench.py --gpus 8` where every rank can map only its OWN device's memory (a launcher that masks devices per rank, or a
+    machine without peer access): the "p2p" probe (device mailboxes, strictly) fails on every rank TOGETHER with the IPC error,
+    nothing hangs, and the run goes on with the legs that do work -- host-placed mailboxes and RCCL -- and says which one
+    `value` comes from."""
+    j, err = _supervised(["--gpus", "8", "--steps", "4", "--warmup", "12", "--dim", "100003", "--hist", "5", "--repeats", "2",
+                          "--no-vector-free", "--no-cpu-baseline", "--total-budget", "400", "--pg-backend", "gloo"],
+                         {"LBFGS_MOCK_NO_DEVICE_IPC": "1", "LBFGS_MOCK_RCCL": "1"})
+    cfg = j["config"]
+    assert cfg["probes"]["p2p"]["status"] != "ok" and cfg["probes"]["p2p-host"]["status"] == "ok" and cfg["probes"]["rccl"]["status"] == "ok"
+    assert "hipIpcOpenMemHandle" in err
+    assert "p2p" not in cfg["legs"] and cfg["legs"]["p2p-host"]["status"] == "ok" and cfg["legs"]["rccl"]["status"] == "ok"
+    host = cfg["legs"]["p2p-host"]
+    assert host["mailbox_placement"] == "host" and host["ranks_seen"] == 8 and host["mailboxes_mapped"] == [0, 7]
+    assert cfg["legs"]["rccl"]["ranks_seen"] == 8
+    assert cfg["value_from_leg"] in ("p2p-host", "rccl") and j["n_gpus"] == 8 and j["value"] > 0
+    assert cfg["rccl"]["iters_per_sec"] > 0 and cfg["budget"]["used_s"] < 400
+    for leg in ("p2p-host", "rccl"):   # the per-leg figures one real run will be read by (all there, None where the double has none)
+        for k in ("exchange_us_mean", "exchange_us_p50", "exchange_us_p99", "exchange_us_max", "local_wait_us_mean", "local_wait_us_max",
+                  "exchanges_per_two_loop", "two_loop_ms"):
+            assert k in cfg["legs"][leg], (leg, k)
+
+
+@pytest.mark.parametrize("fault", [False, True], ids=["gated_agreed", "trial_fails_on_one_rank"])
+def test_the_rccl_leg_is_filed_by_what_every_rank_agreed_on(fault):
+    """bench.py's "rccl" leg OPTS IN to the gated exchange (LBFGS_HIP_RCCL_RESIDENT=1: the library's default is a kernel per
+    step).  If the trial at context creation fails on exactly ONE rank after the handshake passed everywhere, every rank must
+    take the kernel-per-step form (the product's collective skeleton, here on three processes of the test double) and the line
+    must call the measurement what it was: "rccl-per-step" -- in `metric`, `config.allreduce`, `config.rccl.says`."""
+    env = {"LBFGS_MOCK_RCCL": "1", "LBFGS_BENCH_LEGS": "rccl"}
+    if fault:
+        env.update(LBFGS_HIP_RESIDENT_FAULT="-1", LBFGS_MOCK_FAULT_RANK="1")
+    j, err = _supervised(["--gpus", "3", "--steps", "4", "--warmup", "12", "--dim", "5000", "--hist", "5", "--repeats", "2",
+                          "--no-vector-free", "--no-cpu-baseline", "--probe-timeout", "60", "--pg-backend", "gloo"], env)
+    cfg = j["config"]
+    leg = cfg["legs"]["rccl"]
+    assert leg["status"] == "ok" and leg["ranks_seen"] == 3
+    want = "rccl-per-step" if fault else "rccl"
+    assert cfg["allreduce"] == cfg["value_from_leg"] == want and j["metric"].endswith(bench.LEG_SAYS[want])
+    assert cfg["rccl"]["says"] == bench.LEG_SAYS[want] and cfg["rccl"]["iters_per_sec"] == pytest.approx(j["value"], rel=1e-3)
+    assert (leg.get("ran_as") == "rccl-per-step") == fault
+    assert j["roofline"]["two_loop"]["resident_kernel"] is (not fault)
+    assert ("gated RCCL exchange is not used" in err) == fault
+
+
+def test_exchange_quantiles_from_the_device_histogram():
+    """lbfgs_hip_comm_info.exchange_hist (ABI 5): quarter-microsecond bins up to 8 us, octaves beyond; bench.py's p50 / p99."""
+    from rust_lbfgs_amd.api import exchange_bin_edges_us, exchange_quantile
+
+    edges = exchange_bin_edges_us()
+    assert len(edges) == 48 and edges[0] == (0.0, 0.25) and edges[31] == (7.75, 8.0) and edges[32] == (8.0, 16.0) and edges[33] == (16.0, 32.0)
+    assert edges[-1][1] == float("inf")
+    h = [0] * 48
+    assert exchange_quantile(h, 0.5) is None
+    h[16] = 98          # 4.00 .. 4.25 us
+    h[34] = 2           # 32 .. 64 us: two stragglers in a hundred
+    assert 4.0 <= exchange_quantile(h, 0.50) <= 4.25 and 4.0 <= exchange_quantile(h, 0.98) <= 4.25
+    assert 32.0 <= exchange_quantile(h, 0.99) <= 64.0 and exchange_quantile(h, 1.0) == 64.0
+    h = [0] * 48
+    h[47] = 5
+    assert exchange_quantile(h, 0.5) == edges[47][0]

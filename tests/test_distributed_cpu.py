@@ -425,3 +425,182 @@ def test_eight_ranks_as_processes_times_threads_tool_on_the_test_double(tmp_path
     line = rec["result"]["legs"]["callback"]["line"]
     assert line["n_gpus"] == 8 and line["value"] > 0 and line["config"]["comm_info"]["world"] == 8
     assert line["config"]["comm_info"]["exchanges_per_two_loop"] == pytest.approx(12.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# Round 6: first contact with several ranks, blind.  The test double now has stand-ins for the P2P and the RCCL communicator over
+# POSIX shared memory (tests/support/mock_lbfgs_hip.cpp "bus"): real rank PROCESSES run dist.py's communicator code -- the handle
+# exchange, the collective fall-back from device- to host-placed mailboxes, the sealing -- and the product's OWN collective
+# skeleton of the gated RCCL exchange's preparation (rust-lbfgs_amd/csrc/ext_protocol.h) with failures injected on ONE rank,
+# which no single GPU can host.
+# ---------------------------------------------------------------------------------------------
+def run_world_env(case, world, tmp_path, extra_env, ok_codes=(0,)):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, LBFGS_ROOT=ROOT, LBFGS_CASE=json.dumps(case), LBFGS_OUT=str(tmp_path), OMP_NUM_THREADS="1")
+    env.update(extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode in ok_codes, r.stderr[-3000:]
+    return r, [json.load(open(tmp_path / f"rank{k}.json")) for k in range(world) if (tmp_path / f"rank{k}.json").exists()]
+
+
+def _same_as_oracle(case, outs):
+    ref_rows, ref_x = oracle_rows(case)
+    for o in outs[1:]:
+        assert o["rows"] == outs[0]["rows"]
+    rows = outs[0]["rows"]
+    assert len(rows) == len(ref_rows)
+    for got, ref in zip(rows, ref_rows):
+        assert got[:3] == ref[:3]
+        for a, b in zip(got[3:], ref[3:]):
+            assert abs(a - b) <= 1e-9 * max(abs(b), 1e-6), (got, ref)
+    x = np.concatenate([np.array(o["x"])[: o["hi"] - o["lo"]] for o in outs])
+    assert np.max(np.abs(x - ref_x)) <= 1e-9 * max(np.max(np.abs(ref_x)), 1e-12)
+
+
+@pytest.mark.parametrize("kind,world,env,placement", [
+    ("p2p", 3, {}, "device"),
+    ("p2p-host", 2, {}, "host"),
+    # every rank sees only its OWN device (a launcher that masks devices per rank): a peer's device-placed mailbox cannot be
+    # mapped -- every rank learns that some rank failed and all of them retry with host-placed mailboxes, collectively
+    ("p2p", 3, {"LBFGS_MOCK_NO_DEVICE_IPC": "1"}, "host"),
+    ("rccl", 3, {"LBFGS_MOCK_RCCL": "1"}, None),
+], ids=["p2p_device", "p2p_host", "p2p_masked_devices_fall_back_to_host", "rccl"])
+def test_bus_communicators_of_the_test_double_run_whole_optimisations(kind, world, env, placement, tmp_path):
+    case = dict(name="quadratic", n=5000, m=5, iters=18, objective="quadratic")
+    r, outs = run_world_env(case, world, tmp_path, dict(env, LBFGS_COMM_KIND=kind, LBFGS_TEST_EXCLUSIVE_DEVICE="1"))
+    assert len(outs) == world and all(o["err"] == 0 for o in outs), [o["errmsg"] for o in outs]
+    assert all(o["placement"] == placement for o in outs)
+    if env.get("LBFGS_MOCK_NO_DEVICE_IPC"):
+        assert "retrying with host-placed mailboxes" in r.stderr
+    _same_as_oracle(case, outs)
+
+
+def test_p2p_device_placement_is_strict_when_asked_for(tmp_path):
+    """bench.py's "p2p" leg means mailboxes in DEVICE memory (kind "p2p-device": no silent retry -- host placement is its own
+    leg): with masked devices every rank must fail together, with the IPC error, and nobody may hang."""
+    case = dict(name="quadratic", n=5000, m=5, iters=5, objective="quadratic")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.replace('ctx = D.sharded_context(', 'import time\ntry:\n    ctx = D.sharded_context(', 1).replace(
+        'exclusive_device=os.environ.get("LBFGS_TEST_EXCLUSIVE_DEVICE") == "1", bounds=bounds)',
+        'exclusive_device=os.environ.get("LBFGS_TEST_EXCLUSIVE_DEVICE") == "1", bounds=bounds)\n'
+        'except R.LbfgsError as e:\n'
+        '    json.dump(dict(rank=rank, refused=str(e)), open(os.path.join(os.environ["LBFGS_OUT"], f"rank{rank}.json"), "w"))\n'
+        '    dist.barrier(); dist.destroy_process_group(); sys.exit(0)', 1))
+    env = dict(os.environ, LBFGS_ROOT=ROOT, LBFGS_CASE=json.dumps(case), LBFGS_OUT=str(tmp_path), OMP_NUM_THREADS="1",
+               LBFGS_COMM_KIND="p2p-device", LBFGS_MOCK_NO_DEVICE_IPC="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    outs = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(3)]
+    assert all("refused" in o for o in outs)
+    assert any("hipIpcOpenMemHandle" in o["refused"] for o in outs) and all("P2P" in o["refused"] or "mailbox" in o["refused"] for o in outs)
+
+
+GATED_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["LBFGS_ROOT"])
+import numpy as np
+import torch.distributed as dist
+import rust_lbfgs_amd as R
+from rust_lbfgs_amd import _ffi, objectives
+from rust_lbfgs_amd import dist as D
+from tests.support import mock
+mock.install()
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n = int(os.environ["LBFGS_TEST_N"])
+out = dict(rank=rank)
+ctx = None
+try:
+    ctx = D.sharded_context(n, kind="rccl", exclusive_device=True)
+    out["resident_form"] = ctx.prof_read(_ffi.K_TWOLOOP_RESIDENT)[0] > 0   # (the double reports the form the product would take)
+    x = np.zeros(ctx.n_local)
+    rows = []
+    R.lbfgs().with_m(4).with_epsilon(0.0).with_max_iterations(6).minimize(
+        x, objectives.Quadratic(), lambda p: rows.append([p.niter, p.fx, p.gnorm]) and False, ctx=ctx)
+    out["rows"] = rows
+except R.LbfgsError as e:
+    out["error"] = str(e)
+# every rank tells the others whether it has a context BEFORE anybody uses one: in a deployment that is the caller's job too
+# (dist.sharded_context(kind="p2p") does it for P2P); the library's part is that ctx_create RETURNS on every rank
+oks = [None] * world
+dist.all_gather_object(oks, ctx is not None)
+out["ranks_with_a_context"] = oks
+if ctx is not None:
+    ctx.close()
+json.dump(out, open(os.path.join(os.environ["LBFGS_OUT"], f"rank{rank}.json"), "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _gated_world(tmp_path, world, n, extra_env):
+    script = tmp_path / "gated_worker.py"
+    script.write_text(GATED_WORKER)
+    log = tmp_path / "protocol"
+    env = dict(os.environ, LBFGS_ROOT=ROOT, LBFGS_OUT=str(tmp_path), OMP_NUM_THREADS="1", LBFGS_MOCK_RCCL="1", LBFGS_TEST_N=str(n),
+               LBFGS_HIP_RCCL_RESIDENT="1", LBFGS_MOCK_FAKE_KERNEL_TIMES="1", LBFGS_MOCK_PROTOCOL_LOG=str(log))
+    env.update(extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    outs = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(world) if (tmp_path / f"rank{k}.json").exists()]
+    logs = [open(f"{log}.rank{k}").read().split() for k in range(world) if os.path.exists(f"{log}.rank{k}")]
+    return r, outs, logs
+
+
+@pytest.mark.parametrize("name,env,n,want", [
+    ("all_fine", {}, 5000, dict(resident=True, errors=[])),
+    # the trial comes back wrong on rank 1 only, AFTER the handshake passed everywhere: every rank must take the kernel-per-step form
+    ("trial_fails_on_one_rank", {"LBFGS_HIP_RESIDENT_FAULT": "-1", "LBFGS_MOCK_FAULT_RANK": "1"}, 5000, dict(resident=False, errors=[])),
+    ("streams_share_a_queue_on_one_rank", {"LBFGS_MOCK_HANDSHAKE_FAIL_RANK": "2"}, 5000, dict(resident=False, errors=[])),
+    # shard_range(600, r, 3) = [0,256) [256,512) [512,600): fine; n = 500 leaves rank 2 EMPTY -- it cannot take the persistent kernel
+    ("empty_shard_on_the_last_rank", {}, 500, dict(resident=False, errors=[])),
+], ids=lambda v: v if isinstance(v, str) else None)
+def test_gated_exchange_preparation_agrees_across_ranks(name, env, n, want, tmp_path):
+    """The product's collective skeleton (ext_protocol.h) on three rank processes of the test double: whatever ONE rank finds,
+    EVERY rank ends with the same launch form, and every rank made the same sequence of collectives (the double tags each
+    all-reduce with what its caller thinks it is; a mismatch is an error)."""
+    r, outs, logs = _gated_world(tmp_path, 3, n, env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(outs) == 3 and all("error" not in o for o in outs), outs
+    assert [o["resident_form"] for o in outs] == [want["resident"]] * 3
+    assert all(o["rows"] == outs[0]["rows"] and len(o["rows"]) == 6 for o in outs)
+    assert len(logs) == 3 and logs[0] == logs[1] == logs[2] and len(logs[0]) > 0
+    if not want["resident"]:
+        assert "gated RCCL exchange is not used" in r.stderr
+
+
+@pytest.mark.parametrize("fault,rank,says", [("-2", 0, "second stream"), ("-3", 2, "before the gated exchange's trial")])
+def test_a_rank_local_failure_in_the_preparation_leaves_no_peer_waiting(fault, rank, says, tmp_path):
+    """Round-5 advice: a rank that fails LOCALLY between the collectives of lbfgs_hip_ctx_create (stream creation, allocation, the
+    trial's launch) used to return at once and leave its peers inside ncclAllReduce for ever.  Now it votes "bad", takes part in
+    every collective that follows -- the trial's all-reduce included -- and only then returns its error: the other ranks get
+    their contexts (kernel per step) and RETURN.  Here: world 3, the failure injected on one rank."""
+    script = tmp_path / "gated_worker.py"
+    script.write_text(GATED_WORKER.replace(
+        "    x = np.zeros(ctx.n_local)",
+        "    oks0 = [None] * world\n    dist.all_gather_object(oks0, True)\n    if not all(oks0):\n        raise R.LbfgsError(-1, 'a peer has no context: not optimising')\n    x = np.zeros(ctx.n_local)", 1).replace(
+        "except R.LbfgsError as e:\n    out[\"error\"] = str(e)",
+        "except R.LbfgsError as e:\n    out[\"error\"] = str(e)\n    if ctx is None:\n        oks0 = [None] * world\n        dist.all_gather_object(oks0, False)", 1))
+    log = tmp_path / "protocol"
+    env = dict(os.environ, LBFGS_ROOT=ROOT, LBFGS_OUT=str(tmp_path), OMP_NUM_THREADS="1", LBFGS_MOCK_RCCL="1", LBFGS_TEST_N="5000",
+               LBFGS_HIP_RCCL_RESIDENT="1", LBFGS_MOCK_FAKE_KERNEL_TIMES="1", LBFGS_MOCK_PROTOCOL_LOG=str(log),
+               LBFGS_HIP_RESIDENT_FAULT=fault, LBFGS_MOCK_FAULT_RANK=str(rank))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    outs = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(3)]
+    for o in outs:
+        if o["rank"] == rank:
+            assert "injected" in o["error"] and says in o["error"], o
+        else:  # a context, of the kernel-per-step form -- which it does not use, because a peer has none
+            assert o.get("resident_form") is False and "a peer has no context" in o["error"], o
+        assert o["ranks_with_a_context"] == [k != rank for k in range(3)]
+    logs = [open(f"{log}.rank{k}").read().split() for k in range(3)]
+    assert logs[0] == logs[1] == logs[2] and len(logs[0]) >= 2      # the same collectives on every rank, the failing one included

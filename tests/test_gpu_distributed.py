@@ -271,6 +271,9 @@ def test_bench_contract_line(world, launch, kind, tmp_path):
                 leg = legs[name]
                 assert leg["ranks_seen"] == 2 and leg["mailbox_placement"] == placement, leg
                 assert leg["exchanges_per_two_loop"] >= 10 and leg["exchange_us_mean"] > 0.0, leg  # (2 * bound, bound <= m = 10)
+                # (round 6, ABI 5) ... and how the exchanges are DISTRIBUTED: quantiles from the device's histogram, the worst one
+                assert 0.0 < leg["exchange_us_p50"] <= leg["exchange_us_p99"] <= leg["exchange_us_max"] + 0.25, leg
+                assert leg["local_wait_us_max"] >= 0.0
         # ... and an N > 1 line carries the CPU baseline (timed by the supervisor, which touches no GPU)
         assert j["cpu_baseline"]["value"] > 0 and "supervisor" in j["cpu_baseline"]["where"]
 
@@ -389,6 +392,9 @@ def test_bench_p2p_leg_with_the_persistent_kernel(tmp_path):
     assert leg["exchanges_per_two_loop"] == pytest.approx(20.0)       # m = 10, history full: one exchange per hand-off
     assert 0.0 < leg["exchange_us_mean"] < 1000.0 and r["exchange_us_mean"] == leg["exchange_us_mean"]
     assert leg["local_wait_us_mean"] is not None and r["exchanges_per_two_loop"] == pytest.approx(20.0)
+    # (round 6, ABI 5) the distribution behind the mean, from workgroup 0's fire-and-forget histogram updates inside the persistent kernel
+    assert 0.0 < leg["exchange_us_p50"] <= leg["exchange_us_p99"] <= leg["exchange_us_max"] + 0.25 and leg["exchange_us_p50"] < 1000.0, leg
+    assert ci["exchange_hist_counted"] > 0 and leg["local_wait_us_max"] >= leg["local_wait_us_mean"]
     assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] == 1
 
 
@@ -469,6 +475,8 @@ def test_rccl_gated_exchange_under_the_persistent_kernel(n, m, owl, monkeypatch)
             b.minimize(x, objectives.Logistic() if owl else objectives.Quadratic(),
                        lambda p: rows.append((p.niter, p.neval, p.ncall, p.fx, p.xnorm, p.gnorm, p.step)) and False, ctx=ctx)
             ci = ctx.comm_info()
+            assert sum(ci["exchange_hist"]["two_loop"]) == ci["timed_exchanges"]["two_loop"]   # (ABI 5: every timed exchange is in a bin)
+            assert ci["exchange_us_max"]["two_loop"] * ci["timed_exchanges"]["two_loop"] >= ci["exchange_us"]["two_loop"] * 0.999
             stats = dict(resident=ctx.resident_two_loops(), on_chip=ctx.resident_elements(), two_loops=ci["two_loops"],
                          exchanges=ci["two_loop_exchanges"], timed=ci["timed_exchanges"]["two_loop"],
                          us=ci["exchange_us"]["two_loop"], ranks_seen=ci["ranks_seen"], fallbacks=ci["resident_fallbacks"])
