@@ -40,7 +40,8 @@ extern "C" {
 #endif
 
 /* 5: lbfgs_hip_comm_info grew the DISTRIBUTION of the cross-rank exchanges (exchange_us_max, local_wait_us_max,
- *    exchange_hist): one multi-GPU run is then enough to place a leg on the scaling model's latency axis (round 6).
+ *    exchange_hist): one multi-GPU run is then enough to place a leg on the scaling model's latency axis;
+ *    lbfgs_hip_objective_owlqn_trial_update (round 6).
  * 4: lbfgs_evaluator (lbfgs_solver.h) grew device_probe / device_accept: deferred trial points for device closures;
  *    lbfgs_hip_objective_owlqn_first_trial (round 5).
  * 3: lbfgs_hip_ctx_comm_info / lbfgs_hip_comm_info (round 4); lbfgs_hip_sync, lbfgs_hip_vec_download and
@@ -403,6 +404,19 @@ int lbfgs_hip_objective_owlqn_line_eval(const lbfgs_hip_objective* obj, lbfgs_hi
 int lbfgs_hip_objective_owlqn_first_trial(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
                                           const lbfgs_hip_vec* d, double step, lbfgs_hip_vec* wp, lbfgs_hip_vec* g,
                                           lbfgs_hip_vec* pg, double c, uint64_t start, uint64_t end, int out_slot);
+
+/* An OWL-QN trial that ALSO does IterationData::update for its point (lbfgs.rs:640-656), speculatively (ABI 5): next to what
+ * lbfgs_hip_objective_owlqn_line_eval / _first_trial (first != 0) leave, s = x - xp and y = g - gp go into history slot `slot`
+ * (the slot the update is about to fill), ys[slot] is set, and board[upd_slot+0] = ||s||^2, +1 = y.s, +2 = y.y -- the first
+ * three sums of lbfgs_hip_history_update, which the caller then skips.  A backtracking search accepts the trial it evaluated
+ * LAST (line.rs:747-777), so the last trial's s, y and sums are the update's; a search that failed and was reverted
+ * (line.rs:213-220) must run lbfgs_hip_history_update itself (x == xp then: "x not changed", lbfgs.rs:646).  4r 6w (first: 4r 7w)
+ * against 3r 3w + 4r 2w.  Not for Powell damping (lbfgs.rs:664-689 needs s.bs as well).  Objectives without a fused form run
+ * the separate passes (upd_slot then needs the 7 slots of lbfgs_hip_history_update). */
+int lbfgs_hip_objective_owlqn_trial_update(const lbfgs_hip_objective* obj, lbfgs_hip_history* h, int slot, lbfgs_hip_vec* x,
+                                           const lbfgs_hip_vec* xp, const lbfgs_hip_vec* d, double step, lbfgs_hip_vec* wp,
+                                           int first, lbfgs_hip_vec* g, const lbfgs_hip_vec* gp, lbfgs_hip_vec* pg, double c,
+                                           uint64_t start, uint64_t end, int out_slot, int upd_slot);
 
 /* ------------------------------------------------------------------------- */
 /* measurement                                                                 */

@@ -370,12 +370,13 @@ where
 }
 
 // ---- RAII handles ---------------------------------------------------------------------------------
-struct Context {
+/// Device, stream, scalar board: what every `DeviceVec` of one problem lives on (`lbfgs_hip_ctx`).
+pub struct Context {
     raw: *mut ffi::lbfgs_hip_ctx,
 }
 
 impl Context {
-    fn new(device: c_int, n: usize) -> Result<Self> {
+    pub fn new(device: c_int, n: usize) -> Result<Self> {
         // the #[repr(C)] mirrors in ffi.rs are passed by value: never talk to a library of another ABI version
         if unsafe { ffi::lbfgs_hip_abi_version() != ffi::LBFGS_HIP_ABI_VERSION } {
             bail!("liblbfgs_hip reports ABI version {}, this crate was written against {}",
@@ -394,6 +395,107 @@ impl Context {
 impl Drop for Context {
     fn drop(&mut self) {
         unsafe { ffi::lbfgs_hip_ctx_destroy(self.raw) }
+    }
+}
+
+// ---- the seam the crate itself names: `trait LbfgsMath` (src/math.rs:4-29) on device-resident vectors -----------------
+// The reference implements it for `[f64]` (src/math.rs:31-82) and calls it from `Problem`, `lbfgs_two_loop_recursion`,
+// `IterationData::update` and `propagate`.  liblbfgs_hip.so exports ONE symbol per method; this is the `impl` a port of the
+// crate's own host code would sit on (the solver above takes the fused entry points instead: fewer passes, same results).
+// UNCOMPILED like the rest of this file; tests/test_abi_exports.py checks every `ffi::` name against ffi.rs.
+/// A device-resident n-vector (`Vec<f64>` of core.rs:24-39 kept in HBM).  Lives no longer than its `Context`.
+pub struct DeviceVec<'c> {
+    raw: *mut ffi::lbfgs_hip_vec,
+    ctx: &'c Context,
+    n: usize,
+}
+
+impl<'c> DeviceVec<'c> {
+    /// vec![0.0; n]
+    pub fn zeros(ctx: &'c Context, n: usize) -> Result<Self> {
+        let mut raw = ptr::null_mut();
+        let rc = unsafe { ffi::lbfgs_hip_vec_alloc(ctx.raw, &mut raw) };
+        if rc != ffi::LBFGS_HIP_OK {
+            bail!("lbfgs_hip_vec_alloc failed ({}): {}", rc, cstr(unsafe { ffi::lbfgs_hip_last_error(ctx.raw) }));
+        }
+        Ok(DeviceVec { raw, ctx, n })
+    }
+    pub fn from_slice(ctx: &'c Context, host: &[f64]) -> Result<Self> {
+        let v = Self::zeros(ctx, host.len())?;
+        v.ok(unsafe { ffi::lbfgs_hip_vec_upload(v.raw, host.as_ptr(), host.len() as u64) })?;
+        Ok(v)
+    }
+    pub fn to_vec(&self) -> Result<Vec<f64>> {
+        let mut host = vec![0.0; self.n];
+        self.ok(unsafe { ffi::lbfgs_hip_vec_download(self.raw, host.as_mut_ptr(), self.n as u64) })?;
+        Ok(host)
+    }
+    fn ok(&self, rc: c_int) -> Result<()> {
+        if rc == ffi::LBFGS_HIP_OK { Ok(()) } else { Err(anyhow!("{} (status {})", cstr(unsafe { ffi::lbfgs_hip_last_error(self.ctx.raw) }), rc)) }
+    }
+}
+
+impl<'c> Drop for DeviceVec<'c> {
+    fn drop(&mut self) {
+        unsafe { ffi::lbfgs_hip_vec_free(self.raw) }
+    }
+}
+
+/// `trait LbfgsMath<T>` of src/math.rs:4-29 with the other operand device-resident too: same names, same meaning, same
+/// arithmetic (y + (c*x) in two roundings; sums within 1e-10 of the reference's sequential ones).  A failing HIP call panics,
+/// as an out-of-bounds slice would in the reference: the trait's methods return no `Result`.
+pub trait LbfgsMath {
+    /// y += c*x
+    fn vecadd(&mut self, x: &Self, c: f64);
+    /// s = x.dot(y)
+    fn vecdot(&self, other: &Self) -> f64;
+    /// y = x
+    fn veccpy(&mut self, x: &Self);
+    /// y = -x
+    fn vecncpy(&mut self, x: &Self);
+    /// z = x - y
+    fn vecdiff(&mut self, x: &Self, y: &Self);
+    /// y *= c
+    fn vecscale(&mut self, c: f64);
+    /// ||x||
+    fn vec2norm(&self) -> f64;
+    /// 1 / ||x||
+    fn vec2norminv(&self) -> f64;
+}
+
+const MATH_SLOT: c_int = 250; // a board slot the solver does not use (include/lbfgs_hip.h: 256 slots)
+
+impl<'c> LbfgsMath for DeviceVec<'c> {
+    fn vecadd(&mut self, x: &Self, c: f64) {
+        self.ok(unsafe { ffi::lbfgs_hip_vecadd(self.raw, x.raw, c) }).unwrap()
+    }
+    fn vecdot(&self, other: &Self) -> f64 {
+        let mut s = 0.0;
+        self.ok(unsafe { ffi::lbfgs_hip_vecdot(self.raw, other.raw, MATH_SLOT) }).unwrap();
+        self.ok(unsafe { ffi::lbfgs_hip_scalars_read(self.ctx.raw, MATH_SLOT, 1, &mut s) }).unwrap();
+        s
+    }
+    fn veccpy(&mut self, x: &Self) {
+        self.ok(unsafe { ffi::lbfgs_hip_veccpy(self.raw, x.raw) }).unwrap()
+    }
+    fn vecncpy(&mut self, x: &Self) {
+        self.ok(unsafe { ffi::lbfgs_hip_vecncpy(self.raw, x.raw) }).unwrap()
+    }
+    fn vecdiff(&mut self, x: &Self, y: &Self) {
+        self.ok(unsafe { ffi::lbfgs_hip_vecdiff(self.raw, x.raw, y.raw) }).unwrap()
+    }
+    fn vecscale(&mut self, c: f64) {
+        self.ok(unsafe { ffi::lbfgs_hip_vecscale(self.raw, c) }).unwrap()
+    }
+    fn vec2norm(&self) -> f64 {
+        let mut s = 0.0;
+        self.ok(unsafe { ffi::lbfgs_hip_vec2norm(self.raw, MATH_SLOT, &mut s) }).unwrap();
+        s
+    }
+    fn vec2norminv(&self) -> f64 {
+        let mut s = 0.0;
+        self.ok(unsafe { ffi::lbfgs_hip_vec2norminv(self.raw, MATH_SLOT, &mut s) }).unwrap();
+        s
     }
 }
 

@@ -128,7 +128,7 @@ lbfgs_hip_history_scalars_read lbfgs_hip_history_scalars_write lbfgs_hip_history
 lbfgs_hip_two_loop lbfgs_hip_two_loop_from lbfgs_hip_two_loop_owlqn lbfgs_hip_two_loop_gram lbfgs_hip_two_loop_unfused
 lbfgs_hip_owlqn_post_eval lbfgs_hip_orthant_select lbfgs_hip_constrain_direction
 lbfgs_hip_objective_eval lbfgs_hip_objective_line_eval lbfgs_hip_objective_owlqn_line_eval
-lbfgs_hip_objective_owlqn_first_trial
+lbfgs_hip_objective_owlqn_first_trial lbfgs_hip_objective_owlqn_trial_update
 lbfgs_hip_objective_is_elementwise lbfgs_hip_objective_line_probe lbfgs_hip_history_update_from_step
 lbfgs_hip_lj_cells_stats
 lbfgs_hip_device_buffer_create
@@ -217,6 +217,7 @@ def declare(L):
         "lbfgs_hip_history_update_from_step": (i, [vp, i, C.POINTER(Objective), vp, vp, vp, dbl, vp, vp, dbl, i, i]),
         "lbfgs_hip_objective_owlqn_line_eval": (i, [C.POINTER(Objective), vp, vp, vp, dbl, vp, vp, vp, dbl, u64, u64, i]),
         "lbfgs_hip_objective_owlqn_first_trial": (i, [C.POINTER(Objective), vp, vp, vp, dbl, vp, vp, vp, dbl, u64, u64, i]),
+        "lbfgs_hip_objective_owlqn_trial_update": (i, [C.POINTER(Objective), vp, i, vp, vp, vp, dbl, vp, i, vp, vp, vp, dbl, u64, u64, i, i]),
         "lbfgs_hip_device_buffer_create": (i, [vp, vp, u64, C.POINTER(vp)]),
         "lbfgs_hip_host_buffer_create": (i, [vp, u64, C.POINTER(vp)]),
         "lbfgs_hip_host_buffer_destroy": (None, [vp, vp]),

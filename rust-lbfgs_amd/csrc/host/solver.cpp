@@ -196,6 +196,9 @@ struct lbfgs_state {
     double t_eval = 0.0;
     uint64_t trials = 0;  // trial steps evaluated by the running search
     bool orthant_pending = false;  // OWL-QN: wp of the running search is still to be formed, by its first trial's kernel
+    // OWL-QN with a built-in objective: every trial of propagate's search also does IterationData::update for its point
+    // (lbfgs_hip_objective_owlqn_trial_update) -- a backtracking search accepts the trial it evaluated last (line.rs:747-777)
+    bool update_in_trials = false, update_done = false;
     std::string err, ls_err;
 
     bool owlqn() const { return vars.orthantwise != 0; }
@@ -418,7 +421,13 @@ int trial(lbfgs_state* st, double t, bool want_dg, double* dg_out) {
         // OWL-QN trial in one pass: projected line step + evaluate + x1norm + pseudo-gradient (+ g.d); the first trial of a
         // search also forms the orthant of the new point (line.rs:735, core.rs:167-180) -- see search_backtracking
         TRY(owl_range(st));
-        if (st->orthant_pending) {
+        if (st->update_in_trials) {
+            const int first = st->orthant_pending ? 1 : 0;
+            st->orthant_pending = false;
+            TRYB(st, lbfgs_hip_objective_owlqn_trial_update(&st->eval.builtin, st->hist, st->end, st->x, st->xp, st->d, t, st->wp, first,
+                                                            st->gx, st->gp, st->pg, st->vars.owl_c, st->owl_start, st->owl_end, S_F, S_UPD));
+            st->update_done = true;
+        } else if (st->orthant_pending) {
             st->orthant_pending = false;
             TRYB(st, lbfgs_hip_objective_owlqn_first_trial(&st->eval.builtin, st->x, st->xp, st->d, t, st->wp, st->gx, st->pg,
                                                            st->vars.owl_c, st->owl_start, st->owl_end, S_F));
@@ -645,9 +654,14 @@ int line_search_find(lbfgs_state* st, double& step, uint64_t* ncall, bool may_de
                        ((st->eval.kind == LBFGS_EVAL_BUILTIN && st->eval.fuse_line_eval >= 2 &&
                          lbfgs_hip_objective_is_elementwise(&st->eval.builtin)) ||
                         (st->eval.kind == LBFGS_EVAL_DEVICE && st->eval.device_probe != nullptr));
+    // OWL-QN (always backtracking: line.rs:204-211): the trials do the history update themselves.  Not with Powell damping (its
+    // s.bs would be a ninth sum of that kernel), not for the stand-alone line search (no history).
+    st->update_done = false;
+    st->update_in_trials = may_defer && st->owlqn() && st->eval.kind == LBFGS_EVAL_BUILTIN && st->eval.fuse_line_eval != 0 &&
+                           !st->vars.damping && st->hist != nullptr;
     struct Reset {
         lbfgs_state* s;
-        ~Reset() { s->defer_trials = false; }
+        ~Reset() { s->defer_trials = false; s->update_in_trials = false; }
     } reset{st};
     if (!sign_positive(step)) {
         char b[96];
@@ -928,6 +942,7 @@ int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
     // decision sits in between (Powell damping), the early read is kept.
     const int damping = st->vars.damping;
     const bool early = damping || !st->ls_err.empty();
+    bool updated_by_trial = false;
     if (st->point_deferred && st->eval.kind == LBFGS_EVAL_DEVICE) {  // probes of a device closure: form the accepted point now
         st->point_deferred = false;
         const int rc_acc = materialise_device_point(st);
@@ -943,8 +958,13 @@ int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
         TRYB(st, lbfgs_hip_history_update_from_step(st->hist, st->end, &st->eval.builtin, st->x, st->xp, st->d, st->t_eval,
                                                     st->gx, st->gp, st->step, damping, S_UPD));
         st->point_deferred = false;
+    } else if (st->update_done && st->ls_err.empty()) {
+        // the accepted trial -- the last one the search evaluated -- has filled the slot and left ||s||^2, y.s, y.y at S_UPD
+        // (a search that failed was reverted: x == xp, and the update below must find exactly that, lbfgs.rs:646)
+        updated_by_trial = true;
     } else
         TRYB(st, lbfgs_hip_history_update(st->hist, st->end, st->x, st->xp, st->gx, st->gp, st->step, damping, S_UPD));
+    st->update_done = false;
     double u[S_END_BLOCK - S_UPD] = {0};
     auto check_update = [&]() -> int {
         const double snorm = std::sqrt(u[0]), yy = u[2];
@@ -1011,7 +1031,13 @@ int lbfgs_propagate(lbfgs_state* st, lbfgs_progress* out) {  // lbfgs.rs:503-560
     if (st->owlqn() && !projected)  // :554, orthantwise.rs:140-161 (after dnorm, as in the reference)
         TRYB(st, lbfgs_hip_constrain_direction(st->d_next, st->pg, st->owl_start, st->owl_end, S_DNORM2C));
     // plain L-BFGS never writes S_DNORM2C..: asking for them would force the copy path of scalars_read every iteration
-    TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_UPD, (st->owlqn() ? S_END_BLOCK : S_DNORM2C) - S_UPD, u));
+    if (updated_by_trial) {
+        // (the trial's kernel wrote three of the update's seven slots: asking for the others would force the copy path of
+        // scalars_read -- a copy kernel and a stream synchronisation -- on every iteration)
+        TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_UPD, 3, u));
+        TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_DNORM2, S_END_BLOCK - S_DNORM2, u + (S_DNORM2 - S_UPD)));
+    } else
+        TRYB(st, lbfgs_hip_scalars_read(st->ctx, S_UPD, (st->owlqn() ? S_END_BLOCK : S_DNORM2C) - S_UPD, u));
     if (!early) TRY(check_update());
     TRYB(st, lbfgs_hip_vec_swap(st->d, st->d_next));  // the update succeeded: the new direction takes effect (:536-540)
     st->end = new_end;

@@ -1580,42 +1580,64 @@ int lbfgs_hip_history_update_from_step(lbfgs_hip_history* h, int slot, const lbf
 }  // extern "C"  (the template below needs C++ linkage)
 
 namespace {
-// one OWL-QN trial; FIRST: wp is an OUTPUT formed from xp and the previous pg (ops.h OpObjOwlLineEval<Obj, true>)
-template <bool FIRST>
+// one OWL-QN trial; FIRST: wp is an OUTPUT formed from xp and the previous pg (ops.h OpObjOwlLineEval<Obj, true>);
+// UPD: the trial also fills history slot `slot` (s, y, ys) and leaves ||s||^2, y.s, y.y at board[upd_slot ..]
+template <bool FIRST, bool UPD>
 int owlqn_trial(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp, const lbfgs_hip_vec* d, double step,
-                lbfgs_hip_vec* wp, lbfgs_hip_vec* g, lbfgs_hip_vec* pg, double c, uint64_t start, uint64_t end, int out_slot) {
+                lbfgs_hip_vec* wp, lbfgs_hip_vec* g, lbfgs_hip_vec* pg, double c, uint64_t start, uint64_t end, int out_slot,
+                lbfgs_hip_history* h = nullptr, int slot = 0, const lbfgs_hip_vec* gp = nullptr, int upd_slot = 0) {
     if (!obj || !same_ctx(x, xp) || !same_ctx(x, d) || !same_ctx(x, wp) || !same_ctx(x, g) || !same_ctx(x, pg) ||
         !slot_ok(out_slot, 5))
         return LBFGS_HIP_ERR_ARG;
     lbfgs_hip_ctx* ctx = x->ctx;
+    if (UPD && (!h || h->ctx != ctx || slot < 0 || slot >= h->m || !same_ctx(x, gp) || !slot_ok(upd_slot, 3))) return LBFGS_HIP_ERR_ARG;
     double* b = ctx->board + out_slot;
-    double* outs[5] = {b, b + 1, b + 2, b + 3, b + 4};
+    double* u = ctx->board + upd_slot;
+    double* outs[8] = {b, b + 1, b + 2, b + 3, b + 4, u, u + 1, u + 2};
+    // (UPD) lbfgs.rs:656 self.ys = ys: stored by the kernel itself when its totals are final, else copied after the all-reduce
+    const bool single = ctx->comm_kind == LBFGS_HIP_COMM_NONE || ctx->comm_kind == LBFGS_HIP_COMM_P2P;
     auto fill = [&](auto& op) {
         op.in[0] = xp->p; op.in[1] = d->p; op.in[2] = FIRST ? pg->p : wp->p;
         op.out[0] = x->p; op.out[1] = g->p; op.out[2] = pg->p;
         if (FIRST) op.out[3] = wp->p;
+        if (UPD) {
+            op.in[3] = gp->p;
+            op.out[op.O_S] = h->s[slot]->p;
+            op.out[op.O_S + 1] = h->y[slot]->p;
+        }
         op.step = step; op.c = c; op.start = start; op.end = end; op.obj = {obj->seed_a, obj->seed_b};
     };
+    int rc;
     switch (obj->kind) {
         case LBFGS_HIP_OBJ_QUADRATIC: {
-            OpObjOwlLineEval<ObjQuadratic, FIRST> op{};
+            OpObjOwlLineEval<ObjQuadratic, FIRST, UPD> op{};
             fill(op);
-            return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
+            rc = launch(ctx, LBFGS_HIP_K_EVAL, op, outs, (UPD && single) ? h->ys + slot : nullptr, 6);
+            break;
         }
         case LBFGS_HIP_OBJ_LOGISTIC: {
-            OpObjOwlLineEval<ObjLogistic, FIRST> op{};
+            OpObjOwlLineEval<ObjLogistic, FIRST, UPD> op{};
             fill(op);
-            return launch(ctx, LBFGS_HIP_K_EVAL, op, outs);
+            rc = launch(ctx, LBFGS_HIP_K_EVAL, op, outs, (UPD && single) ? h->ys + slot : nullptr, 6);
+            break;
         }
         default: {  // objectives without a fused form: the separate passes
-            int rc = LBFGS_HIP_OK;
+            rc = LBFGS_HIP_OK;
             if (FIRST && (rc = lbfgs_hip_orthant_select(wp, xp, pg)) != LBFGS_HIP_OK) return rc;
             if ((rc = lbfgs_hip_line_step(x, xp, d, step, wp, start, end)) != LBFGS_HIP_OK) return rc;
             if ((rc = lbfgs_hip_objective_eval(obj, x, g, out_slot)) != LBFGS_HIP_OK) return rc;
             if ((rc = lbfgs_hip_owlqn_post_eval(x, g, pg, c, start, end, out_slot + 2)) != LBFGS_HIP_OK) return rc;
-            return lbfgs_hip_vecdot(g, d, out_slot + 1);
+            if ((rc = lbfgs_hip_vecdot(g, d, out_slot + 1)) != LBFGS_HIP_OK) return rc;
+            if (UPD) {  // (the update's own pass; its sums 3..6 land in a scratch copy of the layout: only the first three are asked for)
+                if (!slot_ok(upd_slot, 7)) return LBFGS_HIP_ERR_ARG;
+                return lbfgs_hip_history_update(h, slot, x, xp, g, gp, step, 0, upd_slot);
+            }
+            return rc;
         }
     }
+    if (rc != LBFGS_HIP_OK) return rc;
+    if (UPD && !single) HIP_TRY(ctx, hipMemcpyAsync(h->ys + slot, u + 1, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return LBFGS_HIP_OK;
 }
 }  // namespace
 
@@ -1624,13 +1646,21 @@ extern "C" {
 int lbfgs_hip_objective_owlqn_line_eval(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
                                         const lbfgs_hip_vec* d, double step, const lbfgs_hip_vec* wp, lbfgs_hip_vec* g,
                                         lbfgs_hip_vec* pg, double c, uint64_t start, uint64_t end, int out_slot) {
-    return owlqn_trial<false>(obj, x, xp, d, step, const_cast<lbfgs_hip_vec*>(wp), g, pg, c, start, end, out_slot);
+    return owlqn_trial<false, false>(obj, x, xp, d, step, const_cast<lbfgs_hip_vec*>(wp), g, pg, c, start, end, out_slot);
 }
 
 int lbfgs_hip_objective_owlqn_first_trial(const lbfgs_hip_objective* obj, lbfgs_hip_vec* x, const lbfgs_hip_vec* xp,
                                           const lbfgs_hip_vec* d, double step, lbfgs_hip_vec* wp, lbfgs_hip_vec* g,
                                           lbfgs_hip_vec* pg, double c, uint64_t start, uint64_t end, int out_slot) {
-    return owlqn_trial<true>(obj, x, xp, d, step, wp, g, pg, c, start, end, out_slot);
+    return owlqn_trial<true, false>(obj, x, xp, d, step, wp, g, pg, c, start, end, out_slot);
+}
+
+int lbfgs_hip_objective_owlqn_trial_update(const lbfgs_hip_objective* obj, lbfgs_hip_history* h, int slot, lbfgs_hip_vec* x,
+                                           const lbfgs_hip_vec* xp, const lbfgs_hip_vec* d, double step, lbfgs_hip_vec* wp,
+                                           int first, lbfgs_hip_vec* g, const lbfgs_hip_vec* gp, lbfgs_hip_vec* pg, double c,
+                                           uint64_t start, uint64_t end, int out_slot, int upd_slot) {
+    return first ? owlqn_trial<true, true>(obj, x, xp, d, step, wp, g, pg, c, start, end, out_slot, h, slot, gp, upd_slot)
+                 : owlqn_trial<false, true>(obj, x, xp, d, step, wp, g, pg, c, start, end, out_slot, h, slot, gp, upd_slot);
 }
 
 }  // extern "C"

@@ -577,12 +577,18 @@ struct OpHistUpdateFromStep {
 //   orthant wp_i = xp_i == 0 ? signum(-pg_i) : signum(xp_i) is formed on the fly from xp (streamed anyway) and the PREVIOUS
 //   pseudo-gradient -- in[2] is pg, read before this element's new pg is written over it -- and stored for the later trials.
 //   3r 4w, where orthant_select (2r 1w) + the trial (3r 3w) move 5r 4w.
-template <class Obj, bool FIRST = false>
+// UPD = true (round 6): the trial ALSO does IterationData::update for its point (lbfgs.rs:640-656), speculatively: s = x - xp,
+//   y = g - gp into the history slot the update will fill, and ||s||^2, y.s, y.y.  A backtracking search accepts the trial it
+//   evaluated last (line.rs:747-777), so the last trial's s, y and sums ARE the update's; under OWL-QN the first trial is
+//   accepted almost always (config 3: 1.00 trials per search), and a rejected trial has cost one read and two writes more.
+//   +1r 2w, where the update's own kernel moves 4r 2w.  (Not with Powell damping: its s.bs would be a ninth sum.)
+template <class Obj, bool FIRST = false, bool UPD = false>
 struct OpObjOwlLineEval {
-    static constexpr int NIN = 3, NOUT = FIRST ? 4 : 3, NRED = 5;
+    static constexpr int NIN = 3 + (UPD ? 1 : 0), NOUT = 3 + (FIRST ? 1 : 0) + (UPD ? 2 : 0), NRED = 5 + (UPD ? 3 : 0);
     static constexpr int TUNE_GRID_X32 = obj_grid<Obj, 27>::value;
-    const double* in[3];  // xp, d, wp (FIRST: the previous pg)
-    double* out[4];       // x, g, pg (FIRST: + wp)
+    static constexpr int O_S = 3 + (FIRST ? 1 : 0);  // out[O_S] = s, out[O_S + 1] = y
+    const double* in[4];  // xp, d, wp (FIRST: the previous pg), UPD: gp
+    double* out[6];       // x, g, pg (FIRST: + wp) (UPD: + s, y)
     double step, c;
     uint64_t start, end;
     Obj obj;
@@ -619,6 +625,14 @@ struct OpObjOwlLineEval {
         acc[1] += g * v[1];
         acc[3] += pg * pg;
         acc[4] += x * x;
+        if constexpr (UPD) {                                   // lbfgs.rs:642-654 (OpHistUpdate's arithmetic)
+            const double s = x - v[0];
+            const double y = g - v[3];
+            w[O_S] = s; w[O_S + 1] = y;
+            acc[5] += s * s;
+            acc[6] += y * s;
+            acc[7] += y * y;
+        }
     }
 };
 

@@ -158,3 +158,13 @@ def objective_owlqn_first_trial(obj: BuiltinObjective, x, xp, d, step, wp, g, pg
     o = obj.c_struct(x.ctx)
     x.ctx.check(x._L.lbfgs_hip_objective_owlqn_first_trial(C.byref(o), x._h, xp._h, d._h, float(step), wp._h, g._h, pg._h,
                                                            float(c), start, end, out_slot))
+
+
+def objective_owlqn_trial_update(obj: BuiltinObjective, hist: History, slot, x, xp, d, step, wp, first, g, gp, pg, c, start, end,
+                                 out_slot=0, upd_slot=6):
+    """An OWL-QN trial that also does IterationData::update for its point (lbfgs.rs:640-656): s, y into history slot `slot`,
+    ||s||^2, y.s, y.y at board[upd_slot ..].  `first`: the trial also forms the orthant (objective_owlqn_first_trial).  4r 6w."""
+    o = obj.c_struct(x.ctx)
+    x.ctx.check(x._L.lbfgs_hip_objective_owlqn_trial_update(C.byref(o), hist._h, slot, x._h, xp._h, d._h, float(step), wp._h,
+                                                            int(bool(first)), g._h, gp._h, pg._h, float(c), start, end,
+                                                            out_slot, upd_slot))

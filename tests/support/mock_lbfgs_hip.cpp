@@ -706,6 +706,17 @@ int lbfgs_hip_objective_owlqn_first_trial(const lbfgs_hip_objective* obj, lbfgs_
     return lbfgs_hip_objective_owlqn_line_eval(obj, x, xp, d, step, wp, g, pg, c, start, end, o);
 }
 
+int lbfgs_hip_objective_owlqn_trial_update(const lbfgs_hip_objective* obj, lbfgs_hip_history* h, int slot, lbfgs_hip_vec* x,
+                                           const lbfgs_hip_vec* xp, const lbfgs_hip_vec* d, double step, lbfgs_hip_vec* wp,
+                                           int first, lbfgs_hip_vec* g, const lbfgs_hip_vec* gp, lbfgs_hip_vec* pg, double c,
+                                           uint64_t start, uint64_t end, int o, int upd) {
+    // the trial, then IterationData::update for its point (lbfgs.rs:640-656): the unfused sequence, bit for bit
+    int rc = first ? lbfgs_hip_objective_owlqn_first_trial(obj, x, xp, d, step, wp, g, pg, c, start, end, o)
+                   : lbfgs_hip_objective_owlqn_line_eval(obj, x, xp, d, step, wp, g, pg, c, start, end, o);
+    if (rc) return rc;
+    return lbfgs_hip_history_update(h, slot, x, xp, g, gp, step, 0, upd);
+}
+
 int lbfgs_hip_prof_enable(lbfgs_hip_ctx*, int) { return LBFGS_HIP_OK; }
 int lbfgs_hip_prof_reset(lbfgs_hip_ctx*) { return LBFGS_HIP_OK; }
 int lbfgs_hip_prof_read(lbfgs_hip_ctx* c, int k, uint64_t* launches, double* ms) {

@@ -66,7 +66,7 @@ def test_product_libraries_do_not_link_the_oracle(libs):
 def test_abi_version(libs):
     hdr = open(os.path.join(ROOT, "include", "lbfgs_hip.h")).read()
     want = int(re.search(r"#define LBFGS_HIP_ABI_VERSION (\d+)", hdr).group(1))
-    assert want == 4
+    assert want == 5
     assert libs[0].lbfgs_hip_abi_version() == want == _ffi.ABI_VERSION
     # the other callers written against the header compare before anything else
     assert re.search(r"pub const LBFGS_HIP_ABI_VERSION: i32 = %d;" % want, open(RUST_FFI).read())
@@ -226,6 +226,23 @@ def test_rust_shim_uses_only_what_its_ffi_module_declares():
         assert sorted(named) == sorted(f for f, _ in rs[name]), (name, named)
         literals += 1
     assert literals >= 3  # the evaluator (twice) and the objective
+
+
+def test_rust_shim_shows_the_lbfgsmath_seam(libs):
+    """BASELINE.json's north star names the seam: "the vector primitives in src/math.rs ... through a thin extern "C" FFI".  The
+    shim carries it as `impl LbfgsMath for DeviceVec` -- the reference trait's eight methods (src/math.rs:4-29), each over the
+    library's symbol of the same name, which must exist in the built library and be declared in ffi.rs (uncompiled: no rustc)."""
+    lib = open(os.path.join(os.path.dirname(RUST_FFI), "lib.rs")).read()
+    ffi = open(RUST_FFI).read()
+    impl = lib[lib.index("impl<'c> LbfgsMath for DeviceVec<'c>"):]
+    impl = impl[:impl.index("\n}\n") + 3]
+    for method in ("vecadd", "vecdot", "veccpy", "vecncpy", "vecdiff", "vecscale", "vec2norm", "vec2norminv"):
+        assert re.search(r"fn %s\(" % method, impl), method
+        sym = "lbfgs_hip_" + method
+        assert "ffi::%s(" % sym in impl and re.search(r"pub fn %s\(" % sym, ffi), sym
+        assert hasattr(libs[0], sym)
+    trait = lib[lib.index("pub trait LbfgsMath {"):lib.index("const MATH_SLOT")]
+    assert len(re.findall(r"\bfn \w+\(", trait)) == 8
 
 
 def test_no_kernel_uses_scratch_memory(libs):

@@ -267,8 +267,11 @@ def test_eight_ranks_as_in_the_metric(tmp_path):
 # bench.py's N > 1 supervisor: rank processes run on the test double (tests/support/bench_on_mock.py)
 # ------------------------------------------------------------------------------------------------------------
 def _run_bench(extra_args, launcher, legs=None, timeout=300):
+    # (these tests are about the supervisor and a double WITHOUT communicators of its own: its shared-memory stand-ins of P2P and
+    # RCCL -- round 6 -- stay off here; tests that want them ask for them)
     env = dict(os.environ, LBFGS_BENCH_WORKER=os.path.join(ROOT, "tests", "support", "bench_on_mock.py"),
-               OMP_NUM_THREADS="1")
+               OMP_NUM_THREADS="1", LBFGS_MOCK_NO_P2P="1")
+    env.pop("LBFGS_MOCK_RCCL", None)
     if legs:
         env["LBFGS_BENCH_LEGS"] = legs
     args = ["--gpus", "2", "--steps", "4", "--warmup", "12", "--dim", "3000", "--hist", "5", "--repeats", "2",

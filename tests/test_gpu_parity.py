@@ -997,7 +997,30 @@ def test_fused_owlqn_kernels_equal_their_unfused_sequences(n):
                 assert np.array_equal(got.to_numpy(), want.to_numpy(), equal_nan=True)
             for a, b in zip(first, ref):
                 assert abs(a - b) <= 1e-12 * max(abs(b), 1e-300), (first, ref)
-            for v in (x3, g3, pg3, wp3, wp_ref, pgp):
+            # (round 6) a trial that ALSO does IterationData::update for its point (lbfgs.rs:640-656): s, y into the history slot,
+            # ||s||^2, y.s, y.y on the board -- against the trial followed by the update's own kernel, both forms of the trial
+            hist_f, hist_r = H.History(ctx, 3), H.History(ctx, 3)
+            gp_h = rnd(n, 45)
+            gpv = DeviceVec(ctx, gp_h)
+            x4, g4, pg4, wp4 = (DeviceVec(ctx) for _ in range(4))
+            for first in (False, True):
+                if first:
+                    pg4.upload(pg_prev); pg2.upload(pg_prev)
+                    H.objective_owlqn_trial_update(obj, hist_f, 1, x4, xp, d, 0.37, wp4, True, g4, gpv, pg4, c, start, end, 80, 90)
+                    H.objective_owlqn_first_trial(obj, x2, xp, d, 0.37, wp_ref, g2, pg2, c, start, end, 100)
+                    assert np.array_equal(wp4.to_numpy(), wp_ref.to_numpy())
+                else:
+                    H.objective_owlqn_trial_update(obj, hist_f, 1, x4, xp, d, 0.37, wp, False, g4, gpv, pg4, c, start, end, 80, 90)
+                    H.objective_owlqn_line_eval(obj, x2, xp, d, 0.37, wp, g2, pg2, c, start, end, 100)
+                hist_r.update(1, x2, xp, g2, gpv, 0.37, False, 110)
+                for got, want in ((x4, x2), (g4, g2), (pg4, pg2), (hist_f.s(1), hist_r.s(1)), (hist_f.y(1), hist_r.y(1))):
+                    assert np.array_equal(got.to_numpy(), want.to_numpy(), equal_nan=True)
+                for a, b in zip(list(ctx.scalars(80, 5)) + list(ctx.scalars(90, 3)), list(ctx.scalars(100, 5)) + list(ctx.scalars(110, 3))):
+                    assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-12 * max(abs(b), 1e-300), (first, a, b)
+                ysf, ysr = hist_f.scalars()[0][1], hist_r.scalars()[0][1]
+                assert (np.isnan(ysf) and np.isnan(ysr)) or abs(ysf - ysr) <= 1e-12 * max(abs(ysr), 1e-300)   # lbfgs.rs:656
+            hist_f.free(); hist_r.free()
+            for v in (x3, g3, pg3, wp3, wp_ref, pgp, gpv, x4, g4, pg4, wp4):
                 v.free()
         # two-loop with the projection folded in
         m = 5
