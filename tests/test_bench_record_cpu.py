@@ -261,8 +261,8 @@ def _fake_rocprof(tmp_path, monkeypatch, mode="ok"):
     exe.chmod(0o755)
     monkeypatch.setenv("PATH", str(exe.parent) + os.pathsep + os.environ["PATH"])
     monkeypatch.setenv("FAKE_ROCPROF_MODE", mode)
-    monkeypatch.setenv("FAKE_ROCPROF_ROWS_FETCH_SIZE", os.path.join(ROOT, "profiles", "r05_pmc_fetch_counter_collection.csv"))
-    monkeypatch.setenv("FAKE_ROCPROF_ROWS_WRITE_SIZE", os.path.join(ROOT, "profiles", "r05_pmc_write_counter_collection.csv"))
+    monkeypatch.setenv("FAKE_ROCPROF_ROWS_FETCH_SIZE", os.path.join(ROOT, "profiles", "r06_pmc_fetch_counter_collection.csv"))
+    monkeypatch.setenv("FAKE_ROCPROF_ROWS_WRITE_SIZE", os.path.join(ROOT, "profiles", "r06_pmc_write_counter_collection.csv"))
 
 
 def _args(**kw):
@@ -344,8 +344,8 @@ def _n1_on_the_test_double(tmp_path, mode, extra_env=None, extra_args=()):
     exe.chmod(0o755)
     env = dict(os.environ, OMP_NUM_THREADS="1", LBFGS_BENCH_LIVE_TRAFFIC="force", FAKE_ROCPROF_MODE=mode, LBFGS_MOCK_FAKE_KERNEL_TIMES="1",
                PATH=str(exe.parent) + os.pathsep + os.environ["PATH"],
-               FAKE_ROCPROF_ROWS_FETCH_SIZE=os.path.join(ROOT, "profiles", "r05_pmc_fetch_counter_collection.csv"),
-               FAKE_ROCPROF_ROWS_WRITE_SIZE=os.path.join(ROOT, "profiles", "r05_pmc_write_counter_collection.csv"))
+               FAKE_ROCPROF_ROWS_FETCH_SIZE=os.path.join(ROOT, "profiles", "r06_pmc_fetch_counter_collection.csv"),
+               FAKE_ROCPROF_ROWS_WRITE_SIZE=os.path.join(ROOT, "profiles", "r06_pmc_write_counter_collection.csv"))
     for k in list(env):
         if k.startswith(("ROCPROF", "ROCP_")) or k in ("RANK", "WORLD_SIZE"):
             del env[k]
