@@ -38,7 +38,7 @@ PASSES = [
     (r"OpNorms2", (2, 0), "norms"),
     (r"OpCopy<", (1, 1), "copy / ncopy"),
     # OWL-QN (config 3)
-    (r"OpObjOwlLineEval<.*, true, true>", (4, 6), "FIRST OWL-QN trial of a search that also does IterationData::update for its point (lbfgs.rs:640-656: s, y, ||s||^2, y.s, y.y): orthant + line step + projection + eval + x1norm + pseudo-gradient + g.d + update"),
+    (r"OpObjOwlLineEval<.*, true, true>", (4, 6), "FIRST OWL-QN trial of a search that also does IterationData::update for its point (lbfgs.rs:640-656: s, y, s.s, y.s, y.y): orthant + line step + projection + eval + x1norm + pseudo-gradient + g.d + update"),
     (r"OpObjOwlLineEval<.*, false, true>", (4, 5), "OWL-QN trial that also does IterationData::update for its point (lbfgs.rs:640-656)"),
     (r"OpObjOwlLineEval<.*, true, false>", (3, 4), "FIRST OWL-QN trial of a search: the orthant of the new point (core.rs:167-180) + line step + projection + eval + x1norm + pseudo-gradient + g.d"),
     (r"OpObjOwlLineEval<.*, false, false>", (3, 3), "OWL-QN trial: line step + projection + eval + x1norm + pseudo-gradient + g.d (orthantwise.rs:70-133)"),
