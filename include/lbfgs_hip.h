@@ -93,10 +93,14 @@ typedef struct lbfgs_hip_comm {
                                     library is built for).  Only then may a kernel that occupies the WHOLE chip while it waits
                                     for its peers be used (the on-chip-resident two-loop, rust-lbfgs_amd/csrc/resident.h): ranks
                                     that share a GPU would keep each other from running.  0 = assume the GPU may be shared.
-                                    (RCCL: that kernel's all-reduces then run gated on a second stream the context owns;
-                                    lbfgs_hip_ctx_create is collective -- same value, and same LBFGS_HIP_RCCL_RESIDENT, on every rank:
-                                    it tries one such exchange under a chip-wide kernel on this communicator and the ranks agree on
-                                    the outcome; if any rank fails, every rank runs the two-loop with a kernel per step and says so.) */
+                                    (RCCL: only with LBFGS_HIP_RCCL_RESIDENT=1 in the environment as well -- opt-in, round 6: that form
+                                    has never run with more than one rank.  The kernel's all-reduces then run gated on a second stream
+                                    the context owns, and lbfgs_hip_ctx_create is collective -- same value, and same
+                                    LBFGS_HIP_RCCL_RESIDENT, on every rank: the ranks vote on every rank's stream handshake and shard /
+                                    device eligibility, try one such exchange under a chip-wide kernel on this communicator and vote
+                                    on the outcome; if any rank fails, every rank runs the two-loop with a kernel per step and says so;
+                                    a rank that fails locally in between still makes every collective and gets its error afterwards:
+                                    rust-lbfgs_amd/csrc/ext_protocol.h.) */
     const void* rccl_unique_id;  /* 128 bytes from lbfgs_hip_rccl_unique_id() on rank 0, shared out of band */
     lbfgs_hip_allreduce_cb callback;
     void* callback_user;

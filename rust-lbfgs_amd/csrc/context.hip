@@ -239,9 +239,11 @@ __global__ __launch_bounds__(64) void p2p_allreduce_kernel(const P2PArgs a) {
     if ((int)threadIdx.x < a.count) *a.val[threadIdx.x] = vals[threadIdx.x];
     if (threadIdx.x == 0) {
         a.ctr->p2p_epoch = next_epoch(epoch);
-        x.p2p_ticks += (unsigned long long)(wall_clock64() - t1);
+        const unsigned long long dt_x = (unsigned long long)(wall_clock64() - t1);
+        x.p2p_ticks += dt_x;
         x.count += 1ull;
         *xs = x;
+        xchg_dist_note(a.ctr, a.xchg_class, dt_x, 0ull);  // (every timed exchange is in a bin of the histogram)
     }
 }
 
@@ -475,6 +477,7 @@ void ext_abort(lbfgs_hip_ctx* ctx) {
     }
 }
 int rccl_allreduce_on(lbfgs_hip_ctx* ctx, double* buf, int count, hipStream_t stream) {
+    if (!ctx->nccl) return fail(ctx, LBFGS_HIP_ERR_COMM, "the RCCL communicator of this context was aborted (a gated chain did not drain)");
     const int rc = g_rccl.AllReduce(buf, buf, (size_t)count, kNcclDouble, kNcclSum, ctx->nccl, stream);
     if (rc != 0) return fail(ctx, LBFGS_HIP_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString(rc));
     return LBFGS_HIP_OK;
@@ -504,6 +507,7 @@ int allreduce(lbfgs_hip_ctx* ctx, double* const* ptrs, int count) {
     ctx->allreduce_calls += 1;
     if (ctx->xchg_class && ctx->comm_kind != LBFGS_HIP_COMM_P2P) ctx->two_loop_exchanges += 1;  // (P2P: next_p2p counts)
     if (ctx->comm_kind == LBFGS_HIP_COMM_RCCL) {
+        if (!ctx->nccl) return fail(ctx, LBFGS_HIP_ERR_COMM, "the RCCL communicator of this context was aborted (a gated chain did not drain)");
         // coalesce runs of consecutive addresses into one message each; group them into one launch
         int rc = g_rccl.GroupStart();
         if (rc != 0) return fail(ctx, LBFGS_HIP_ERR_COMM, "ncclGroupStart: %s", g_rccl.GetErrorString(rc));

@@ -394,7 +394,10 @@ struct LogisticMath {
         p = __builtin_fma(p, r, 0x1.5555555555556p-3);
         p = __builtin_fma(p, r, 0x1.0000000000001p-1);
         const double q = __builtin_fma(r * r, p, r);
-        const double e = __builtin_amdgcn_ldexp(1.0 + q, (int)kf);
+        // k as an integer without a float-to-int conversion (of a NaN it would be undefined): kf + 1.5 * 2^52 carries k, two's
+        // complement, in the low word of the sum (|k| <= 1155); a NaN stays a NaN through the ldexp whatever that word holds
+        const int k = __double2loint(kf + 0x1.8p52);
+        const double e = __builtin_amdgcn_ldexp(1.0 + q, k);
         const double u = 1.0 + e;
         const bool big = e > 0x1.a827999fcef32p-2;             // u > sqrt 2
         const double kk = big ? 1.0 : 0.0;

@@ -21,7 +21,8 @@ static void fast(double z, double* sp, double* sig) {
     double p = EP[9];
     for (int i = 8; i >= 0; --i) p = fma(p, r, EP[i]);
     double q = fma(r * r, p, r);
-    double e = ldexp(1.0 + q, (int)kf);
+    union { double d; int32_t w[2]; } kb; kb.d = kf + 0x1.8p52;   /* k from the low word of kf + 1.5 * 2^52 (no conversion of a NaN) */
+    double e = ldexp(1.0 + q, kb.w[0]);
     double u = 1.0 + e;
     int big = e > SQRT2M1;
     double kk = big ? 1.0 : 0.0;
