@@ -657,8 +657,9 @@ int line_search_find(lbfgs_state* st, double& step, uint64_t* ncall, bool may_de
     // OWL-QN (always backtracking: line.rs:204-211): the trials do the history update themselves.  Not with Powell damping (its
     // s.bs would be a ninth sum of that kernel), not for the stand-alone line search (no history).
     st->update_done = false;
+    static const bool trial_update_off = getenv("LBFGS_OWL_TRIAL_UPDATE") != nullptr && atoi(getenv("LBFGS_OWL_TRIAL_UPDATE")) == 0;  // (A/B, diagnostics)
     st->update_in_trials = may_defer && st->owlqn() && st->eval.kind == LBFGS_EVAL_BUILTIN && st->eval.fuse_line_eval != 0 &&
-                           !st->vars.damping && st->hist != nullptr;
+                           !st->vars.damping && st->hist != nullptr && !trial_update_off;
     struct Reset {
         lbfgs_state* s;
         ~Reset() { s->defer_trials = false; s->update_in_trials = false; }

@@ -369,13 +369,18 @@ struct ObjQuadratic {  // f_i = x*(0.5*a*x - b), g_i = a*x - b ; a = 1 + 999*u^2
 // benchmark objective of BASELINE config 3 (the CALLER's closure kept on the device, not the reference's path; the oracle's
 // restatement, oracle/objectives.c, calls glibc).  ocml's exp + log1p + an IEEE division cost ~170 issue slots per element and
 // made every kernel that evaluates this objective ALU-bound at 2.4 TB/s (profiles/r05_probe_alu_check.log); this form takes
-// ~55: within 6e-16 of the exact value (softplus) / 4.8e-16 (sigma) over |z| <= 745, mean 5e-17 / 7e-17 -- glibc's own
+// ~60: within 4.2e-16 of the exact value (softplus) / 3.6e-16 (sigma) over |z| <= 745, mean 5e-17 / 6e-17 -- glibc's own
 // sequence: 2.2e-16 / 3.3e-16 (tools/logistic_math_check.c emulates it bit for bit on the host; tests hold the device to it).
+// (Both quotients are refined once against their exact residuals: without that -- 6.0e-16 / 4.8e-16, five operations fewer --
+// two of 12 000 random logistic runs left the calibrated free-running bar of the test suite, profiles/r06_fuzz_soak*.log.)
 //   e = exp(-|z|):      k = rint(t log2 e), r = t - k ln2 (two-part ln2: k ln2_hi exact), e = 2^k (1 + r + r^2 P9(r))
 //   u = 1 + e in (1,2]: u > sqrt 2 ? (N, D, kk) = (e - 1, e + 3, 1) : (e, e + 2, 0), so that s = N / D = (m-1)/(m+1) with
 //                       m = u / 2^kk in (0.707, 1.414]: log u = kk ln2 + 2 atanh s = kk ln2 + 2 s + s^3 Q6(s^2), |s| <= 0.1716
-//   ONE reciprocal:     w = 1 / (u D) (v_rcp_f64 + one third-order step); 1/u = D w; s = N u w
+//   ONE reciprocal:     w = 1 / (u D) (v_rcp_f64 + one third-order step); 1/u = D w; s = N u w; each refined once (fma residual)
 // NaN propagates through every step; z = +-inf, +-0 and |z| > 745 (e denormal or 0) give the oracle's values exactly.
+#ifndef LH_LOGISTIC_REFINE
+#define LH_LOGISTIC_REFINE 1  // 0: the quotients as they come (~2.5 ulp): 5 operations fewer, 6.0e-16 / 4.8e-16 (A/B builds)
+#endif
 struct LogisticMath {
     __device__ static __forceinline__ void eval(const double z, double& softplus, double& sigma) {
         double t = -__builtin_fabs(z);
@@ -407,8 +412,13 @@ struct LogisticMath {
         double w = __builtin_amdgcn_rcp(pd);                    // ~2^-23 (measured: tests/test_gpu_parity.py holds the result to 2e-15)
         const double e0 = __builtin_fma(-pd, w, 1.0);
         w = __builtin_fma(w, __builtin_fma(e0, e0, e0), w);     // one third-order step: w (1 + e0 + e0^2), error e0^3
-        const double inv_u = D * w;
-        const double s = (N * u) * w;
+        double inv_u = D * w;
+        double s = (N * u) * w;
+#if LH_LOGISTIC_REFINE
+        // both quotients once more against their exact residuals (fma): 1/u and s = N/D to ~1 ulp instead of ~2.5
+        inv_u = __builtin_fma(inv_u, __builtin_fma(-u, inv_u, 1.0), inv_u);
+        s = __builtin_fma(__builtin_fma(-D, s, N), u * w, s);
+#endif
         const double s2 = s * s;
         double l = 0x1.2b5f68a50d903p-3;
         l = __builtin_fma(l, s2, 0x1.39fdcceb4bb45p-3);

@@ -34,6 +34,10 @@ static void fast(double z, double* sp, double* sig) {
     w = fma(w, fma(e0, e0, e0), w);
     double inv_u = D * w;
     double s = (N * u) * w;
+#ifndef NO_REFINE                                             /* ops.h LH_LOGISTIC_REFINE (default 1) */
+    inv_u = fma(inv_u, fma(-u, inv_u, 1.0), inv_u);          /* 1/u once more against its exact residual */
+    s = fma(fma(-D, s, N), u * w, s);                         /* s += (N - D s) / D with 1/D ~ u w */
+#endif
     double ww = s * s;
     double qq = LQ[6];
     for (int i = 5; i >= 0; --i) qq = fma(qq, ww, LQ[i]);
