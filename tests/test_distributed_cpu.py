@@ -32,7 +32,9 @@ n = case["n"]
 bounds = json.loads(os.environ.get("LBFGS_TEST_BOUNDS", "null"))     # uneven shards: [0, b1, ..., n]
 if os.environ.get("LBFGS_TEST_RESIDENT_GRIDS"):                      # workgroups of the resident kernel, per rank
     os.environ["LBFGS_HIP_RESIDENT_GRID"] = os.environ["LBFGS_TEST_RESIDENT_GRIDS"].split(",")[rank]
-ctx = D.sharded_context(n, kind=os.environ.get("LBFGS_COMM_KIND", "callback"),
+# (LBFGS_TEST_DEVICE_PER_RANK=1: one GPU per rank, as on a real node -- tests/test_gpu_multi_device.py; otherwise device 0)
+dev = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("LBFGS_TEST_DEVICE_PER_RANK") == "1" else 0
+ctx = D.sharded_context(n, device=dev, kind=os.environ.get("LBFGS_COMM_KIND", "callback"),
                         exclusive_device=os.environ.get("LBFGS_TEST_EXCLUSIVE_DEVICE") == "1", bounds=bounds)
 lo, hi = (bounds[rank], bounds[rank + 1]) if bounds else D.shard_range(n, rank, world)
 assert ctx.n_local == hi - lo and ctx.shard.offset == lo
